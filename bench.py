@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — IFCB images/sec of the CNN classification hot path on MI355X.
+
+One "step" = one pass of the hot path over one per-GPU batch of synthetic
+224x224x3 ROIs through ResNet-50 (+ the reference's 256,128,50 head):
+  infer: net_pass body (forward + base-1.3 softmax), reference
+         sykepic/compute/probability.py:184-194
+  train: zero_grad/forward/CE/backward/step, reference sykepic/train/train.py:239-243
+Inputs are resident in HBM before the timed region.  Weak scaling: every rank
+runs the same per-GPU batch (inference needs no collective; training
+all-reduces the flat gradient buffer over RCCL).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel
+(conv_igemm_kernel): algorithmic conv FLOPs / its HIP-event time.  The
+`cpu_baseline` leg times the oracle (torch fp32 CPU restatement of the
+reference path) on this box's host cores on a bounded sample.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--network", default="resnet50")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--classes", type=int, default=50)
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"])
+    ap.add_argument("--precision", default="precise", choices=["precise", "fast", "bf16"],
+                    help="precise: fp16 + hi/lo split weights (passes the 1e-3 parity tolerance); "
+                         "fast: plain fp16; bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
+    return ap.parse_args()
+
+
+def cpu_baseline(network, classes, size, mode, budget_s):
+    """The reference's CPU path (torch fp32 NCHW kernels driven by the
+    net_pass / train-step logic) timed on this host; oracle = its restatement."""
+    from oracle import refnet
+    from sykepic_hip import arch, synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    g = arch.build_graph(network, classes)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    net = refnet.load_numpy_state(refnet.RefNet(network, classes), sd)
+    bs = 32
+    x = torch.from_numpy(synth.synth_images(bs, 3, size, size, seed=0))
+    y = torch.from_numpy(synth.synth_labels(bs, classes, seed=1))
+    if mode == "train":
+        net.train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        step = lambda: refnet.train_step(net, opt, x, y)  # noqa: E731
+    else:
+        step = lambda: refnet.probabilities(net, x)  # noqa: E731
+    step()  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        step()
+        iters += 1
+        if time.perf_counter() - t0 > budget_s or iters >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} x batch {bs} of {network} {mode} fp32 NCHW on host CPU "
+                      f"({iters * bs} images, {dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from sykepic_hip import arch, synth
+    from sykepic_hip.net import HipNet
+
+    g = arch.build_graph(args.network, args.classes)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    net = HipNet(args.network, args.classes, weights=None, device=dev)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    if args.precision == "bf16":
+        net.set_precision(split_weights=False, bf16=True)
+    else:
+        net.set_precision(split_weights=(args.precision == "precise"))
+    # same generator, different seed per rank: every rank has its own shard
+    x = torch.from_numpy(synth.synth_images(args.batch, 3, args.size, args.size, seed=rank)).to(dev)
+    y = torch.from_numpy(synth.synth_labels(args.batch, args.classes, seed=1000 + rank)).to(dev)
+
+    if args.mode == "train":
+        from sykepic_hip.optim import HipOptimizer
+        from sykepic_hip.dp import GradSync
+        net.train()
+        for p in net.parameters():   # post-step_3 state: everything unfrozen (most expensive phase)
+            p.requires_grad = True
+        opt = HipOptimizer(net, "Adam", [
+            {"params": [p for p in net.parameters()], "lr": 1e-4}, {"params": [], "lr": 0.0},
+            {"params": [], "lr": 0.0}])
+        sync = GradSync(net, dist) if world > 1 else None
+
+        def step():
+            net.forward_backward(x, y)
+            if sync:
+                sync.all_reduce()
+            opt.step()
+        dtype = "bf16"
+    else:
+        net.eval()
+
+        def step():
+            return net.probabilities(x)
+        dtype = "bf16" if args.precision == "bf16" else "f16"
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream ----
+    roof = None
+    layers = []
+    if rank == 0 and args.mode == "infer":
+        layers = net.profile_layers(x, iters=5)
+        conv = [(n, ms, fl, by) for n, ms, fl, by in layers if fl > 0 and not n.startswith("head.")]
+        conv_ms = sum(ms for _, ms, _, _ in conv)
+        conv_fl = sum(fl for _, _, fl, _ in conv)
+        all_ms = sum(ms for _, ms, _, _ in layers)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
+                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
+                "hbm_GBs_algorithmic": round(sum(by for _, _, _, by in layers) / (all_ms * 1e-3) / 1e9, 1)}
+        if args.layers_out:
+            Path(args.layers_out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.layers_out).write_text(json.dumps(
+                [{"layer": n, "ms": round(ms, 4), "gflop": round(fl / 1e9, 3), "mbytes": round(by / 1e6, 2),
+                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+                  "gbs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+                 for n, ms, fl, by in layers], indent=1))
+
+    if rank == 0:
+        total_images = args.batch * world * args.steps
+        out = {
+            "metric": f"IFCB images/sec, {args.network} 224x224 {args.mode} step",
+            "value": round(total_images / dt, 1), "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": f"{args.network}_{args.mode}_b{args.batch}x{world}_"
+                                   f"{args.size}x{args.size}x3_{args.classes}cls_head256-128",
+                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                       "precision": args.precision if args.mode == "infer" else "bf16",
+                       "parallelism": f"dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.network, args.classes, args.size, args.mode,
+                                               args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

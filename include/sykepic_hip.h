@@ -1,0 +1,183 @@
+/*
+ * sykepic_hip.h — C-ABI of libsykepic_hip.so: the MI355X (gfx950) replacement
+ * for the CNN classification hot path of sykefi/syke-pic.
+ *
+ * The reference has no FFI: its seam is Python duck-typing on three objects,
+ * each created in exactly one place (paths relative to
+ * /root/reference):
+ *   - the network          sykepic/train/config.py:63-77  (TorchVisionNet(...))
+ *   - the loss             sykepic/train/train.py:127     (nn.CrossEntropyLoss())
+ *   - the optimizer        sykepic/train/train.py:131-138 (getattr(optim, name)([...]))
+ * and everything heavy happens at two call sites:
+ *   - inference  `out = net(x)` + base-1.3 softmax   sykepic/compute/probability.py:189-194
+ *   - training   zero_grad/forward/loss/backward/step sykepic/train/train.py:239-243
+ * Each entry point below names the reference lines it stands in for.  The
+ * Python adapter (syke-pic_amd/sykepic_hip/lib.py) binds them with ctypes.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer it
+ * passes; the library owns weights, activations, gradients and workspace
+ * inside the handle; no exception crosses the boundary (0 = ok, <0 = error,
+ * text via spk_last_error()).  Host-facing parameter I/O always uses the
+ * reference's on-disk layout (NCHW / [out,in] float32, int64 counters) so a
+ * best_state.pth stays interchangeable.  Device pointers are HIP device
+ * memory on the model's device; work is enqueued on the model's stream
+ * (spk_model_set_stream) and is asynchronous unless stated.
+ */
+#ifndef SYKEPIC_HIP_H
+#define SYKEPIC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPK_OK 0
+#define SPK_ERR_ARG (-1)
+#define SPK_ERR_HIP (-2)
+#define SPK_ERR_KEY (-3)
+#define SPK_ERR_UNSUPPORTED (-4)
+#define SPK_ERR_STATE (-5)
+
+/* layer kinds of spk_layer_desc.kind */
+#define SPK_OP_CONV 1      /* Conv2d(bias=False) + BatchNorm2d (+residual) (+ReLU) */
+#define SPK_OP_MAXPOOL 2   /* MaxPool2d(k, stride, pad) */
+#define SPK_OP_GAVGPOOL 3  /* AdaptiveAvgPool2d(1) + flatten */
+#define SPK_OP_LINEAR 4    /* Linear with bias, no activation (head) */
+#define SPK_OP_DROPOUT 5   /* Dropout(p) in the head */
+
+/* input layouts / dtypes of the image batch */
+#define SPK_LAYOUT_NCHW 0
+#define SPK_LAYOUT_NHWC 1
+#define SPK_DTYPE_F32 0
+#define SPK_DTYPE_I64 1
+#define SPK_DTYPE_U8 2
+
+/* optimizers (reference: any torch.optim class by name; Adam is the default,
+ * train.ini.example:74) */
+#define SPK_OPT_SGD 0
+#define SPK_OPT_ADAM 1
+
+typedef struct spk_model spk_model;
+
+/* One node of the layer graph that TorchVisionNet.__init__ builds
+ * (sykepic/train/network.py:48-63): backbone children minus the last one,
+ * then the Linear head.  `name`/`bn` are state_dict prefixes ("base.4.0.conv1",
+ * "base.4.0.bn1", "head.0"). src/dst/res are activation ids (0 = input). */
+typedef struct {
+  int32_t kind;
+  int32_t cin, cout, k, stride, pad;
+  int32_t relu;
+  int32_t src, dst, res;
+  int32_t child; /* index of the owning child of `base`; -1 for the head */
+  float p;       /* dropout probability */
+  char name[96];
+  char bn[96];
+} spk_layer_desc;
+
+/* Hyper-parameters of one optimizer step; lr per param group as kept by
+ * LRWarmup (sykepic/train/network.py:98-130). */
+typedef struct {
+  int32_t kind;     /* SPK_OPT_* */
+  float lr[3];
+  float beta1, beta2, eps;  /* Adam */
+  float weight_decay;
+  float momentum;           /* SGD */
+  float grad_scale;         /* multiplies every gradient first (1/world for DP mean) */
+} spk_optim_desc;
+
+const char* spk_last_error(void);
+const char* spk_version(void);
+
+/* TorchVisionNet(...) construction — sykepic/train/config.py:63-77,
+ * sykepic/train/network.py:14-64.  Weights start at zero; load them with
+ * spk_model_load_param. */
+int spk_model_create(const spk_layer_desc* layers, int n_layers, int in_chans,
+                     int num_classes, int device, spk_model** out);
+void spk_model_destroy(spk_model* m);
+/* net.to(device) has no counterpart (the handle lives on one GPU); the
+ * stream is a hipStream_t (0 = default stream). */
+int spk_model_set_stream(spk_model* m, void* hip_stream);
+
+/* state_dict()/load_state_dict() — sykepic/train/train.py:300,179,
+ * sykepic/compute/probability.py:129.  Enumerates tensors in torch's
+ * state_dict order. dtype is SPK_DTYPE_F32 or SPK_DTYPE_I64
+ * (num_batches_tracked). Synchronous. */
+int spk_model_num_params(spk_model* m);
+int spk_model_param_info(spk_model* m, int idx, char* key, int key_cap,
+                         int64_t shape[4], int* ndim, int* dtype);
+int spk_model_load_param(spk_model* m, const char* key, const void* host, int64_t numel);
+int spk_model_read_param(spk_model* m, const char* key, void* host, int64_t numel);
+
+/* param.requires_grad = flag — sykepic/train/network.py:133-172 */
+int spk_model_set_requires_grad(spk_model* m, const char* key, int flag);
+/* optimizer.param_groups[group]["params"] membership (group -1: not in the
+ * optimizer) — sykepic/train/train.py:131-138, network.py:108-128 */
+int spk_model_set_param_group(spk_model* m, const char* key, int group);
+/* 16-bit storage/MFMA input type of the eval path: 0 = fp16 (default; the
+ * 1e-3 probability tolerance needs its 11-bit mantissa), 1 = bf16. fp32
+ * accumulation either way. Training always runs bf16. */
+int spk_model_set_infer_dtype(spk_model* m, int bf16);
+/* Precision knobs of the fp16 eval path (defaults: split_weights = 1,
+ * precise_residual = 0).  split_weights: every conv weight is carried as
+ * hi + lo fp16 halves and both products are accumulated (2x MFMA work, weight
+ * rounding error ~2^-22) — weight rounding is the dominant logit error at
+ * 16-bit storage.  precise_residual: shortcut tensors keep their fp16
+ * rounding remainder for the residual add (+2 B/element of shortcut traffic). */
+int spk_model_set_precision(spk_model* m, int split_weights, int precise_residual);
+/* Dropout mask seed for training steps. */
+int spk_model_set_seed(spk_model* m, uint64_t seed);
+
+/* net.eval(); out = net(x); softmax(out * ln(base)) — the body of net_pass,
+ * sykepic/compute/probability.py:184-194.  x: n images h x w of the model's
+ * in_chans; out: float32 [n, num_classes] device buffer.  softmax_base <= 0
+ * returns raw logits (test_net / val loop, sykepic/train/train.py:265,338). */
+int spk_forward_infer(spk_model* m, const void* x_dev, int n, int h, int w, int layout,
+                      int dtype, float softmax_base, float* out_dev);
+
+/* net.eval() forward + CrossEntropyLoss + arg-max accuracy — the validation
+ * loop body, sykepic/train/train.py:262-270.  stats_dev: float32[2] device
+ * buffer, ACCUMULATED: stats[0] += loss*n, stats[1] += #correct.  logits_dev
+ * may be NULL. */
+int spk_eval_step(spk_model* m, const void* x_dev, int n, int h, int w, int layout, int dtype,
+                  const int64_t* y_dev, float* stats_dev, float* logits_dev);
+
+/* net.train(); optimizer.zero_grad(); out = net(x); loss = CE(out, y);
+ * loss.backward() — sykepic/train/train.py:233,239-242.  Train-mode BatchNorm
+ * (batch statistics, running-stat update, num_batches_tracked += 1).
+ * Gradients land in the flat buffer of spk_model_grad_buffer; stats_dev as
+ * in spk_eval_step (train.py:244-247). */
+int spk_train_forward_backward(spk_model* m, const void* x_dev, int n, int h, int w, int layout,
+                               int dtype, const int64_t* y_dev, float* stats_dev,
+                               float* logits_dev);
+/* optimizer.step() — sykepic/train/train.py:243 */
+int spk_optim_step(spk_model* m, const spk_optim_desc* opt);
+
+/* Flat float32 gradient buffer covering every trainable tensor (device
+ * pointer, element count): what a data-parallel caller all-reduces over RCCL
+ * between spk_train_forward_backward and spk_optim_step. */
+int spk_model_grad_buffer(spk_model* m, void** dev_ptr, int64_t* numel);
+/* Gradient of one tensor, copied to host in state_dict layout (tests). */
+int spk_model_read_grad(spk_model* m, const char* key, void* host, int64_t numel);
+
+/* Test hook: copy activation `tensor_id` (spk_layer_desc.dst numbering) of the
+ * most recent forward to the host as float32 NCHW ([n,c,h,w]; [n,c] for the
+ * head).  The stem input (id 0) is not readable.  Synchronous. */
+int spk_model_read_activation(spk_model* m, int tensor_id, int n, float* host, int64_t numel);
+
+/* Per-layer timing of the last spk_forward_infer call (HIP events on the
+ * model's stream); used by bench.py for the roofline line. Returns the
+ * number of records written. */
+typedef struct {
+  char name[96];
+  float ms;
+  double flops;
+  double bytes;
+} spk_layer_time;
+int spk_model_profile_infer(spk_model* m, const void* x_dev, int n, int h, int w, int layout,
+                            int dtype, int iters, spk_layer_time* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

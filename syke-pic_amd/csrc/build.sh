@@ -1,0 +1,20 @@
+#!/bin/bash
+# Builds libsykepic_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../sykepic_hip/libsykepic_hip.so
+SRCS="model.hip train.hip conv_igemm.hip pointwise.hip head.hip"
+mkdir -p build
+pids=()
+for f in $SRCS; do
+  o=build/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ spk_common.h -nt "$o" ] || [ model.h -nt "$o" ] || [ ../../include/sykepic_hip.h -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+objs=""
+for f in $SRCS; do objs="$objs build/${f%.hip}.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC $objs -o "$OUT"
+echo "built $OUT"

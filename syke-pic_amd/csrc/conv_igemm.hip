@@ -1,0 +1,382 @@
+// Implicit-GEMM 2-D convolution for gfx950 (MI355X), bf16 in / fp32 accumulate.
+//
+// Stands in for the torch Conv2d+BatchNorm2d(+add)(+ReLU) chains that the
+// reference reaches through `net(x)` (sykepic/compute/probability.py:189,
+// sykepic/train/train.py:240) — SURVEY.md §2.2.
+//
+// GEMM view: M = N*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin with the
+// filter tap major and the channel minor, so that every 16-byte chunk of K is
+// 8 consecutive channels of ONE input pixel: NHWC activations are read with
+// coalesced 16-B buffer loads, padding taps are dropped by the buffer range
+// check (voffset past num_records reads as zero) — no divergent branches.
+// Tiles are staged through LDS (XOR-swizzled 128-B rows, conflict-free for the
+// 16x16x32 operand reads), double buffered, one barrier per 64-deep K step;
+// v_mfma_f32_16x16x32_bf16 accumulates in fp32.  The epilogue goes back
+// through LDS so that BN scale/shift, the residual add, ReLU and the bf16
+// rounding happen on whole 16-B row segments and the stores are full lines.
+//
+// Block -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous run
+// of tiles, N-tiles of one M-tile adjacent, so the activation tile a block
+// streams is an L2 hit for its neighbour.
+#include "spk_common.h"
+
+namespace {
+
+constexpr int BK = 64;            // K elements per LDS stage
+constexpr int ROW_BYTES = BK * 2; // 128-B LDS rows
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  // 16-B chunk swizzle: rows r and r^1 share a 256-B bank row; (row>>1)&7
+  // spreads 16 consecutive rows of one chunk column over all 16 slots.
+  return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvArgs a, int m_tiles,
+                                                                            int n_tiles) {
+  constexpr int NTHREADS = WARPS_M * WARPS_N * 64;
+  constexpr int ROWS_PER_PASS = NTHREADS / 8;  // 8 chunks per 128-B row
+  constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+  constexpr int MT = WM / 16, NT = WN / 16;
+  // SPLITW: weights carried as hi + lo (w = w_hi + w_lo, both 16-bit) and both
+  // products accumulated: the weight rounding error (the dominant term of the
+  // logit error at 16-bit storage) drops to ~2^-22 for 2x the MFMA work.
+  constexpr int NB = SPLITW ? 2 : 1;
+  constexpr int A_ITERS = BM / ROWS_PER_PASS, B_ITERS = NB * BN / ROWS_PER_PASS;
+  constexpr int A_BYTES = BM * ROW_BYTES, B_BYTES = NB * BN * ROW_BYTES;
+  static_assert(A_ITERS >= 1 && B_ITERS >= 1, "tile too small for the block");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sA = smem;                 // [2][BM][128 B]
+  unsigned char* const sB = smem + 2 * A_BYTES;   // [2][BN][128 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+
+  // XCD-aware, bijective block -> tile map
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int nt_idx = swz % n_tiles, mt_idx = swz / n_tiles;
+  const int m0 = mt_idx * BM, n0 = nt_idx * BN;
+
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+
+  // ---- per-thread staging coordinates (fixed over the K loop) ----
+  const int chunk = tid & 7;
+  const int srow = tid >> 3;
+  int a_base[A_ITERS], a_h0[A_ITERS], a_w0[A_ITERS];
+  const int HoWo = a.Ho * a.Wo;
+#pragma unroll
+  for (int i = 0; i < A_ITERS; ++i) {
+    const int m = m0 + srow + i * ROWS_PER_PASS;
+    const int img = m / HoWo;
+    const int rem = m - img * HoWo;
+    const int ho = rem / a.Wo;
+    const int wo = rem - ho * a.Wo;
+    if (MODE == CONV_MODE_STEM) {
+      // K row = one filter row: 8 taps x 4 channels starting at pixel 2*wo-4
+      const int h0 = ho * 2 - 3, p0 = wo * 2 - 4;
+      a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
+      a_w0[i] = p0;
+      a_base[i] = ((img * a.H + h0) * a.W + p0) * 4;
+    } else {
+      const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
+      a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
+      a_w0[i] = w0;
+      a_base[i] = ((img * a.H + h0) * a.W + w0) * a.Cin + chunk * 8;
+    }
+  }
+  int b_off[B_ITERS];
+#pragma unroll
+  for (int i = 0; i < B_ITERS; ++i) {
+    const int rr = srow + i * ROWS_PER_PASS;  // [0, NB*BN): hi rows then lo rows
+    const int half = rr / BN;
+    b_off[i] = ((half * a.Cout + n0 + rr - half * BN) * a.K + chunk * 8) * 2;
+  }
+
+  const int KT = a.K / BK;
+  u32x4_t ra[A_ITERS], rb[B_ITERS];
+
+  // scalar walk over (tap row r, tap col s, channel block c0) for generic mode
+  int kr = 0, ks_ = 0, kc0 = 0;
+
+  auto issue_loads = [&](int kt) {
+    if (MODE == CONV_MODE_STEM) {
+      const int krow = kt * 2 + (chunk >> 2);
+      const int qq = chunk & 3;
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        const int hi = a_h0[i] + krow, px = a_w0[i] + 2 * qq;
+        const bool ok = (krow < 7) && ((unsigned)hi < (unsigned)a.H) && ((unsigned)px < (unsigned)a.W);
+        const unsigned off = ok ? (unsigned)((a_base[i] + (krow * a.W + 2 * qq) * 4) * 2) : 0x80000000u;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      }
+    } else {
+      const int tap_off = (kr * a.W + ks_) * a.Cin + kc0;
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        const bool ok = ((unsigned)(a_h0[i] + kr) < (unsigned)a.H) &&
+                        ((unsigned)(a_w0[i] + ks_) < (unsigned)a.W);
+        const unsigned off = ok ? (unsigned)((a_base[i] + tap_off) * 2) : 0x80000000u;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      }
+      kc0 += BK;
+      if (kc0 >= a.Cin) {
+        kc0 = 0;
+        if (++ks_ == a.kw) { ks_ = 0; ++kr; }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i)
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, (unsigned)(b_off[i] + kt * (BK * 2)), 0, 0);
+  };
+
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i)
+      *(u32x4_t*)(sA + buf * A_BYTES + lds_off(srow + i * ROWS_PER_PASS, chunk)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i)
+      *(u32x4_t*)(sB + buf * B_BYTES + lds_off(srow + i * ROWS_PER_PASS, chunk)) = rb[i];
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+
+  issue_loads(0);
+  store_lds(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) issue_loads(kt + 1);
+    const unsigned char* pa = sA + buf * A_BYTES;
+    const unsigned char* pb = sB + buf * B_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t fa[MT], fb[NT], fl[SPLITW ? NT : 1];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        fa[i] = *(const u32x4_t*)(pa + lds_off(wm * WM + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        fb[j] = *(const u32x4_t*)(pb + lds_off(wn * WN + j * 16 + frow, ks * 4 + fq));
+      if (SPLITW) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          fl[j] = *(const u32x4_t*)(pb + lds_off(BN + wn * WN + j * 16 + frow, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
+      if (SPLITW) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = mfma16<DT>(fa[i], fl[j], acc[i][j]);
+      }
+    }
+    if (kt + 1 < KT) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc -> LDS (fp32, per-wave region) -> fused pointwise -> bf16 rows ----
+  constexpr int EPI_LD = WN + 4;          // floats per staged row (pad: conflict-free writes)
+  constexpr int LPR = WN / 8;             // lanes per output row (8 columns each)
+  constexpr int RPP = 64 / LPR;           // rows per pass
+  constexpr int PASSES = 16 / RPP;
+  static_assert(PASSES >= 1, "WN too large");
+  float* const epi = (float*)smem + wave * (16 * EPI_LD);
+  static_assert(WARPS_M * WARPS_N * 16 * EPI_LD * 4 <= 2 * (A_BYTES + B_BYTES), "epilogue LDS");
+
+  const int ecol = (lane % LPR) * 8;
+  const int erow = lane / LPR;
+  const int gcol = n0 + wn * WN + ecol;
+  float sc[8], bi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.scale ? a.scale[gcol + j] : 1.f;
+    bi[j] = a.bias ? a.bias[gcol + j] : 0.f;
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) epi[(fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int row = erow + p * RPP;
+      const int m = m0 + wm * WM + i * 16 + row;
+      const f32x4_t v0 = *(const f32x4_t*)(epi + row * EPI_LD + ecol);
+      const f32x4_t v1 = *(const f32x4_t*)(epi + row * EPI_LD + ecol + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      if (m < a.M) {
+        const size_t o = (size_t)m * a.Cout + gcol;
+        if (a.stats) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+        if (a.res) {
+          const u32x4_t rr = *(const u32x4_t*)(a.res + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += lo_f32<DT>(rr[j]);
+            v[2 * j + 1] += hi_f32<DT>(rr[j]);
+          }
+          if (a.res_lo) {  // rounding remainder of the shortcut tensor
+            const u32x4_t rl = *(const u32x4_t*)(a.res_lo + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[2 * j] += lo_f32<DT>(rl[j]);
+              v[2 * j + 1] += hi_f32<DT>(rl[j]);
+            }
+          }
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        u32x4_t ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = pack2<DT>(v[2 * j], v[2 * j + 1]);
+        *(u32x4_t*)(a.y + o) = ov;
+        if (a.y_lo) {  // what the 16-bit rounding dropped, for the next shortcut add
+          u32x4_t lv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            lv[j] = pack2<DT>(v[2 * j] - lo_f32<DT>(ov[j]), v[2 * j + 1] - hi_f32<DT>(ov[j]));
+          *(u32x4_t*)(a.y_lo + o) = lv;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (a.stats) {
+    // per-column partial sums of this block's rows: lanes with equal ecol,
+    // then the WARPS_M waves stacked in M (through LDS), fixed order.
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      for (int d = LPR; d < 64; d <<= 1) {
+        s1[j] += __shfl_xor(s1[j], d);
+        s2[j] += __shfl_xor(s2[j], d);
+      }
+    }
+    float* red = (float*)smem;  // [WARPS_M][2][BN]
+    if (erow == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wm * 2 + 0) * BN + wn * WN + ecol + j] = s1[j];
+        red[(wm * 2 + 1) * BN + wn * WN + ecol + j] = s2[j];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < 2 * BN; c += NTHREADS) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WARPS_M; ++w) t += red[(w * 2) * BN + c];
+      const int which = c / BN, col = c - which * BN;
+      a.stats[((size_t)mt_idx * 2 + which) * a.Cout + n0 + col] = t;
+    }
+  }
+}
+
+struct TileCfg {
+  int bm, bn;
+};
+
+thread_local char g_cfg_name[64] = "";
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW>
+int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
+  const size_t lds = 2 * (size_t)(BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES;
+  auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(m_tiles * n_tiles), dim3(WARPS_M * WARPS_N * 64), lds, s, a, m_tiles, n_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
+  const int m_tiles = (a.M + BM - 1) / BM;
+  const int n_tiles = a.Cout / BN;
+  if (m_tiles_out) *m_tiles_out = m_tiles;
+  snprintf(g_cfg_name, sizeof g_cfg_name, "%dx%d%s", BM, BN, a.splitw ? "+wlo" : "");
+#define SPK_GO(MODE, DT, SW) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles)
+  if (mode == CONV_MODE_STEM) {
+    if (a.dt == DT_F16) { if (a.splitw) SPK_GO(CONV_MODE_STEM, DT_F16, 1); SPK_GO(CONV_MODE_STEM, DT_F16, 0); }
+    SPK_GO(CONV_MODE_STEM, DT_BF16, 0);
+  }
+  if (a.dt == DT_F16) { if (a.splitw) SPK_GO(CONV_MODE_GENERIC, DT_F16, 1); SPK_GO(CONV_MODE_GENERIC, DT_F16, 0); }
+  SPK_GO(CONV_MODE_GENERIC, DT_BF16, 0);
+#undef SPK_GO
+}
+
+// tile choice: keep >= ~2 blocks per CU where the problem allows, prefer the
+// widest N tile (activations are then streamed once).
+int pick_cfg(int M, int Cout) {
+  const long blocks128 = (long)((M + 127) / 128) * (Cout / 128 > 0 ? Cout / 128 : 1);
+  if (Cout % 128 == 0 && blocks128 >= 512) return 0;  // 128x128
+  if (Cout == 64 && M >= 256 * 512) return 1;         // 256x64
+  const long blocks12864 = (long)((M + 127) / 128) * (Cout / 64);
+  if (blocks12864 >= 384) return 3;                   // 128x64
+  return 2;                                           // 64x64
+}
+
+}  // namespace
+
+const char* spk_conv_last_config() { return g_cfg_name; }
+
+static int env_cfg() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("SPK_CONV_CFG");
+    v = e ? atoi(e) : -1;
+  }
+  return v;
+}
+
+int spk_conv_m_tiles(int M, int Cout, int mode) {
+  int cfg = env_cfg() >= 0 ? env_cfg() : pick_cfg(M, Cout);
+  if (cfg == 0 && Cout % 128) cfg = 3;
+  const int bm = (cfg == 0 || cfg == 3) ? 128 : (cfg == 1 ? 256 : 64);
+  return (M + bm - 1) / bm;
+}
+
+int spk_conv_launch(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
+  if (a.K % BK || a.Cout % 64) return -2;
+  int cfg = env_cfg() >= 0 ? env_cfg() : pick_cfg(a.M, a.Cout);
+  if (cfg == 0 && a.Cout % 128) cfg = 3;
+  switch (cfg) {
+    case 0: return launch_cfg<128, 128, 2, 2>(a, mode, s, m_tiles_out);
+    case 1: return launch_cfg<256, 64, 4, 1>(a, mode, s, m_tiles_out);
+    case 3: return launch_cfg<128, 64, 2, 2>(a, mode, s, m_tiles_out);
+    default: return launch_cfg<64, 64, 2, 2>(a, mode, s, m_tiles_out);
+  }
+}

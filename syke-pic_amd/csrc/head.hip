@@ -1,0 +1,167 @@
+// Classifier head on gfx950: the reference's head is a stack of Linear
+// layers with NO activation between them (sykepic/train/network.py:58-63,
+// quirk Q1), then either the base-1.3 softmax of net_pass
+// (sykepic/compute/probability.py:191-194) or CrossEntropyLoss
+// (sykepic/train/train.py:127,241).  The head is 0.01 % of the FLOPs, so it
+// stays in exact fp32 (LDS-tiled FMA GEMM) — this keeps the logits' error
+// budget for the bf16 backbone.
+#include "spk_common.h"
+
+namespace {
+
+// C[i][j] = sum_k A(i,k) * B(j,k) (+ bias[j]);  A(i,k) = A[i*sai + k*sak], B likewise.
+// 64x64 tile, 256 threads, 4x4 outputs per thread, K step 16.
+// accumulate != 0: C += result (used for gradient accumulation).
+__global__ __launch_bounds__(256) void sgemm_strided_kernel(
+    const float* __restrict__ A, long sai, long sak, const float* __restrict__ B, long sbj, long sbk,
+    const float* __restrict__ bias, float* __restrict__ C, long sci, long scj, int M, int N, int K,
+    float alpha, int accumulate) {
+  __shared__ float sa[16][64 + 4];
+  __shared__ float sb[16][64 + 4];
+  const int tid = threadIdx.x;
+  const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int ty = tid >> 4, tx = tid & 15;
+  float acc[4][4] = {};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    for (int e = tid; e < 64 * 16; e += 256) {
+      // choose the element order so the fastest-varying global index is contiguous
+      int r, kk;
+      if (sak == 1) { kk = e & 15; r = e >> 4; } else { r = e & 63; kk = e >> 6; }
+      const int gi = i0 + r, gk = k0 + kk;
+      sa[kk][r] = (gi < M && gk < K) ? A[gi * sai + gk * sak] : 0.f;
+    }
+    for (int e = tid; e < 64 * 16; e += 256) {
+      int r, kk;
+      if (sbk == 1) { kk = e & 15; r = e >> 4; } else { r = e & 63; kk = e >> 6; }
+      const int gj = j0 + r, gk = k0 + kk;
+      sb[kk][r] = (gj < N && gk < K) ? B[gj * sbj + gk * sbk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { av[u] = sa[kk][ty * 4 + u]; bv[u] = sb[kk][tx * 4 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(av[u], bv[v], acc[u][v]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int gi = i0 + ty * 4 + u;
+    if (gi >= M) continue;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int gj = j0 + tx * 4 + v;
+      if (gj >= N) continue;
+      float r = acc[u][v] * alpha + (bias ? bias[gj] : 0.f);
+      float* c = C + gi * sci + gj * scj;
+      *c = accumulate ? *c + r : r;
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+  for (int d = 32; d; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+
+// one wave per row: p = softmax(z * scale)
+__global__ void softmax_kernel(const float* __restrict__ z, float* __restrict__ p, int n, int c,
+                               float scale) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* zr = z + (size_t)row * c;
+  float mx = -INFINITY;
+  for (int j = lane; j < c; j += 64) mx = fmaxf(mx, zr[j] * scale);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int j = lane; j < c; j += 64) s += expf(zr[j] * scale - mx);
+  s = wave_sum(s);
+  const float inv = 1.0f / s;
+  for (int j = lane; j < c; j += 64) p[(size_t)row * c + j] = expf(zr[j] * scale - mx) * inv;
+}
+
+// Mean cross-entropy + arg-max accuracy + dlogits in ONE block so that the
+// loss sum has a fixed summation order (bitwise reproducible).
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ z,
+                                                 const int64_t* __restrict__ y, int n, int c,
+                                                 float* __restrict__ stats,
+                                                 float* __restrict__ dz) {
+  __shared__ float s_loss[4];
+  __shared__ float s_corr[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float loss = 0.f, corr = 0.f;
+  const float invn = 1.0f / (float)n;
+  for (int row = wave; row < n; row += 4) {
+    const float* zr = z + (size_t)row * c;
+    const int label = (int)y[row];
+    float mx = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int j = lane; j < c; j += 64) {
+      const float v = zr[j];
+      if (v > mx) { mx = v; arg = j; }
+    }
+    // arg-max with torch's tie rule: lowest index among the maxima
+    for (int d = 32; d; d >>= 1) {
+      const float om = __shfl_xor(mx, d);
+      const int oa = __shfl_xor(arg, d);
+      if (om > mx || (om == mx && oa < arg)) { mx = om; arg = oa; }
+    }
+    float s = 0.f;
+    for (int j = lane; j < c; j += 64) s += expf(zr[j] - mx);
+    s = wave_sum(s);
+    const float lse = mx + logf(s);
+    if (lane == 0) {
+      loss += lse - zr[label];
+      corr += (arg == label) ? 1.f : 0.f;
+    }
+    if (dz) {
+      const float inv = 1.0f / s;
+      for (int j = lane; j < c; j += 64)
+        dz[(size_t)row * c + j] = (expf(zr[j] - mx) * inv - (j == label ? 1.f : 0.f)) * invn;
+    }
+  }
+  if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    stats[0] += (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
+    stats[1] += (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
+  }
+}
+
+}  // namespace
+
+int spk_launch_sgemm(const float* A, long sai, long sak, const float* B, long sbj, long sbk,
+                     const float* bias, float* C, long sci, long scj, int M, int N, int K,
+                     float alpha, int accumulate, hipStream_t s) {
+  dim3 grid((N + 63) / 64, (M + 63) / 64);
+  hipLaunchKernelGGL(sgemm_strided_kernel, grid, dim3(256), 0, s, A, sai, sak, B, sbj, sbk, bias, C,
+                     sci, scj, M, N, K, alpha, accumulate);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int spk_launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,
+                          int out, hipStream_t s) {
+  // y[n][out] = x[n][in] . w[out][in]^T + b
+  return spk_launch_sgemm(x, in, 1, w, in, 1, b, y, out, 1, n, out, in, 1.f, 0, s);
+}
+
+int spk_launch_softmax(const float* z, float* p, int n, int c, float scale, hipStream_t s) {
+  hipLaunchKernelGGL(softmax_kernel, dim3((n + 3) / 4), dim3(256), 0, s, z, p, n, c, scale);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int spk_launch_ce(const float* z, const int64_t* y, int n, int c, float* stats, float* dlogits,
+                  hipStream_t s) {
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, s, z, y, n, c, stats, dlogits);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

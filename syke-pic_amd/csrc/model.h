@@ -1,0 +1,86 @@
+// Model handle internals (host side).  Not part of the public ABI.
+#pragma once
+#include "../../include/sykepic_hip.h"
+#include "spk_common.h"
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+enum ParamKind { PK_CONV_W = 1, PK_BN_W, PK_BN_B, PK_BN_MEAN, PK_BN_VAR, PK_BN_NBT, PK_FC_W, PK_FC_B };
+
+struct Param {
+  std::string key;
+  int kind = 0, layer = -1, dtype = 0, ndim = 0;
+  int64_t shape[4] = {1, 1, 1, 1};
+  int64_t numel = 0;
+  bool trainable = false;  // nn.Parameter (true) vs buffer (false)
+  int requires_grad = 0;
+  int group = -1;          // optimizer param group, -1: not in the optimizer
+  size_t off = 0;          // element offset in the flat fp32 buffers
+  long step = 0;           // per-tensor Adam step count (torch keeps it per parameter)
+};
+
+struct TDim {
+  int h = 0, w = 0, c = 0;
+  bool bf16 = true;
+};
+
+struct Layer {
+  spk_layer_desc d;
+  int mode = 0;     // CONV_MODE_*
+  int kpad = 0;     // GEMM K of the packed weights
+  int p_w = -1, p_g = -1, p_b = -1, p_mean = -1, p_var = -1, p_nbt = -1;
+  size_t wpack_off = 0, sb_off = 0;
+  int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
+};
+
+struct TrainState;
+
+struct spk_model {
+  int device = 0;
+  int in_chans = 3, num_classes = 0;
+  hipStream_t stream = nullptr;
+  std::vector<Layer> layers;
+  std::vector<Param> params;
+  std::unordered_map<std::string, int> index;
+  int n_tensors = 1;
+
+  float* pbuf = nullptr;       // flat fp32 master parameters + buffers
+  size_t n_flat = 0, n_train = 0;
+  bf16_t* wpack = nullptr;     // bf16 conv weights, [Cout][K] per layer
+  float* scale_bias = nullptr; // eval-BN folded scale/bias per conv
+  bool dirty = true;
+  int infer_dt = DT_F16;       // 16-bit storage type of the eval path
+  int packed_dt = -1;          // dtype the packed weights currently hold
+  int packed_split = -1;
+  bool splitw = true;          // eval: hi+lo 16-bit weights (2x MFMA, ~fp32-exact weights)
+  int act_dt = DT_F16;         // dtype of the activations now in the arena
+
+  // activations of one (n,h,w) plan
+  void* arena = nullptr;
+  size_t arena_bytes = 0;
+  int cap_n = 0, cap_h = 0, cap_w = 0;
+  int mb_limit = 1;
+  std::vector<TDim> tdims;
+  std::vector<size_t> toff;
+  std::vector<size_t> toff_lo;  // 0 = no remainder tensor
+  bool precise_res = false;     // keep the 16-bit rounding remainder of shortcut tensors
+  size_t logits_off = 0;
+
+  uint64_t seed = 0;
+  TrainState* train = nullptr;
+
+  float* P(int pi) const { return pbuf + params[pi].off; }
+  void* T(int t) const { return (char*)arena + toff[t]; }
+  void* TLo(int t) const { return toff_lo[t] ? (char*)arena + toff_lo[t] : nullptr; }
+};
+
+void spk_set_error(const std::string& s);
+int spk_commit(spk_model* m);
+int spk_plan(spk_model* m, int n, int h, int w);
+int spk_run_layer_eval(spk_model* m, Layer& L, int nb);
+int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype,
+                            float* logits_dev);
+int spk_read_flat(spk_model* m, const float* flat, const Param& p, float* host);
+void spk_train_free(spk_model* m);

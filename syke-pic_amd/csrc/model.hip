@@ -1,0 +1,636 @@
+// libsykepic_hip.so — C-ABI, model handle and layer executor (host side).
+// Public contract and the reference lines each entry point replaces:
+// include/sykepic_hip.h.
+#include "../../include/sykepic_hip.h"
+#include "spk_common.h"
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static thread_local std::string g_err;
+
+void spk_set_error(const std::string& s) { g_err = s; }
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess) {                                                             \
+      spk_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+      return SPK_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define SPK_TRY(expr)              \
+  do {                             \
+    int r_ = (expr);               \
+    if (r_ != SPK_OK) return r_;   \
+  } while (0)
+
+static int fail(int code, const std::string& msg) {
+  spk_set_error(msg);
+  return code;
+}
+
+extern "C" const char* spk_last_error(void) { return g_err.c_str(); }
+extern "C" const char* spk_version(void) { return "sykepic_hip 0.1.0 (gfx950)"; }
+
+// ---------------------------------------------------------------------------
+// construction
+// ---------------------------------------------------------------------------
+static int add_param(spk_model* m, const std::string& key, int kind, int layer, int dtype,
+                     std::initializer_list<int64_t> shape, bool trainable) {
+  Param p;
+  p.key = key;
+  p.kind = kind;
+  p.layer = layer;
+  p.dtype = dtype;
+  p.ndim = (int)shape.size();
+  p.numel = 1;
+  int i = 0;
+  for (int64_t s : shape) { p.shape[i++] = s; p.numel *= s; }
+  p.trainable = trainable;
+  p.requires_grad = trainable ? 1 : 0;
+  p.group = trainable ? 0 : -1;
+  m->index[key] = (int)m->params.size();
+  m->params.push_back(p);
+  return (int)m->params.size() - 1;
+}
+
+extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int in_chans,
+                                int num_classes, int device, spk_model** out) {
+  if (!layers || n_layers <= 0 || !out) return fail(SPK_ERR_ARG, "spk_model_create: bad arguments");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev)
+    return fail(SPK_ERR_HIP, "spk_model_create: no such HIP device " + std::to_string(device));
+  HIP_TRY(hipSetDevice(device));
+  spk_model* m = new spk_model();
+  m->device = device;
+  m->in_chans = in_chans;
+  m->num_classes = num_classes;
+  if (in_chans < 1 || in_chans > 4) { delete m; return fail(SPK_ERR_UNSUPPORTED, "in_chans must be 1..4"); }
+
+  // torch orders a residual block's modules conv1,bn1,conv2,bn2,(conv3,bn3),
+  // downsample; the graph runs the downsample branch earlier.  Register the
+  // parameters in state_dict order: stable sort of conv layers inside a block.
+  std::vector<int> order;
+  for (int i = 0; i < n_layers; ++i) order.push_back(i);
+  auto block_of = [&](int i) -> std::string {
+    std::string nm = layers[i].name;
+    size_t p = nm.find(".downsample.");
+    if (p != std::string::npos) return nm.substr(0, p);
+    p = nm.rfind('.');
+    return (layers[i].kind == SPK_OP_CONV && layers[i].child >= 4 && p != std::string::npos)
+               ? nm.substr(0, p) : nm;
+  };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (layers[a].kind != SPK_OP_CONV || layers[b].kind != SPK_OP_CONV) return false;
+    if (block_of(a) != block_of(b)) return false;
+    const bool da = strstr(layers[a].name, ".downsample.") != nullptr;
+    const bool db = strstr(layers[b].name, ".downsample.") != nullptr;
+    return !da && db;
+  });
+
+  m->layers.resize(n_layers);
+  for (int i = 0; i < n_layers; ++i) {
+    Layer& L = m->layers[i];
+    L.d = layers[i];
+    L.d.name[sizeof L.d.name - 1] = 0;
+    L.d.bn[sizeof L.d.bn - 1] = 0;
+    m->n_tensors = std::max(m->n_tensors, std::max(L.d.dst, std::max(L.d.src, L.d.res)) + 1);
+    if (L.d.kind == SPK_OP_CONV) {
+      if (L.d.cout % 64) { delete m; return fail(SPK_ERR_UNSUPPORTED, "conv Cout must be a multiple of 64"); }
+      const bool stem = (L.d.cin <= 4);
+      if (stem && !(L.d.k == 7 && L.d.stride == 2 && L.d.pad == 3)) {
+        delete m; return fail(SPK_ERR_UNSUPPORTED, "only the 7x7/2 pad 3 stem is supported for Cin<=4");
+      }
+      if (!stem && L.d.cin % 64) { delete m; return fail(SPK_ERR_UNSUPPORTED, "conv Cin must be a multiple of 64"); }
+      L.mode = stem ? CONV_MODE_STEM : CONV_MODE_GENERIC;
+      L.kpad = stem ? 256 : L.d.k * L.d.k * L.d.cin;
+    }
+  }
+  for (int oi : order) {
+    Layer& L = m->layers[oi];
+    const std::string nm = L.d.name, bn = L.d.bn;
+    if (L.d.kind == SPK_OP_CONV) {
+      L.p_w = add_param(m, nm + ".weight", PK_CONV_W, oi, SPK_DTYPE_F32,
+                        {L.d.cout, L.d.cin, L.d.k, L.d.k}, true);
+      L.p_g = add_param(m, bn + ".weight", PK_BN_W, oi, SPK_DTYPE_F32, {L.d.cout}, true);
+      L.p_b = add_param(m, bn + ".bias", PK_BN_B, oi, SPK_DTYPE_F32, {L.d.cout}, true);
+      L.p_mean = add_param(m, bn + ".running_mean", PK_BN_MEAN, oi, SPK_DTYPE_F32, {L.d.cout}, false);
+      L.p_var = add_param(m, bn + ".running_var", PK_BN_VAR, oi, SPK_DTYPE_F32, {L.d.cout}, false);
+      L.p_nbt = add_param(m, bn + ".num_batches_tracked", PK_BN_NBT, oi, SPK_DTYPE_I64, {}, false);
+    } else if (L.d.kind == SPK_OP_LINEAR) {
+      L.p_w = add_param(m, nm + ".weight", PK_FC_W, oi, SPK_DTYPE_F32, {L.d.cout, L.d.cin}, true);
+      L.p_b = add_param(m, nm + ".bias", PK_FC_B, oi, SPK_DTYPE_F32, {L.d.cout}, true);
+    }
+  }
+
+  // flat fp32 storage: trainable tensors first (this prefix is what the
+  // gradient / optimizer-state buffers mirror), then BN running stats.
+  size_t off = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (Param& p : m->params) {
+      if (p.dtype != SPK_DTYPE_F32 || p.trainable != (pass == 0)) continue;
+      p.off = off;
+      off += (size_t)((p.numel + 63) / 64 * 64);  // 256-B aligned tensors
+    }
+    if (pass == 0) m->n_train = off;
+  }
+  m->n_flat = off;
+  if (hipMalloc((void**)&m->pbuf, m->n_flat * sizeof(float)) != hipSuccess) {
+    delete m; return fail(SPK_ERR_HIP, "hipMalloc(params) failed");
+  }
+  hipMemset(m->pbuf, 0, m->n_flat * sizeof(float));
+  // BN defaults as torch: gamma 1, running_var 1
+  for (Param& p : m->params) {
+    if (p.kind == PK_BN_W || p.kind == PK_BN_VAR) {
+      std::vector<float> ones((size_t)p.numel, 1.0f);
+      hipMemcpy(m->pbuf + p.off, ones.data(), ones.size() * 4, hipMemcpyHostToDevice);
+    }
+  }
+  // packed bf16 weights + folded BN scale/bias
+  size_t wpack = 0, sb = 0;
+  for (Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV) continue;
+    L.wpack_off = wpack;
+    wpack += (size_t)2 * L.d.cout * L.kpad;  // room for the hi + lo halves
+    L.sb_off = sb;
+    sb += (size_t)2 * L.d.cout;
+  }
+  if (hipMalloc((void**)&m->wpack, std::max<size_t>(wpack, 8) * 2) != hipSuccess ||
+      hipMalloc((void**)&m->scale_bias, std::max<size_t>(sb, 8) * 4) != hipSuccess) {
+    spk_model_destroy(m);
+    return fail(SPK_ERR_HIP, "hipMalloc(packed weights) failed");
+  }
+  m->dirty = true;
+  *out = m;
+  return SPK_OK;
+}
+
+static void free_acts(spk_model* m) {
+  if (m->arena) hipFree(m->arena);
+  m->arena = nullptr;
+  m->arena_bytes = 0;
+  m->cap_n = m->cap_h = m->cap_w = 0;
+}
+
+extern "C" void spk_model_destroy(spk_model* m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  hipDeviceSynchronize();
+  free_acts(m);
+  if (m->pbuf) hipFree(m->pbuf);
+  if (m->wpack) hipFree(m->wpack);
+  if (m->scale_bias) hipFree(m->scale_bias);
+  spk_train_free(m);
+  delete m;
+}
+
+extern "C" int spk_model_set_stream(spk_model* m, void* s) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  m->stream = (hipStream_t)s;
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// state_dict I/O
+// ---------------------------------------------------------------------------
+extern "C" int spk_model_num_params(spk_model* m) { return m ? (int)m->params.size() : 0; }
+
+extern "C" int spk_model_param_info(spk_model* m, int idx, char* key, int key_cap, int64_t shape[4],
+                                    int* ndim, int* dtype) {
+  if (!m || idx < 0 || idx >= (int)m->params.size()) return fail(SPK_ERR_ARG, "param index out of range");
+  const Param& p = m->params[idx];
+  if (key && key_cap > 0) { strncpy(key, p.key.c_str(), key_cap - 1); key[key_cap - 1] = 0; }
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = i < p.ndim ? p.shape[i] : 1;
+  if (ndim) *ndim = p.ndim;
+  if (dtype) *dtype = p.dtype;
+  return SPK_OK;
+}
+
+static Param* find_param(spk_model* m, const char* key) {
+  if (!m || !key) return nullptr;
+  auto it = m->index.find(key);
+  return it == m->index.end() ? nullptr : &m->params[it->second];
+}
+
+extern "C" int spk_model_load_param(spk_model* m, const char* key, const void* host, int64_t numel) {
+  Param* p = find_param(m, key);
+  if (!p) return fail(SPK_ERR_KEY, std::string("unknown state_dict key: ") + (key ? key : "(null)"));
+  if (numel != p->numel) return fail(SPK_ERR_ARG, std::string("size mismatch for ") + key);
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (p->dtype == SPK_DTYPE_I64) {
+    m->layers[p->layer].nbt = *(const int64_t*)host;
+    return SPK_OK;
+  }
+  const float* src = (const float*)host;
+  std::vector<float> tmp;
+  if (p->kind == PK_CONV_W) {
+    // OIHW (state_dict) -> O,H,W,I (device master layout, K = tap-major)
+    const int64_t O = p->shape[0], I = p->shape[1], H = p->shape[2], W = p->shape[3];
+    tmp.resize((size_t)numel);
+    for (int64_t o = 0; o < O; ++o)
+      for (int64_t i = 0; i < I; ++i)
+        for (int64_t h = 0; h < H; ++h)
+          for (int64_t w = 0; w < W; ++w)
+            tmp[(size_t)(((o * H + h) * W + w) * I + i)] = src[(size_t)(((o * I + i) * H + h) * W + w)];
+    src = tmp.data();
+  }
+  HIP_TRY(hipMemcpy(m->pbuf + p->off, src, (size_t)numel * 4, hipMemcpyHostToDevice));
+  m->dirty = true;
+  return SPK_OK;
+}
+
+extern "C" int spk_model_read_param(spk_model* m, const char* key, void* host, int64_t numel) {
+  Param* p = find_param(m, key);
+  if (!p) return fail(SPK_ERR_KEY, std::string("unknown state_dict key: ") + (key ? key : "(null)"));
+  if (numel != p->numel) return fail(SPK_ERR_ARG, std::string("size mismatch for ") + key);
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (p->dtype == SPK_DTYPE_I64) {
+    *(int64_t*)host = m->layers[p->layer].nbt;
+    return SPK_OK;
+  }
+  return spk_read_flat(m, m->pbuf, *p, (float*)host);
+}
+
+int spk_read_flat(spk_model* m, const float* flat, const Param& p, float* host) {
+  if (p.kind != PK_CONV_W) {
+    HIP_TRY(hipMemcpy(host, flat + p.off, (size_t)p.numel * 4, hipMemcpyDeviceToHost));
+    return SPK_OK;
+  }
+  std::vector<float> tmp((size_t)p.numel);
+  HIP_TRY(hipMemcpy(tmp.data(), flat + p.off, (size_t)p.numel * 4, hipMemcpyDeviceToHost));
+  const int64_t O = p.shape[0], I = p.shape[1], H = p.shape[2], W = p.shape[3];
+  for (int64_t o = 0; o < O; ++o)
+    for (int64_t i = 0; i < I; ++i)
+      for (int64_t h = 0; h < H; ++h)
+        for (int64_t w = 0; w < W; ++w)
+          host[(size_t)(((o * I + i) * H + h) * W + w)] = tmp[(size_t)(((o * H + h) * W + w) * I + i)];
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_requires_grad(spk_model* m, const char* key, int flag) {
+  Param* p = find_param(m, key);
+  if (!p) return fail(SPK_ERR_KEY, std::string("unknown state_dict key: ") + (key ? key : "(null)"));
+  if (!p->trainable) return fail(SPK_ERR_ARG, std::string(key) + " is a buffer, not a parameter");
+  p->requires_grad = flag ? 1 : 0;
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_param_group(spk_model* m, const char* key, int group) {
+  Param* p = find_param(m, key);
+  if (!p) return fail(SPK_ERR_KEY, std::string("unknown state_dict key: ") + (key ? key : "(null)"));
+  if (!p->trainable || group < -1 || group > 2) return fail(SPK_ERR_ARG, "bad param group");
+  p->group = group;
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_infer_dtype(spk_model* m, int bf16) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  m->infer_dt = bf16 ? DT_BF16 : DT_F16;
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_precision(spk_model* m, int split_weights, int precise_residual) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  m->splitw = split_weights != 0;
+  if ((precise_residual != 0) != m->precise_res) {
+    m->precise_res = precise_residual != 0;
+    m->cap_n = 0;  // re-plan: remainder tensors appear / disappear
+  }
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  m->seed = seed;
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// commit: fold eval-BN into per-channel scale/bias, pack bf16 weights
+// ---------------------------------------------------------------------------
+int spk_commit(spk_model* m) {
+  if (!m->dirty && m->packed_dt == m->infer_dt && m->packed_split == (int)m->splitw) return SPK_OK;
+  for (Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV) continue;
+    float* sc = m->scale_bias + L.sb_off;
+    float* bi = sc + L.d.cout;
+    if (spk_launch_bn_fold(m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean), m->P(L.p_var), 1e-5f, sc, bi,
+                           L.d.cout, m->stream))
+      return fail(SPK_ERR_HIP, "bn_fold launch failed");
+    if (spk_launch_pack_weights(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
+                                L.mode, m->infer_dt, m->splitw && m->infer_dt == DT_F16, m->stream))
+      return fail(SPK_ERR_HIP, "pack_weights launch failed");
+  }
+  m->packed_dt = m->infer_dt;
+  m->packed_split = (int)m->splitw;
+  m->dirty = false;
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// activation planning
+// ---------------------------------------------------------------------------
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+int spk_plan(spk_model* m, int n, int h, int w) {
+  if (n <= m->cap_n && h == m->cap_h && w == m->cap_w) return SPK_OK;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  free_acts(m);
+  m->tdims.assign(m->n_tensors, TDim());
+  const int wp = (w + 1) & ~1;
+  m->tdims[0] = {h, wp, 4, true};
+  for (Layer& L : m->layers) {
+    const TDim& in = m->tdims[L.d.src];
+    TDim o;
+    switch (L.d.kind) {
+      case SPK_OP_CONV:
+      case SPK_OP_MAXPOOL: {
+        const int ih = in.h, iw = (L.d.src == 0) ? w : in.w;
+        o.h = (ih + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
+        o.w = (iw + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
+        o.c = L.d.cout;
+        o.bf16 = true;
+        if (o.h < 1 || o.w < 1) return fail(SPK_ERR_ARG, "image too small for the network");
+        break;
+      }
+      case SPK_OP_GAVGPOOL: o = {1, 1, in.c, false}; break;
+      case SPK_OP_LINEAR: o = {1, 1, L.d.cout, false}; break;
+      default: o = in; break;
+    }
+    m->tdims[L.d.dst] = o;
+  }
+  size_t total = 0;
+  size_t max_img_bytes = 1;
+  m->toff.assign(m->n_tensors, 0);
+  for (int t = 0; t < m->n_tensors; ++t) {
+    const TDim& d = m->tdims[t];
+    const size_t per_img = (size_t)d.h * d.w * d.c * (d.bf16 ? 2 : 4);
+    max_img_bytes = std::max(max_img_bytes, per_img);
+    m->toff[t] = total;
+    total += align256(per_img * n);
+  }
+  // rounding-remainder companions of every conv output that a later layer
+  // adds as a shortcut (see ConvArgs::y_lo)
+  m->toff_lo.assign(m->n_tensors, 0);
+  if (m->precise_res) {
+    for (const Layer& L : m->layers) {
+      if (L.d.kind != SPK_OP_CONV || L.d.res < 0 || m->toff_lo[L.d.res]) continue;
+      bool from_conv = false;
+      for (const Layer& P : m->layers) from_conv |= (P.d.kind == SPK_OP_CONV && P.d.dst == L.d.res);
+      if (!from_conv) continue;
+      const TDim& d = m->tdims[L.d.res];
+      m->toff_lo[L.d.res] = total;
+      total += align256((size_t)d.h * d.w * d.c * 2 * n);
+    }
+  }
+  m->logits_off = total;
+  total += align256((size_t)n * m->num_classes * 4);
+  HIP_TRY(hipMalloc((void**)&m->arena, total));
+  m->arena_bytes = total;
+  m->cap_n = n;
+  m->cap_h = h;
+  m->cap_w = w;
+  // 32-bit buffer offsets inside the conv kernel: keep every activation of a
+  // micro-batch below 2 GiB
+  m->mb_limit = (int)std::max<size_t>(1, ((size_t)1 << 31) / max_img_bytes - 1);
+  return SPK_OK;
+}
+
+static int micro_batch(spk_model* m, int n) {
+  static int env = -1;
+  if (env < 0) {
+    const char* e = getenv("SPK_MICRO_BATCH");
+    env = e ? atoi(e) : 0;
+  }
+  int mb = std::min(n, m->mb_limit);
+  if (env > 0) mb = std::min(mb, env);
+  return std::max(mb, 1);
+}
+
+// ---------------------------------------------------------------------------
+// eval-mode forward of images [i0, i0+nb) into logits rows [i0, i0+nb)
+// ---------------------------------------------------------------------------
+static int run_conv_eval(spk_model* m, Layer& L, int nb) {
+  const TDim& in = m->tdims[L.d.src];
+  const TDim& o = m->tdims[L.d.dst];
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = (const bf16_t*)m->T(L.d.src);
+  a.w = m->wpack + L.wpack_off;
+  a.y = (bf16_t*)m->T(L.d.dst);
+  a.res = L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr;
+  a.res_lo = L.d.res >= 0 ? (const bf16_t*)m->TLo(L.d.res) : nullptr;
+  a.y_lo = (bf16_t*)m->TLo(L.d.dst);
+  a.scale = m->scale_bias + L.sb_off;
+  a.bias = a.scale + L.d.cout;
+  a.N = nb; a.H = in.h; a.W = in.w; a.Cin = in.c;
+  a.Ho = o.h; a.Wo = o.w; a.Cout = L.d.cout;
+  a.kh = a.kw = L.d.k; a.stride = L.d.stride; a.pad = L.d.pad;
+  a.M = nb * o.h * o.w;
+  a.K = L.kpad;
+  a.relu = L.d.relu;
+  a.dt = m->infer_dt;
+  a.splitw = m->splitw && m->infer_dt == DT_F16;
+  a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
+  a.w_bytes = (unsigned)((size_t)L.d.cout * L.kpad * 2 * (a.splitw ? 2 : 1));
+  if (spk_conv_launch(a, L.mode, m->stream, nullptr))
+    return fail(SPK_ERR_HIP, std::string("conv launch failed for ") + L.d.name);
+  return SPK_OK;
+}
+
+int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
+  const TDim& in = m->tdims[L.d.src];
+  const TDim& o = m->tdims[L.d.dst];
+  switch (L.d.kind) {
+    case SPK_OP_CONV: return run_conv_eval(m, L, nb);
+    case SPK_OP_MAXPOOL:
+      if (spk_launch_maxpool((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), nb, in.h, in.w,
+                             in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, m->infer_dt, m->stream))
+        return fail(SPK_ERR_HIP, "maxpool launch failed");
+      return SPK_OK;
+    case SPK_OP_GAVGPOOL:
+      if (spk_launch_gavgpool((const bf16_t*)m->T(L.d.src), (float*)m->T(L.d.dst), nb, in.h * in.w,
+                              in.c, m->infer_dt, m->stream))
+        return fail(SPK_ERR_HIP, "avgpool launch failed");
+      return SPK_OK;
+    case SPK_OP_LINEAR:
+      if (spk_launch_linear_fwd((const float*)m->T(L.d.src), m->P(L.p_w), m->P(L.p_b),
+                                (float*)m->T(L.d.dst), nb, L.d.cin, L.d.cout, m->stream))
+        return fail(SPK_ERR_HIP, "linear launch failed");
+      return SPK_OK;
+    case SPK_OP_DROPOUT:  // eval: identity
+      HIP_TRY(hipMemcpyAsync(m->T(L.d.dst), m->T(L.d.src), (size_t)nb * in.c * 4,
+                             hipMemcpyDeviceToDevice, m->stream));
+      return SPK_OK;
+  }
+  return fail(SPK_ERR_UNSUPPORTED, "unknown layer kind");
+}
+
+static size_t image_stride_bytes(int c, int h, int w, int dtype) {
+  return (size_t)c * h * w * (dtype == SPK_DTYPE_U8 ? 1 : 4);
+}
+
+int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype,
+                            float* logits_dev) {
+  if (!m || !x || n <= 0) return fail(SPK_ERR_ARG, "forward: bad arguments");
+  if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return fail(SPK_ERR_ARG, "forward: dtype must be f32 or u8");
+  HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_commit(m));
+  SPK_TRY(spk_plan(m, n, h, w));
+  const int mb = micro_batch(m, n);
+  const int last = m->layers.back().d.dst;
+  m->act_dt = m->infer_dt;
+  for (int i0 = 0; i0 < n; i0 += mb) {
+    const int nb = std::min(mb, n - i0);
+    const char* xi = (const char*)x + (size_t)i0 * image_stride_bytes(m->in_chans, h, w, dtype);
+    if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream))
+      return fail(SPK_ERR_HIP, "input conversion launch failed");
+    for (Layer& L : m->layers) SPK_TRY(spk_run_layer_eval(m, L, nb));
+    HIP_TRY(hipMemcpyAsync(logits_dev + (size_t)i0 * m->num_classes, m->T(last),
+                           (size_t)nb * m->num_classes * 4, hipMemcpyDeviceToDevice, m->stream));
+  }
+  return SPK_OK;
+}
+
+extern "C" int spk_forward_infer(spk_model* m, const void* x, int n, int h, int w, int layout,
+                                 int dtype, float softmax_base, float* out_dev) {
+  if (!out_dev) return fail(SPK_ERR_ARG, "forward: null output");
+  if (softmax_base <= 0.f) return spk_forward_eval_logits(m, x, n, h, w, layout, dtype, out_dev);
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_plan(m, n, h, w));
+  float* logits = (float*)((char*)m->arena + m->logits_off);
+  SPK_TRY(spk_forward_eval_logits(m, x, n, h, w, layout, dtype, logits));
+  // softmax(z * ln(base)) == base^z / sum base^z   (probability.py:191-194)
+  if (spk_launch_softmax(logits, out_dev, n, m->num_classes, logf(softmax_base), m->stream))
+    return fail(SPK_ERR_HIP, "softmax launch failed");
+  return SPK_OK;
+}
+
+extern "C" int spk_eval_step(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype,
+                             const int64_t* y, float* stats, float* logits_out) {
+  if (!m || !y || !stats) return fail(SPK_ERR_ARG, "eval_step: bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_plan(m, n, h, w));
+  float* logits = logits_out ? logits_out : (float*)((char*)m->arena + m->logits_off);
+  SPK_TRY(spk_forward_eval_logits(m, x, n, h, w, layout, dtype, logits));
+  // CrossEntropyLoss is a batch mean; the caller accumulates loss*n (train.py:269)
+  if (spk_launch_ce(logits, y, n, m->num_classes, stats, nullptr, m->stream))
+    return fail(SPK_ERR_HIP, "cross-entropy launch failed");
+  return SPK_OK;
+}
+
+extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host, int64_t numel) {
+  if (!m || !host || t <= 0 || t >= m->n_tensors || !m->arena || n > m->cap_n)
+    return fail(SPK_ERR_ARG, "read_activation: bad arguments or no forward has run");
+  const TDim& d = m->tdims[t];
+  const size_t cnt = (size_t)n * d.h * d.w * d.c;
+  if ((int64_t)cnt != numel) return fail(SPK_ERR_ARG, "read_activation: size mismatch");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (!d.bf16) {
+    HIP_TRY(hipMemcpy(host, m->T(t), cnt * 4, hipMemcpyDeviceToHost));
+    return SPK_OK;
+  }
+  std::vector<bf16_t> tmp(cnt);
+  HIP_TRY(hipMemcpy(tmp.data(), m->T(t), cnt * 2, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i)
+    for (int y = 0; y < d.h; ++y)
+      for (int x = 0; x < d.w; ++x)
+        for (int c = 0; c < d.c; ++c) {
+          const bf16_t raw = tmp[(((size_t)i * d.h + y) * d.w + x) * d.c + c];
+          float f;
+          if (m->act_dt == DT_F16) {
+            _Float16 hv;
+            memcpy(&hv, &raw, 2);
+            f = (float)hv;
+          } else {
+            const unsigned u = (unsigned)raw << 16;
+            memcpy(&f, &u, 4);
+          }
+          host[(((size_t)i * d.c + c) * d.h + y) * d.w + x] = f;
+        }
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// per-layer timing (bench.py roofline line)
+// ---------------------------------------------------------------------------
+extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h, int w, int layout,
+                                       int dtype, int iters, spk_layer_time* out, int cap) {
+  if (!m || !x || !out || cap <= 0 || iters <= 0) return fail(SPK_ERR_ARG, "profile: bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_commit(m));
+  SPK_TRY(spk_plan(m, n, h, w));
+  const int nb = std::min(n, micro_batch(m, n));
+  const int nl = (int)m->layers.size();
+  std::vector<hipEvent_t> ev(nl + 2);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  std::vector<double> ms(nl + 1, 0.0);
+  for (int it = 0; it < iters + 1; ++it) {  // first pass is a warm-up
+    HIP_TRY(hipEventRecord(ev[0], m->stream));
+    if (spk_launch_to_nhwc4(x, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream))
+      return fail(SPK_ERR_HIP, "input conversion launch failed");
+    HIP_TRY(hipEventRecord(ev[1], m->stream));
+    for (int i = 0; i < nl; ++i) {
+      SPK_TRY(spk_run_layer_eval(m, m->layers[i], nb));
+      HIP_TRY(hipEventRecord(ev[i + 2], m->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (it == 0) continue;
+    for (int i = 0; i <= nl; ++i) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+      ms[i] += t;
+    }
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  int cnt = 0;
+  auto put = [&](const char* name, double t, double fl, double by) {
+    if (cnt >= cap) return;
+    memset(&out[cnt], 0, sizeof out[cnt]);
+    strncpy(out[cnt].name, name, sizeof out[cnt].name - 1);
+    out[cnt].ms = (float)(t / iters);
+    out[cnt].flops = fl;
+    out[cnt].bytes = by;
+    ++cnt;
+  };
+  put("input.to_nhwc4", ms[0], 0.0,
+      (double)nb * h * w * (m->in_chans * (dtype == SPK_DTYPE_U8 ? 1 : 4) + 8));
+  for (int i = 0; i < nl; ++i) {
+    const Layer& L = m->layers[i];
+    const TDim& in = m->tdims[L.d.src];
+    const TDim& o = m->tdims[L.d.dst];
+    double fl = 0, by = 0;
+    const double in_b = (double)nb * in.h * in.w * in.c * (in.bf16 ? 2 : 4);
+    const double out_b = (double)nb * o.h * o.w * o.c * (o.bf16 ? 2 : 4);
+    char nm[96];
+    if (L.d.kind == SPK_OP_CONV) {
+      const int cin = L.d.cin;
+      fl = 2.0 * nb * o.h * o.w * (double)L.d.cout * cin * L.d.k * L.d.k;
+      const double real_in = L.mode == CONV_MODE_STEM ? (double)nb * in.h * in.w * 8 : in_b;
+      by = real_in + out_b + (L.d.res >= 0 ? out_b : 0) + (double)L.d.cout * L.kpad * 2;
+      snprintf(nm, sizeof nm, "%s", L.d.name);
+    } else if (L.d.kind == SPK_OP_LINEAR) {
+      fl = 2.0 * nb * L.d.cin * L.d.cout;
+      by = in_b + out_b + (double)L.d.cin * L.d.cout * 4;
+      snprintf(nm, sizeof nm, "%s", L.d.name);
+    } else {
+      by = in_b + out_b;
+      snprintf(nm, sizeof nm, "%s@base.%d",
+               L.d.kind == SPK_OP_MAXPOOL ? "maxpool" : (L.d.kind == SPK_OP_GAVGPOOL ? "avgpool" : "dropout"),
+               L.d.child);
+    }
+    put(nm, ms[i + 1], fl, by);
+  }
+  return cnt;
+}

@@ -1,0 +1,228 @@
+// HBM-bound helper kernels of the inference path (gfx950): image batch ->
+// NHWC bf16, 3x3/2 max-pool, global average pool, BatchNorm(eval) folding and
+// weight packing.  All of them move 16 B (or 8 B) per lane, coalesced along
+// the channel-minor NHWC axis; none has data reuse worth LDS.
+//
+// Reference ops they stand in for (torch modules reached through `net(x)`,
+// sykepic/compute/probability.py:189): MaxPool2d(3,2,1), AdaptiveAvgPool2d(1),
+// BatchNorm2d in eval mode; `x.to(device)` layout conversion at :188.
+#include "spk_common.h"
+
+namespace {
+
+// one thread = one output pixel (4 bf16 channels = 8 B)
+template <typename T, bool NHWC, int DT>
+__global__ void to_nhwc4_kernel(const T* __restrict__ x, bf16_t* __restrict__ out, int n, int c,
+                                int h, int w, int wp) {
+  const size_t total = (size_t)n * h * wp;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int px = (int)(i % wp);
+    const size_t row = i / wp;  // img*h + y
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (px < w) {
+      const int img = (int)(row / h), y = (int)(row % h);
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) {
+        if (ch < c) {
+          const size_t src = NHWC ? (((size_t)img * h + y) * w + px) * c + ch
+                                  : (((size_t)img * c + ch) * h + y) * w + px;
+          v[ch] = sizeof(T) == 1 ? (float)x[src] * (1.0f / 255.0f) : (float)x[src];
+        }
+      }
+    }
+    u32x2_t o;
+    o[0] = pack2<DT>(v[0], v[1]);
+    o[1] = pack2<DT>(v[2], v[3]);
+    *(u32x2_t*)(out + i * 4) = o;
+  }
+}
+
+template <int DT>
+__device__ __forceinline__ void max8(u32x4_t& acc, const u32x4_t v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    // max of two exactly representable values is exactly representable
+    const bool l = lo_f32<DT>(v[j]) > lo_f32<DT>(acc[j]);
+    const bool h = hi_f32<DT>(v[j]) > hi_f32<DT>(acc[j]);
+    acc[j] = ((l ? v[j] : acc[j]) & 0xffffu) | ((h ? v[j] : acc[j]) & 0xffff0000u);
+  }
+}
+
+// one thread = 8 channels of one output pixel
+template <int DT>
+__global__ void maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int n, int h,
+                               int w, int c, int k, int stride, int pad, int ho, int wo) {
+  const int c8 = c >> 3;
+  const size_t total = (size_t)n * ho * wo * c8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    size_t p = i / c8;
+    const int ox = (int)(p % wo);
+    p /= wo;
+    const int oy = (int)(p % ho);
+    const int img = (int)(p / ho);
+    const unsigned NEG = DT == DT_BF16 ? 0xff80ff80u : 0xfc00fc00u;  // two -inf
+    u32x4_t acc = {NEG, NEG, NEG, NEG};
+    for (int r = 0; r < k; ++r) {
+      const int iy = oy * stride - pad + r;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int s = 0; s < k; ++s) {
+        const int ix = ox * stride - pad + s;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        max8<DT>(acc, *(const u32x4_t*)(x + (((size_t)img * h + iy) * w + ix) * c + cc * 8));
+      }
+    }
+    *(u32x4_t*)(y + i * 8) = acc;
+  }
+}
+
+// one thread = 8 channels of one image; fp32 mean over hw pixels
+template <int DT>
+__global__ void gavgpool_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int n, int hw,
+                                int c) {
+  const int c8 = c >> 3;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * c8) return;
+  const int img = i / c8, cc = i % c8;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bf16_t* p = x + (size_t)img * hw * c + cc * 8;
+  for (int t = 0; t < hw; ++t) {
+    const u32x4_t v = *(const u32x4_t*)(p + (size_t)t * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s[2 * j] += lo_f32<DT>(v[j]);
+      s[2 * j + 1] += hi_f32<DT>(v[j]);
+    }
+  }
+  const float inv = 1.0f / (float)hw;
+  float* o = y + (size_t)img * c + cc * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = s[j] * inv;
+}
+
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var,
+                               float eps, float* scale, float* bias, int c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c) return;
+  const float sc = g[i] / sqrtf(var[i] + eps);
+  scale[i] = sc;
+  bias[i] = b[i] - mean[i] * sc;
+}
+
+template <int DT>
+__device__ __forceinline__ float h16_to_f32(unsigned short v) { return lo_f32<DT>((unsigned int)v); }
+
+template <int DT>
+__global__ void pack_generic_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, size_t n,
+                                    int splitw) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const unsigned short hi = to_h16<DT>(w[i]);
+    out[i] = hi;
+    if (splitw) out[n + i] = to_h16<DT>(w[i] - h16_to_f32<DT>(hi));
+  }
+}
+
+// stem image: [Cout][8 filter rows][8 taps][4 ch]; tap t <-> filter column
+// t-1 (tap 0 is the zero that 16-B-aligns the pixel pairs), row 7 / ch 3 zero.
+template <int DT>
+__global__ void pack_stem_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout,
+                                 int kh, int kw, int cin, int splitw) {
+  const int total = cout * 256;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ch = i & 3, t = (i >> 2) & 7, r = (i >> 5) & 7, co = i >> 8;
+  float v = 0.f;
+  const int s = t - 1;
+  if (r < kh && s >= 0 && s < kw && ch < cin) v = w[(((size_t)co * kh + r) * kw + s) * cin + ch];
+  const unsigned short hi = to_h16<DT>(v);
+  out[i] = hi;
+  if (splitw) out[total + i] = to_h16<DT>(v - h16_to_f32<DT>(hi));
+}
+
+inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  if (g > 256 * 8 * 4) g = 256 * 8 * 4;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define DT_DISPATCH(dt, CALL_BF16, CALL_F16) \
+  do { if ((dt) == DT_F16) { CALL_F16; } else { CALL_BF16; } } while (0)
+
+template <typename T, bool NHWC>
+static void launch_to_nhwc4(const void* x, bf16_t* out, int n, int c, int h, int w, int wp, int dt, int g,
+                            hipStream_t s) {
+  DT_DISPATCH(dt,
+              hipLaunchKernelGGL((to_nhwc4_kernel<T, NHWC, DT_BF16>), dim3(g), dim3(256), 0, s, (const T*)x, out, n, c, h, w, wp),
+              hipLaunchKernelGGL((to_nhwc4_kernel<T, NHWC, DT_F16>), dim3(g), dim3(256), 0, s, (const T*)x, out, n, c, h, w, wp));
+}
+
+int spk_launch_to_nhwc4(const void* x, int layout, int dtype, int n, int c, int h, int w,
+                        bf16_t* out, int dt, hipStream_t s) {
+  if (c < 1 || c > 4) return -1;
+  const int wp = (w + 1) & ~1;
+  const size_t total = (size_t)n * h * wp;
+  const int g = grid_for(total, 256);
+  if (dtype == 0) {
+    if (layout == 0) launch_to_nhwc4<float, false>(x, out, n, c, h, w, wp, dt, g, s);
+    else launch_to_nhwc4<float, true>(x, out, n, c, h, w, wp, dt, g, s);
+  } else if (dtype == 2) {
+    if (layout == 0) launch_to_nhwc4<unsigned char, false>(x, out, n, c, h, w, wp, dt, g, s);
+    else launch_to_nhwc4<unsigned char, true>(x, out, n, c, h, w, wp, dt, g, s);
+  } else {
+    return -1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int spk_launch_maxpool(const bf16_t* x, bf16_t* y, int n, int h, int w, int c, int k, int stride,
+                       int pad, int ho, int wo, int dt, hipStream_t s) {
+  if (c % 8) return -1;
+  const size_t total = (size_t)n * ho * wo * (c / 8);
+  const int g = grid_for(total, 256);
+  DT_DISPATCH(dt,
+              hipLaunchKernelGGL(maxpool_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, x, y, n, h, w, c, k, stride, pad, ho, wo),
+              hipLaunchKernelGGL(maxpool_kernel<DT_F16>, dim3(g), dim3(256), 0, s, x, y, n, h, w, c, k, stride, pad, ho, wo));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int spk_launch_gavgpool(const bf16_t* x, float* y, int n, int hw, int c, int dt, hipStream_t s) {
+  if (c % 8) return -1;
+  const int total = n * (c / 8);
+  const int g = (total + 255) / 256;
+  DT_DISPATCH(dt,
+              hipLaunchKernelGGL(gavgpool_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, x, y, n, hw, c),
+              hipLaunchKernelGGL(gavgpool_kernel<DT_F16>, dim3(g), dim3(256), 0, s, x, y, n, hw, c));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int spk_launch_bn_fold(const float* g, const float* b, const float* mean, const float* var,
+                       float eps, float* scale, float* bias, int c, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((c + 255) / 256), dim3(256), 0, s, g, b, mean, var, eps,
+                     scale, bias, c);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
+                            int mode, int dt, int splitw, hipStream_t s) {
+  if (mode == CONV_MODE_STEM) {
+    if (kh > 7 || kw > 7 || cin > 4) return -1;
+    const int total = cout * 256;
+    const int g = (total + 255) / 256;
+    DT_DISPATCH(dt,
+                hipLaunchKernelGGL(pack_stem_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, w_krsc, out, cout, kh, kw, cin, splitw),
+                hipLaunchKernelGGL(pack_stem_kernel<DT_F16>, dim3(g), dim3(256), 0, s, w_krsc, out, cout, kh, kw, cin, splitw));
+  } else {
+    const size_t n = (size_t)cout * kh * kw * cin;
+    const int g = grid_for(n, 256);
+    DT_DISPATCH(dt,
+                hipLaunchKernelGGL(pack_generic_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, w_krsc, out, n, splitw),
+                hipLaunchKernelGGL(pack_generic_kernel<DT_F16>, dim3(g), dim3(256), 0, s, w_krsc, out, n, splitw));
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -1,0 +1,117 @@
+// Internal declarations shared by the HIP translation units of
+// libsykepic_hip.so (gfx950 only).  Public C-ABI: include/sykepic_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef unsigned short bf16_t;  // storage type of a bfloat16 value
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __builtin_bit_cast(float, ((unsigned int)v) << 16);
+}
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  return __builtin_bit_cast(bf16_t, (__bf16)f);  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+// 16-bit activation/weight storage type of a kernel instantiation.
+// bf16: training (range for gradients).  f16: inference (3 more mantissa bits
+// at the same MFMA rate; needed for the 1e-3 probability tolerance).
+enum { DT_BF16 = 0, DT_F16 = 1 };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+
+template <int DT> __device__ __forceinline__ float lo_f32(unsigned int u) {
+  if (DT == DT_BF16) return __builtin_bit_cast(float, u << 16);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+}
+template <int DT> __device__ __forceinline__ float hi_f32(unsigned int u) {
+  if (DT == DT_BF16) return __builtin_bit_cast(float, u & 0xffff0000u);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+}
+template <int DT> __device__ __forceinline__ unsigned short to_h16(float f) {
+  if (DT == DT_BF16) return f32_to_bf16(f);
+  // saturate instead of overflowing to inf
+  return __builtin_bit_cast(unsigned short, (_Float16)fminf(fmaxf(f, -65504.f), 65504.f));
+}
+template <int DT> __device__ __forceinline__ unsigned int pack2(float lo, float hi) {
+  return (unsigned int)to_h16<DT>(lo) | ((unsigned int)to_h16<DT>(hi) << 16);
+}
+template <int DT> __device__ __forceinline__ f32x4_t mfma16(const u32x4_t a, const u32x4_t b, f32x4_t c) {
+  if (DT == DT_BF16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution (conv_igemm.hip).
+//   M = N*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin (tap-major, channel
+//   minor), activations NHWC bf16, weights [Cout][K] bf16.
+// Epilogue: v = acc*scale[c] + bias[c] (+ residual) (ReLU) -> bf16.
+// ---------------------------------------------------------------------------
+enum { CONV_MODE_GENERIC = 0, CONV_MODE_STEM = 1, CONV_MODE_DGRAD = 2 };
+
+struct ConvArgs {
+  const bf16_t* x;      // [N,H,W,Cin]   (stem mode: Cin stored = 4)
+  const bf16_t* w;      // [Cout][K]
+  bf16_t* y;            // [N,Ho,Wo,Cout]
+  const bf16_t* res;    // [N,Ho,Wo,Cout] or null
+  const bf16_t* res_lo; // rounding remainder of res (res_true = res + res_lo) or null
+  bf16_t* y_lo;         // if set: y_true - y, kept for a later shortcut add
+  const float* scale;   // [Cout] or null (=1)
+  const float* bias;    // [Cout] or null (=0)
+  float* stats;         // train: [m_tiles][2][Cout] partial sum / sum of squares of the raw output, or null
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int kh, kw, stride, pad;
+  int M, K;
+  int relu;
+  int dt;               // DT_BF16 / DT_F16
+  int splitw;           // w holds [2][Cout][K]: hi then lo halves (f16 eval only)
+  unsigned int x_bytes, w_bytes;
+};
+
+// returns 0 on success; fills *m_tiles with the number of row tiles used
+// (needed to size/finalize the stats partials)
+int spk_conv_launch(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out);
+int spk_conv_m_tiles(int M, int Cout, int mode);
+const char* spk_conv_last_config();
+
+// ---------------------------------------------------------------------------
+// Pointwise / pooling / packing kernels (pointwise.hip)
+// ---------------------------------------------------------------------------
+// image batch -> NHWC bf16 with channels padded to 4 (stem input)
+int spk_launch_to_nhwc4(const void* x, int layout, int dtype, int n, int c, int h, int w,
+                        bf16_t* out, int dt, hipStream_t s);
+int spk_launch_maxpool(const bf16_t* x, bf16_t* y, int n, int h, int w, int c, int k, int stride,
+                       int pad, int ho, int wo, int dt, hipStream_t s);
+int spk_launch_gavgpool(const bf16_t* x, float* y, int n, int hw, int c, int dt, hipStream_t s);
+// BatchNorm(eval) folding: scale = g/sqrt(var+eps), bias = b - mean*scale
+int spk_launch_bn_fold(const float* g, const float* b, const float* mean, const float* var,
+                       float eps, float* scale, float* bias, int c, hipStream_t s);
+// master fp32 KRSC weights -> bf16 [Cout][K] (generic) or the stem image
+// splitw: out = [2][Cout][K], second half = remainder w - float(first half)
+int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
+                            int mode, int dt, int splitw, hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Head (head.hip): fp32 Linear layers, softmax, cross-entropy
+// ---------------------------------------------------------------------------
+// C[i][j] (+)= alpha * sum_k A(i,k)*B(j,k) + bias[j], arbitrary element strides
+int spk_launch_sgemm(const float* A, long sai, long sak, const float* B, long sbj, long sbk,
+                     const float* bias, float* C, long sci, long scj, int M, int N, int K,
+                     float alpha, int accumulate, hipStream_t s);
+int spk_launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,
+                          int out, hipStream_t s);
+int spk_launch_softmax(const float* z, float* p, int n, int c, float scale, hipStream_t s);
+// stats[0] += sum_i CE_i ; stats[1] += #(argmax == y); dlogits (may be null) = (softmax - onehot)/n
+int spk_launch_ce(const float* z, const int64_t* y, int n, int c, float* stats, float* dlogits,
+                  hipStream_t s);

@@ -1,0 +1,98 @@
+"""ctypes binding of libsykepic_hip.so (C-ABI: include/sykepic_hip.h).
+
+There is no CPU fallback: if the library is missing or fails to load, every
+use of the product path raises.
+"""
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("SYKEPIC_HIP_LIB", _HERE / "libsykepic_hip.so"))
+
+
+class LayerDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("cin", C.c_int32), ("cout", C.c_int32), ("k", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("relu", C.c_int32), ("src", C.c_int32),
+        ("dst", C.c_int32), ("res", C.c_int32), ("child", C.c_int32), ("p", C.c_float),
+        ("name", C.c_char * 96), ("bn", C.c_char * 96),
+    ]
+
+
+class OptimDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("lr", C.c_float * 3), ("beta1", C.c_float), ("beta2", C.c_float),
+        ("eps", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float),
+        ("grad_scale", C.c_float),
+    ]
+
+
+class LayerTime(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("ms", C.c_float), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
+DTYPE_F32, DTYPE_I64, DTYPE_U8 = 0, 1, 2
+OPT_SGD, OPT_ADAM = 0, 1
+
+# every symbol include/sykepic_hip.h declares: (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "spk_last_error": (C.c_char_p, []),
+    "spk_version": (C.c_char_p, []),
+    "spk_model_create": (C.c_int, [C.POINTER(LayerDesc), C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(_P)]),
+    "spk_model_destroy": (None, [_P]),
+    "spk_model_set_stream": (C.c_int, [_P, _P]),
+    "spk_model_num_params": (C.c_int, [_P]),
+    "spk_model_param_info": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "spk_model_load_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "spk_model_read_param": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "spk_model_set_requires_grad": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "spk_model_set_param_group": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "spk_model_set_infer_dtype": (C.c_int, [_P, C.c_int]),
+    "spk_model_set_precision": (C.c_int, [_P, C.c_int, C.c_int]),
+    "spk_model_set_seed": (C.c_int, [_P, C.c_uint64]),
+    "spk_forward_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                    _P]),
+    "spk_eval_step": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "spk_train_forward_backward": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             _P, _P, _P]),
+    "spk_optim_step": (C.c_int, [_P, C.POINTER(OptimDesc)]),
+    "spk_model_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "spk_model_read_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
+    "spk_model_read_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
+    "spk_model_profile_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(LayerTime), C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once). Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.is_file():
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP library is not built "
+            "(run syke-pic_amd/csrc/build.sh or __graft_entry__.build()); "
+            "there is no CPU fallback on the product path")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().spk_last_error().decode(errors="replace")
+        raise RuntimeError(f"libsykepic_hip error {rc}: {msg}")

@@ -1,0 +1,179 @@
+"""`sykepic prob`: class probabilities for raw IFCB samples on MI355X.
+
+Host-side mirror of the reference's inference workflow
+(``/root/reference/sykepic/compute/probability.py``): same entry points
+(``call`` :27, ``main`` :67, ``prepare_model`` :118, ``process_sample`` :133,
+``process_images`` :165, ``net_pass`` :180, ``probabilities_to_csv`` :200),
+same arguments, same ``<out>/YYYY/MM/DD/<sample>.prob.csv`` files.  What
+differs is below the seam: the forward and the base-1.3 softmax run fused in
+``libsykepic_hip.so``; ROIs go from the ``.roi`` blob straight to tensors (no
+PNG round trip beside the raw data, quirk Q8); no weights are downloaded
+before ``best_state.pth`` is loaded (quirk Q7).
+"""
+
+import logging
+from collections import namedtuple
+from configparser import ConfigParser
+from pathlib import Path
+
+import numpy as np
+import torch
+
+SOFTMAX_EXP = 1.3
+FILE_SUFFIX = ".prob"
+log = logging.getLogger("prob")
+
+EvalParams = namedtuple(
+    "EvalParams", ["batch_size", "num_workers", "classes", "img_shape", "transform", "device"])
+
+
+def roi_number(path):
+    """``…_00002.png`` -> 2 (reference probability.py:190)."""
+    return int(Path(path).stem.split("_")[-1])
+
+
+def net_pass(net, dataloader, device="cuda:0"):
+    """[(roi, [p_class...]), ...] sorted by ROI number.
+
+    ``dataloader`` yields ``(x [B,C,H,W] float32 in [0,1], paths)``.  The
+    probabilities are softmax(logits * ln 1.3), computed on the GPU."""
+    results = []
+    net.to(device)
+    net.eval()
+    pending = []
+    for batch in dataloader:
+        x, paths = batch[0], batch[1]
+        probs = net.probabilities(x, SOFTMAX_EXP)  # async on the stream
+        pending.append((tuple(roi_number(p) for p in paths), probs))
+    for rois, probs in pending:  # one device->host copy per batch, after all launches
+        results.extend(zip(rois, probs.tolist()))
+    return sorted(results)
+
+
+def probabilities_to_csv(probabilities, classes, csv_path):
+    csv_path = Path(csv_path)
+    csv_path.parent.mkdir(parents=True, exist_ok=True)
+    lines = ["roi," + ",".join(classes)]
+    for roi, probs in probabilities:
+        lines.append(f"{roi}," + ",".join("%.5f" % p for p in probs))
+    csv_path.write_text("\n".join(lines) + "\n")
+
+
+def prepare_model(model_dir, device=None):
+    """model directory -> (net, classes, img_shape, eval_transform, device)."""
+    from .config import get_img_shape, get_network, get_transforms
+    model_dir = Path(model_dir)
+    classes = (model_dir / "class_names.txt").read_text().splitlines()
+    config = ConfigParser()
+    config.read(model_dir / "config.ini")
+    img_shape = get_img_shape(config)
+    _, eval_transform = get_transforms(config, img_shape)
+    device = torch.device(device or "cuda:0")
+    net = get_network(config, len(classes), device=device, pretrained_ok=False)
+    net.load_state_dict(torch.load(model_dir / "best_state.pth", map_location="cpu"))
+    return net, classes, img_shape, eval_transform, device
+
+
+def _batches(items, transform, batch_size):
+    """(x, paths) batches from [(name, HxW or HxWx3 uint8 array)]."""
+    for i in range(0, len(items), batch_size):
+        chunk = items[i:i + batch_size]
+        x = torch.stack([transform(img) for _, img in chunk])
+        yield x, [name for name, _ in chunk]
+
+
+def process_sample(sample_path, net, params, out_dir, force=False):
+    from . import files, ifcb
+    sample_path = Path(sample_path)
+    sample = sample_path.name
+    csv_path = files.sample_csv_path(sample_path, out_dir, suffix=FILE_SUFFIX)
+    if csv_path.is_file():
+        if force:
+            log.warning(f"{csv_path.name} already exists, overwriting")
+        else:
+            log.warning(f"{csv_path.name} already exists, skipping")
+            return sample
+    log.debug(f"Computing probabilities for {sample}")
+    rois = ifcb.read_rois(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"))
+    items = [(f"{sample}_{num:05d}.png", _as_chans(img, params.img_shape[0])) for num, img in rois]
+    probabilities = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
+    probabilities_to_csv(probabilities, params.classes, csv_path)
+    return sample
+
+
+def _as_chans(gray, num_chans):
+    """What cv2.imread + BGR2RGB gives for a greyscale PNG (data.py:214-219)."""
+    if num_chans == 1:
+        return gray[:, :, None]
+    return np.repeat(gray[:, :, None], 3, axis=2)
+
+
+def process_images(img_paths, net, params, csv_path, force=False):
+    from . import pngio
+    csv_path = Path(csv_path)
+    if csv_path.is_file():
+        if force:
+            log.warning(f"{csv_path.name} already exists, overwriting")
+        else:
+            log.warning(f"{csv_path.name} already exists, skipping")
+            return
+    items = [(str(p), pngio.read_image(p, params.img_shape[0])) for p in img_paths]
+    probabilities = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
+    probabilities_to_csv(probabilities, params.classes, csv_path)
+
+
+def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=False,
+         progress_bar=True, samples_as_images=False):
+    net, classes, img_shape, eval_transform, device = prepare_model(model_dir)
+    params = EvalParams(batch_size, num_workers, classes, img_shape, eval_transform, device)
+    try:
+        from tqdm import tqdm
+    except ImportError:  # pragma: no cover
+        tqdm = None
+    if samples_as_images:
+        it = sample_paths.items()
+        if progress_bar and tqdm:
+            it = tqdm(it, desc="Processing samples")
+        for sample, img_paths in it:
+            process_images(img_paths, net, params, Path(out_dir) / f"{sample}{FILE_SUFFIX}.csv", force)
+        return None
+    it = sample_paths
+    if progress_bar and tqdm:
+        it = tqdm(it, desc="Processing samples")
+    done = set()
+    for sample_path in it:
+        try:
+            done.add(process_sample(sample_path, net, params, out_dir, force))
+        except ValueError:
+            log.exception(f"Faulty raw data for {Path(sample_path).name}")
+        except Exception:
+            log.exception(f"Unexpected error for {Path(sample_path).name}")
+    return done
+
+
+def call(args):
+    from . import files
+    if args.image_dir or args.images:
+        as_images = True
+        if args.image_dir:
+            img_paths = sorted(Path(args.image_dir).rglob("*.png"))
+        else:
+            img_paths = sorted(Path(p) for p in args.images)
+        sample_paths = {}
+        for p in img_paths:
+            sample_paths.setdefault(p.name.rpartition("_")[0], []).append(p)
+        selected = sample_paths
+    else:
+        as_images = False
+        if args.raw:
+            sample_paths = files.list_sample_paths(args.raw)
+        else:
+            sample_paths = [Path(p) for p in args.samples]
+        selected = []
+        for sp in sample_paths:  # .roi files over 1 GB are skipped (probability.py:45-51)
+            if sp.with_suffix(".roi").stat().st_size <= 1e9:
+                selected.append(sp)
+            else:
+                log.warning(f"{sp.name} is over 1G, skipping")
+    return main(selected, args.model, args.out, args.batch_size, args.num_workers, args.force,
+                progress_bar=True, samples_as_images=as_images)

@@ -1,0 +1,113 @@
+"""Parity of the HIP inference path (through the C-ABI) with the oracle and
+with the golden vectors produced by the reference's own net_pass.
+
+Tolerances (north_star): per-class probabilities within 1e-3 of the fp32 CPU
+reference; top-1 identical wherever the reference's top-2 margin exceeds the
+probability tolerance (SURVEY.md §7 "hard parts": near-ties below the error
+bound are excluded explicitly)."""
+
+import numpy as np
+import pytest
+import torch
+
+from sykepic_hip import arch, synth
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-3
+
+
+def _state(network, golden, tag, classes=50):
+    g = arch.build_graph(network, classes)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    last = [k for k in sd if k.startswith("head.") and k.endswith(".bias")][-1]
+    sd[last] = sd[last] + golden[f"{tag}_bias_adj"]
+    return g, sd
+
+
+def _hipnet(network, sd, classes=50):
+    from sykepic_hip.net import HipNet
+    net = HipNet(network, classes, weights=None)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return net.eval()
+
+
+@pytest.mark.parametrize("network,hw", [("resnet18", 180), ("resnet18", 224), ("resnet50", 224)])
+def test_probabilities_match_reference_golden(golden_dir, network, hw):
+    gold = np.load(golden_dir / "net_pass.npz")
+    tag = f"{network}_{hw}"
+    g, sd = _state(network, gold, tag)
+    net = _hipnet(network, sd)
+    n = len(gold[f"{tag}_rois_in"])
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=0)).cuda()
+    from sykepic_hip.prob import net_pass
+    rois = [int(r) for r in gold[f"{tag}_rois_in"]]
+    paths = [f"/x/D20180712T065600_IFCB114_{r:05d}.png" for r in rois]
+    half = n // 2
+    res = net_pass(net, [(x[:half], paths[:half]), (x[half:], paths[half:])], "cuda:0")
+    assert [r for r, _ in res] == gold[f"{tag}_rois_out"].tolist()
+    p = np.array([q for _, q in res], dtype=np.float64)
+    ref = gold[f"{tag}_probs"].astype(np.float64)
+    err = np.abs(p - ref).max()
+    print(f"{tag}: max |dp| = {err:.2e}")
+    assert err <= PROB_TOL
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    decided = (top2[:, 1] - top2[:, 0]) > 2 * PROB_TOL
+    assert decided.sum() >= n // 2
+    assert (p.argmax(1)[decided] == ref.argmax(1)[decided]).all()
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+
+
+@pytest.mark.parametrize("network,hw,n", [("resnet18", 96, 5), ("resnet50", 64, 3), ("resnet34", 64, 2)])
+def test_layerwise_vs_oracle(network, hw, n):
+    """Every activation of the graph against the torch fp32 interpreter
+    (bf16 storage => relative tolerance 2^-7 of the layer's scale)."""
+    from oracle import graph_eval, refnet
+    g = arch.build_graph(network, 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=3)
+    net = _hipnet(network, sd)
+    x = synth.synth_images(n, 3, hw, hw, seed=21)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    acts = graph_eval.run(g, tsd, torch.from_numpy(x))
+    # the interpreter itself agrees with the reference-pinned oracle module
+    ref = refnet.load_numpy_state(refnet.RefNet(network, 50), sd)
+    z_ref = refnet.probabilities(ref, torch.from_numpy(x), base=None)
+    assert torch.allclose(acts[g.ops[-1].dst], z_ref, atol=1e-4, rtol=1e-4)
+    z = net.forward(torch.from_numpy(x).cuda()).cpu()
+    worst = 0.0
+    for op in g.ops:
+        want = acts[op.dst]
+        got = net.read_activation(op.dst, n, tuple(want.shape))
+        scale = float(want.abs().max()) + 1e-6
+        err = float((got - want).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 0.03, f"{network} {op.name or op.kind} id {op.dst}: rel err {err:.3e}"
+    print(f"{network}@{hw}: worst layer rel err {worst:.2e}")
+    assert float((z - z_ref).abs().max()) / (float(z_ref.abs().max()) + 1e-6) < 0.03
+
+
+def test_ragged_batches_and_odd_sizes():
+    """batch of 1, batch not a multiple of any tile, odd image width."""
+    from oracle import refnet
+    g = arch.build_graph("resnet18", 7)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=4)
+    net = _hipnet("resnet18", sd, classes=7)
+    ref = refnet.load_numpy_state(refnet.RefNet("resnet18", 7), sd)
+    for n, h, w in [(1, 64, 64), (3, 75, 101), (13, 40, 56)]:
+        x = torch.from_numpy(synth.synth_images(n, 3, h, w, seed=n))
+        p = net.probabilities(x.cuda()).cpu()
+        pr = refnet.probabilities(ref, x)
+        assert float((p - pr).abs().max()) <= PROB_TOL, (n, h, w)
+
+
+def test_state_dict_round_trip():
+    g = arch.build_graph("resnet18", 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    sd["base.1.num_batches_tracked"] = np.array(1234567890123, dtype=np.int64)
+    net = _hipnet("resnet18", sd)
+    out = net.state_dict()
+    assert list(out.keys()) == [k for k, _, _ in arch.param_specs(g)]
+    for k, v in sd.items():
+        assert np.array_equal(out[k].numpy(), np.asarray(v)), k
+    with pytest.raises(RuntimeError):
+        net.load_state_dict({"nope": torch.zeros(1)})
