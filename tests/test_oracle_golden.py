@@ -1,0 +1,88 @@
+"""The oracle (torch fp32 restatement under oracle/) against the golden
+vectors that the REFERENCE's own code produced (tests/golden/make_golden.py).
+This is what pins the oracle; CPU only."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graph_eval, refnet
+from sykepic_hip import arch, synth
+
+
+def _net(network, classes, sd):
+    return refnet.load_numpy_state(refnet.RefNet(network, classes), sd)
+
+
+@pytest.mark.parametrize("network,hw", [("resnet18", 180), ("resnet18", 224), ("resnet50", 224)])
+def test_net_pass_matches_reference(golden_dir, network, hw):
+    gold = np.load(golden_dir / "net_pass.npz")
+    tag = f"{network}_{hw}"
+    g = arch.build_graph(network, 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    last = [k for k in sd if k.startswith("head.") and k.endswith(".bias")][-1]
+    sd[last] = sd[last] + gold[f"{tag}_bias_adj"]
+    net = _net(network, 50, sd)
+    rois = gold[f"{tag}_rois_in"].tolist()
+    n = len(rois)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=0))
+    paths = [f"/x/D20180712T065600_IFCB114_{r:05d}.png" for r in rois]
+    res = refnet.net_pass(net, [(x[: n // 2], paths[: n // 2]), (x[n // 2:], paths[n // 2:])])
+    assert [r for r, _ in res] == gold[f"{tag}_rois_out"].tolist()
+    p = np.array([q for _, q in res])
+    assert np.abs(p - gold[f"{tag}_probs"]).max() < 1e-6
+    # the layer-graph interpreter used for layer-wise GPU checks agrees too
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    z = graph_eval.run(g, tsd, x)[g.ops[-1].dst]
+    assert np.abs(z.numpy() - gold[f"{tag}_logits"]).max() < 2e-3 * np.abs(gold[f"{tag}_logits"]).max()
+
+
+@pytest.mark.parametrize("optim_name", ["SGD", "Adam"])
+def test_train_steps_match_reference(golden_dir, optim_name):
+    """3 epochs x 1 batch with LRWarmup steps at epochs 1,2,3 (one step per
+    phase of the unfreeze schedule), as the reference's train_net ran them."""
+    gold = np.load(golden_dir / f"train_{optim_name.lower()}.npz")
+    n, hw, classes = 8, 64, 10
+    g = arch.build_graph("resnet18", classes)
+    specs = arch.param_specs(g)
+    sd0 = synth.synth_state_dict(specs, seed=5, logit_gain=2.0)
+    net = _net("resnet18", classes, sd0)
+    refnet.freeze_base(net.base)
+    opt = refnet.make_optimizer(net, optim_name, 0.01)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10))
+    y = torch.from_numpy(synth.synth_labels(n, classes, seed=11))
+    xv = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=12))
+    yv = torch.from_numpy(synth.synth_labels(n, classes, seed=13))
+    keys = [k for k, _, _ in specs]
+    for epoch in (1, 2, 3):
+        refnet.warmup_step(net, opt, epoch, 0.1, 0.5, 1, 2, 3)
+        net.train()
+        loss, _, logits = refnet.train_step(net, opt, x, y)
+        assert abs(loss - gold["train_loss"][epoch - 1]) < 1e-5
+        assert np.abs(logits.numpy() - gold["train_logits"][epoch - 1]).max() < 1e-4
+        snap = net.state_dict()
+        l2 = np.array([float(snap[k].double().norm()) for k in keys])
+        assert np.allclose(l2, gold[f"e{epoch}_l2"], rtol=1e-5, atol=1e-6)
+        assert int(snap["base.1.num_batches_tracked"]) == int(gold[f"e{epoch}_nbt"])
+        for k in ("base.0.weight", "base.1.running_var", "base.7.1.conv2.weight", "head.2.bias"):
+            assert np.allclose(snap[k].flatten()[:64].numpy(), gold[f"e{epoch}_{k}"], rtol=1e-4, atol=1e-6), k
+        net.eval()
+        vloss, _, vlogits = refnet.eval_step(net, xv, yv)
+        assert abs(vloss - gold["val_loss"][epoch - 1]) < 1e-5
+    assert np.allclose([gp["lr"] for gp in opt.param_groups], gold["group_lr"][0])
+    assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == gold["group_sizes"].tolist()
+
+
+def test_lr_warmup_trajectory(golden_dir):
+    traj = json.loads((golden_dir / "schedules.json").read_text())["lr_warmup"]
+    g = arch.build_graph("resnet18", 50)
+    net = _net("resnet18", 50, synth.synth_state_dict(arch.param_specs(g), seed=2))
+    refnet.freeze_base(net.base)
+    opt = refnet.make_optimizer(net, "Adam", 0.01)
+    for rec in traj:
+        refnet.warmup_step(net, opt, rec["epoch"], 0.1, 0.5, 4, 14, 24)
+        assert np.allclose([gp["lr"] for gp in opt.param_groups], rec["lr"])
+        assert [len(gp["params"]) for gp in opt.param_groups] == rec["n_tensors"]
+        assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == rec["n_elems"]
