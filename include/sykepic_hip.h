@@ -165,6 +165,10 @@ int spk_model_read_grad(spk_model* m, const char* key, void* host, int64_t numel
  * head).  The stem input (id 0) is not readable.  Synchronous. */
 int spk_model_read_activation(spk_model* m, int tensor_id, int n, float* host, int64_t numel);
 
+/* Test hook: gradient w.r.t. activation `tensor_id` left by the most recent
+ * spk_train_forward_backward, float32 NCHW like spk_model_read_activation. */
+int spk_model_read_activation_grad(spk_model* m, int tensor_id, int n, float* host, int64_t numel);
+
 /* Per-layer timing of the last spk_forward_infer call (HIP events on the
  * model's stream); used by bench.py for the roofline line. Returns the
  * number of records written. */

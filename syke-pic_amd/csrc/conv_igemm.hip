@@ -85,6 +85,12 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
       a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
       a_w0[i] = p0;
       a_base[i] = ((img * a.H + h0) * a.W + p0) * 4;
+    } else if (MODE == CONV_MODE_DGRAD) {
+      // rows are pixels of the forward conv's INPUT; the "input" tensor is dy.
+      // tap (r,s) reads dy[(h+pad-r)/stride][(w+pad-s)/stride] when divisible.
+      a_h0[i] = (m < a.M) ? ho + a.pad : -(1 << 20);
+      a_w0[i] = wo + a.pad;
+      a_base[i] = img * a.H * a.W * a.Cin + chunk * 8;
     } else {
       const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
       a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
@@ -116,6 +122,22 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
         const bool ok = (krow < 7) && ((unsigned)hi < (unsigned)a.H) && ((unsigned)px < (unsigned)a.W);
         const unsigned off = ok ? (unsigned)((a_base[i] + (krow * a.W + 2 * qq) * 4) * 2) : 0x80000000u;
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      }
+    } else if (MODE == CONV_MODE_DGRAD) {
+      const int sh = a.stride == 2 ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < A_ITERS; ++i) {
+        const int t = a_h0[i] - kr, u = a_w0[i] - ks_;
+        const bool ok = (t >= 0) && (u >= 0) && (((t | u) & sh) == 0) && ((t >> sh) < a.H) &&
+                        ((u >> sh) < a.W);
+        const unsigned off =
+            ok ? (unsigned)((a_base[i] + ((t >> sh) * a.W + (u >> sh)) * a.Cin + kc0) * 2) : 0x80000000u;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      }
+      kc0 += BK;
+      if (kc0 >= a.Cin) {
+        kc0 = 0;
+        if (++ks_ == a.kw) { ks_ = 0; ++kr; }
       }
     } else {
       const int tap_off = (kr * a.W + ks_) * a.Cin + kc0;
@@ -333,6 +355,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.dt == DT_F16) { if (a.splitw) SPK_GO(CONV_MODE_STEM, DT_F16, 1); SPK_GO(CONV_MODE_STEM, DT_F16, 0); }
     SPK_GO(CONV_MODE_STEM, DT_BF16, 0);
   }
+  if (mode == CONV_MODE_DGRAD) SPK_GO(CONV_MODE_DGRAD, DT_BF16, 0);
   if (a.dt == DT_F16) { if (a.splitw) SPK_GO(CONV_MODE_GENERIC, DT_F16, 1); SPK_GO(CONV_MODE_GENERIC, DT_F16, 0); }
   SPK_GO(CONV_MODE_GENERIC, DT_BF16, 0);
 #undef SPK_GO

@@ -1,0 +1,240 @@
+// Weight gradient of a 2-D convolution on gfx950 (bf16 in, fp32 out).
+//
+// Part of `loss.backward()` at sykepic/train/train.py:242 for every conv whose
+// weight has requires_grad (the unfreeze schedule of
+// sykepic/train/network.py:98-130 decides which).
+//
+//   dW[co][r][s][ci] = sum over output pixels m=(n,ho,wo) of
+//                      dy[m][co] * x[n, ho*stride-pad+r, wo*stride-pad+s, ci]
+//
+// GEMM view: rows = Cout, cols = (tap, Cin), contraction = pixels.  Both
+// operands are pixel-major in memory (NHWC), i.e. k-strided for the MFMA, so
+// the [pixel][channel] tiles are staged in LDS exactly as they are loaded
+// (coalesced 16-B rows) and read back TRANSPOSED with ds_read_b64_tr_b16 — the
+// hardware transpose gives each lane its 4 consecutive k for one channel.  The
+// LDS images are XOR-swizzled so that the transposed reads are conflict-free.
+// The pixel range is split over blockIdx.y; every split writes its own fp32
+// slab and a second kernel adds the slabs in a fixed order (reproducible, no
+// atomics).
+#include "spk_common.h"
+
+struct WgradArgs {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* slabs;  // [splits][Cout][Ktot]
+  int N, H, W, Cin, Ho, Wo, Cout;
+  int kh, kw, stride, pad;
+  int M, Ktot;
+  int pix_per_split;
+  unsigned int x_bytes, dy_bytes;
+};
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <int WIDTH>
+__device__ __forceinline__ int tile_off(int row, int ch) {
+  if (WIDTH == 128)  // 256-B rows: T10 image (b)
+    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+  // 128-B rows: two rows per 256-B bank period; spread row bit 1 and bit 3
+  return 128 * row + 16 * (ch ^ ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1));
+}
+
+// transposed fragment: 8 consecutive k (rows k0 + 8*(lane>>4) + 0..7) of column
+// col0 + (lane&15)
+template <int WIDTH>
+__device__ __forceinline__ u32x4_t tr_frag(const unsigned char* tile, int k0, int col0, int lane) {
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+  const int ch = (col0 >> 3) + (p >> 1);
+  const int r0 = k0 + 8 * g + q;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_t __attribute__((address_space(3)))*)(tile + tile_off<WIDTH>(r0, ch) + 8 * (p & 1)));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (s16x4_t __attribute__((address_space(3)))*)(tile + tile_off<WIDTH>(r0 + 4, ch) + 8 * (p & 1)));
+  u32x2_t a = __builtin_bit_cast(u32x2_t, lo), b = __builtin_bit_cast(u32x2_t, hi);
+  return u32x4_t{a[0], a[1], b[0], b[1]};
+}
+
+template <int BCO, int BCI, bool STEM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_tiles) {
+  constexpr int BK = 64;  // pixels per LDS stage
+  constexpr int WCO = BCO / 2, WCI = BCI / 2;
+  constexpr int MT = WCO / 16, NT = WCI / 16;
+  constexpr int DY_BYTES = BK * BCO * 2, X_BYTES = BK * BCI * 2;
+  constexpr int DY_CPR = BCO / 8, X_CPR = BCI / 8;          // 16-B chunks per row
+  constexpr int DY_RPP = 256 / DY_CPR, X_RPP = 256 / X_CPR; // rows per pass
+  constexpr int DY_IT = BK / DY_RPP, X_IT = BK / X_RPP;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sD = smem;                  // [2][BK][BCO]
+  unsigned char* const sX = smem + 2 * DY_BYTES;   // [2][BK][BCI]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int co0 = (blockIdx.x % co_tiles) * BCO;
+  const int kcol0 = (blockIdx.x / co_tiles) * BCI;
+  const int split = blockIdx.y;
+  const int p_begin = split * a.pix_per_split;
+  const int p_end = min(a.M, p_begin + a.pix_per_split);
+
+  int tap_r = 0, tap_s = 0, ci0 = 0;
+  if (!STEM) {
+    const int tap = kcol0 / a.Cin;
+    ci0 = kcol0 - tap * a.Cin;
+    tap_r = tap / a.kw;
+    tap_s = tap - tap_r * a.kw;
+  }
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
+
+  const int d_ch = tid % DY_CPR, d_row = tid / DY_CPR;
+  const int x_ch = tid % X_CPR, x_row = tid / X_CPR;
+  const int HoWo = a.Ho * a.Wo;
+
+  u32x4_t rdv[DY_IT], rxv[X_IT];
+
+  auto issue = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i) {
+      const int m = p0 + d_row + i * DY_RPP;
+      const unsigned off = m < p_end ? (unsigned)((m * a.Cout + co0 + d_ch * 8) * 2) : 0x80000000u;
+      rdv[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, off, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int m = p0 + x_row + i * X_RPP;
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      unsigned off = 0x80000000u;
+      if (STEM) {
+        // column chunk -> (filter row, pixel pair) of the [8 rows][8 taps][4 ch] image
+        const int fr = (kcol0 >> 5) + (x_ch >> 2), qq = x_ch & 3;
+        const int hi = ho * 2 - 3 + fr, px = wo * 2 - 4 + 2 * qq;
+        if (m < p_end && fr < 7 && (unsigned)hi < (unsigned)a.H && (unsigned)px < (unsigned)a.W)
+          off = (unsigned)((((img * a.H + hi) * a.W + px) * 4) * 2);
+      } else {
+        const int hi = ho * a.stride - a.pad + tap_r, wi = wo * a.stride - a.pad + tap_s;
+        if (m < p_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+          off = (unsigned)((((img * a.H + hi) * a.W + wi) * a.Cin + ci0 + x_ch * 8) * 2);
+      }
+      rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < DY_IT; ++i)
+      *(u32x4_t*)(sD + buf * DY_BYTES + tile_off<BCO>(d_row + i * DY_RPP, d_ch)) = rdv[i];
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i)
+      *(u32x4_t*)(sX + buf * X_BYTES + tile_off<BCI>(x_row + i * X_RPP, x_ch)) = rxv[i];
+  };
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (p_end - p_begin + BK - 1) / BK;
+  if (nsteps > 0) {
+    issue(p_begin);
+    stash(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) issue(p_begin + (st + 1) * BK);
+    const unsigned char* pd = sD + buf * DY_BYTES;
+    const unsigned char* px = sX + buf * X_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      u32x4_t fa[MT], fb[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) fa[i] = tr_frag<BCO>(pd, ks * 32, wr * WCO + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) fb[j] = tr_frag<BCI>(px, ks * 32, wc * WCI + j * 16, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT_BF16>(fa[i], fb[j], acc[i][j]);
+    }
+    if (st + 1 < nsteps) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // C layout: col = lane&15 (ci), row = (lane>>4)*4 + reg (co)
+  float* slab = a.slabs + (size_t)split * a.Cout * a.Ktot;
+  const int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wr * WCO + i * 16 + fq * 4 + r;
+        const int kc = kcol0 + wc * WCI + j * 16 + fr;
+        slab[(size_t)co * a.Ktot + kc] = acc[i][j][r];
+      }
+}
+
+template <int BCO, int BCI, bool STEM>
+int launch(const WgradArgs& a, int splits, hipStream_t s) {
+  const int co_tiles = a.Cout / BCO;
+  const int k_tiles = a.Ktot / BCI;
+  const size_t lds = 2 * (size_t)64 * (BCO + BCI) * 2;
+  auto k = conv_wgrad_kernel<BCO, BCI, STEM>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(co_tiles * k_tiles, splits), dim3(256), lds, s, a, co_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+// Chooses the split count (fills *splits, *pix_per_split); slabs must hold
+// splits*Cout*Ktot floats.
+void spk_wgrad_plan(int M, int Cout, int Ktot, int* splits, int* pix_per_split) {
+  const int bco = Cout % 128 == 0 ? 128 : 64;
+  const int bci = 128;
+  const int tiles = (Cout / bco) * ((Ktot + bci - 1) / bci);
+  int sp = (1024 + tiles - 1) / tiles;
+  const int max_sp = (M + 511) / 512;
+  if (sp > max_sp) sp = max_sp;
+  if (sp < 1) sp = 1;
+  int pps = ((M + sp - 1) / sp + 63) / 64 * 64;
+  sp = (M + pps - 1) / pps;
+  *splits = sp;
+  *pix_per_split = pps;
+}
+
+int spk_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* slabs, int N, int H, int W, int Cin,
+                     int Ho, int Wo, int Cout, int k, int stride, int pad, int stem, int splits,
+                     int pix_per_split, hipStream_t s) {
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.slabs = slabs;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.kh = a.kw = k; a.stride = stride; a.pad = pad;
+  a.M = N * Ho * Wo;
+  a.Ktot = stem ? 256 : k * k * Cin;
+  a.pix_per_split = pix_per_split;
+  a.x_bytes = (unsigned)((size_t)N * H * W * (stem ? 4 : Cin) * 2);
+  a.dy_bytes = (unsigned)((size_t)a.M * Cout * 2);
+  if (stem) {
+    if (Cout % 64) return -2;
+    return launch<64, 128, true>(a, splits, s);
+  }
+  if (Cin % 128 == 0) {
+    if (Cout % 128 == 0) return launch<128, 128, false>(a, splits, s);
+    return launch<64, 128, false>(a, splits, s);
+  }
+  if (Cout % 128 == 0) return launch<128, 64, false>(a, splits, s);
+  return launch<64, 64, false>(a, splits, s);
+}

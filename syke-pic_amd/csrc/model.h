@@ -84,3 +84,4 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
                             float* logits_dev);
 int spk_read_flat(spk_model* m, const float* flat, const Param& p, float* host);
 void spk_train_free(spk_model* m);
+void spk_train_mark_dirty(spk_model* m);

@@ -244,6 +244,7 @@ extern "C" int spk_model_load_param(spk_model* m, const char* key, const void* h
   }
   HIP_TRY(hipMemcpy(m->pbuf + p->off, src, (size_t)numel * 4, hipMemcpyHostToDevice));
   m->dirty = true;
+  spk_train_mark_dirty(m);
   return SPK_OK;
 }
 

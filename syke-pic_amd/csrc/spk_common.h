@@ -115,3 +115,45 @@ int spk_launch_softmax(const float* z, float* p, int n, int c, float scale, hipS
 // stats[0] += sum_i CE_i ; stats[1] += #(argmax == y); dlogits (may be null) = (softmax - onehot)/n
 int spk_launch_ce(const float* z, const int64_t* y, int n, int c, float* stats, float* dlogits,
                   hipStream_t s);
+
+// ---------------------------------------------------------------------------
+// Training kernels (train_kernels.hip, conv_wgrad.hip)
+// ---------------------------------------------------------------------------
+struct OptEntry {
+  unsigned long long off;  // element offset in the flat buffers
+  unsigned int n;
+  float lr, bc1, bc2s;
+  int first;               // SGD momentum: first step of this tensor
+};
+struct OptTable {
+  OptEntry e[64];
+  int count;
+};
+
+int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, const float* gamma,
+                           const float* beta, float* rmean, float* rvar, float* mean, float* invstd,
+                           float* scale, float* shift, float eps, float momentum, hipStream_t s);
+int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift, const bf16_t* res,
+                        bf16_t* a, size_t numel, int C, int relu, hipStream_t s);
+int spk_bn_bwd_blocks(int M, int C, int* rows_per_block);
+int spk_launch_bn_bwd(const bf16_t* g, const bf16_t* a, const bf16_t* y, const float* mean,
+                      const float* invstd, const float* gamma, float* partials, float* coef,
+                      float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
+                      int C, int relu, hipStream_t s);
+int spk_launch_maxpool_idx(const bf16_t* x, bf16_t* y, unsigned char* idx, int n, int h, int w, int c,
+                           int k, int stride, int pad, int ho, int wo, hipStream_t s);
+int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* gx, int n, int h, int w,
+                           int c, int k, int stride, int pad, int ho, int wo, hipStream_t s);
+int spk_launch_gavgpool_bwd(const float* gy, bf16_t* gx, int n, int hw, int c, hipStream_t s);
+int spk_launch_colsum(const float* dy, float* db, int n, int c, hipStream_t s);
+int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s);
+int spk_launch_stem_wgrad_unpack(const float* slabs, float* out, int cout, int kh, int kw, int cin,
+                                 int splits, hipStream_t s);
+int spk_launch_pack_dgrad(const float* w, bf16_t* out, int cout, int taps, int cin, hipStream_t s);
+int spk_launch_opt_multi(int adam, float* p, const float* g, float* m, float* v, const OptTable& t,
+                         float b1, float b2, float eps, float wd, float momentum, float gscale,
+                         hipStream_t s);
+void spk_wgrad_plan(int M, int Cout, int Ktot, int* splits, int* pix_per_split);
+int spk_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* slabs, int N, int H, int W, int Cin,
+                     int Ho, int Wo, int Cout, int k, int stride, int pad, int stem, int splits,
+                     int pix_per_split, hipStream_t s);

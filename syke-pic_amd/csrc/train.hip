@@ -1,28 +1,428 @@
-// Training path (train-mode BatchNorm, backward, optimizer) — entry points of
-// include/sykepic_hip.h that stand in for sykepic/train/train.py:239-243.
+// Training step executor: the library side of
+//   net.train(); optimizer.zero_grad(); out = net(x); loss = CE(out, y);
+//   loss.backward(); optimizer.step()         (sykepic/train/train.py:233,239-243)
+// bf16 activations / gradients, fp32 master weights, statistics and optimizer
+// state.  Train-mode BatchNorm everywhere (train.py:233 overrides the .eval()
+// of frozen modules); data gradients flow through every layer down to the
+// stem's BatchNorm, weight gradients only where requires_grad is set
+// (sykepic/train/network.py:133-172).
 #include "model.h"
 
-struct TrainState {};
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+static int tfail(int code, const std::string& msg) {
+  spk_set_error(msg);
+  return code;
+}
+#define HIP_TRY(expr)                                                          \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) return tfail(SPK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+#define SPK_TRY(expr)            \
+  do {                           \
+    int r_ = (expr);             \
+    if (r_ != SPK_OK) return r_; \
+  } while (0)
+#define K_TRY(expr, what)                                            \
+  do {                                                               \
+    if ((expr) != 0) return tfail(SPK_ERR_HIP, std::string(what) + " launch failed"); \
+  } while (0)
+
+struct ConvTrain {
+  size_t raw_off = 0;       // bf16 raw conv output (pre-BN), same shape as dst
+  size_t stat_off = 0;      // floats: mean[C], invstd[C], scale[C], shift[C]
+  size_t wfwd_off = 0;      // bf16 [Cout][K] forward image
+  size_t wdg_off = 0;       // bf16 [Cin][taps][Cout] dgrad image
+};
+
+struct TrainState {
+  // persistent across plans
+  float* gbuf = nullptr;   // flat gradients   [n_train]
+  float* m1 = nullptr;     // Adam exp_avg / SGD momentum [n_train]
+  float* m2 = nullptr;     // Adam exp_avg_sq [n_train]
+  bf16_t* wpack = nullptr; // bf16 forward + dgrad weight images
+  float* stats = nullptr;  // per-conv mean/invstd/scale/shift
+  std::vector<ConvTrain> conv;  // indexed by layer
+  bool weights_dirty = true;
+  bool sgd_started = false;
+
+  // per (n,h,w) plan
+  void* arena = nullptr;
+  int cap_n = 0, cap_h = 0, cap_w = 0;
+  std::vector<size_t> goff;   // gradient tensor per activation id
+  size_t dy_off = 0, idx_off = 0, part_off = 0, coef_off = 0, slab_off = 0;
+  size_t part_floats = 0, slab_floats = 0;
+
+  void* G(int t) const { return (char*)arena + goff[t]; }
+  bf16_t* RAW(int layer) const { return (bf16_t*)((char*)arena + conv[layer].raw_off); }
+};
 
 void spk_train_free(spk_model* m) {
-  delete m->train;
+  TrainState* t = m->train;
+  if (!t) return;
+  if (t->arena) hipFree(t->arena);
+  if (t->gbuf) hipFree(t->gbuf);
+  if (t->m1) hipFree(t->m1);
+  if (t->m2) hipFree(t->m2);
+  if (t->wpack) hipFree(t->wpack);
+  if (t->stats) hipFree(t->stats);
+  delete t;
   m->train = nullptr;
 }
 
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static int ensure_state(spk_model* m) {
+  if (m->train) return SPK_OK;
+  TrainState* t = new TrainState();
+  m->train = t;
+  const size_t nb = std::max<size_t>(m->n_train, 64) * sizeof(float);
+  HIP_TRY(hipMalloc((void**)&t->gbuf, nb));
+  HIP_TRY(hipMalloc((void**)&t->m1, nb));
+  HIP_TRY(hipMalloc((void**)&t->m2, nb));
+  HIP_TRY(hipMemset(t->gbuf, 0, nb));
+  HIP_TRY(hipMemset(t->m1, 0, nb));
+  HIP_TRY(hipMemset(t->m2, 0, nb));
+  t->conv.resize(m->layers.size());
+  size_t w = 0, st = 0;
+  for (size_t i = 0; i < m->layers.size(); ++i) {
+    const Layer& L = m->layers[i];
+    if (L.d.kind != SPK_OP_CONV) continue;
+    ConvTrain& c = t->conv[i];
+    c.wfwd_off = w;
+    w += (size_t)L.d.cout * L.kpad;
+    c.wdg_off = w;
+    if (L.mode != CONV_MODE_STEM) w += (size_t)L.d.cin * L.d.k * L.d.k * L.d.cout;
+    c.stat_off = st;
+    st += (size_t)4 * L.d.cout;
+  }
+  HIP_TRY(hipMalloc((void**)&t->wpack, std::max<size_t>(w, 8) * 2));
+  HIP_TRY(hipMalloc((void**)&t->stats, std::max<size_t>(st, 8) * 4));
+  return SPK_OK;
+}
+
+// activations live in the model's arena (spk_plan); everything backward needs
+// lives in the training arena
+static int plan_train(spk_model* m, int n, int h, int w) {
+  TrainState* t = m->train;
+  SPK_TRY(spk_plan(m, n, h, w));
+  if (n <= t->cap_n && h == t->cap_h && w == t->cap_w) return SPK_OK;
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (t->arena) hipFree(t->arena);
+  t->arena = nullptr;
+  size_t total = 0, max_conv = 0, max_slab = 0, max_part = 0, max_c = 0;
+  t->goff.assign(m->n_tensors, 0);
+  for (int id = 0; id < m->n_tensors; ++id) {
+    const TDim& d = m->tdims[id];
+    const size_t bytes = (size_t)n * d.h * d.w * d.c * (d.bf16 ? 2 : 4);
+    if (bytes >= ((size_t)1 << 31))
+      return tfail(SPK_ERR_UNSUPPORTED, "training batch too large: an activation exceeds 2 GiB");
+    t->goff[id] = total;
+    total += al256(bytes);
+  }
+  for (size_t i = 0; i < m->layers.size(); ++i) {
+    const Layer& L = m->layers[i];
+    const TDim& o = m->tdims[L.d.dst];
+    if (L.d.kind == SPK_OP_CONV) {
+      const size_t bytes = (size_t)n * o.h * o.w * o.c * 2;
+      t->conv[i].raw_off = total;
+      total += al256(bytes);
+      max_conv = std::max(max_conv, bytes);
+      const int M = n * o.h * o.w;
+      int sp, pps;
+      const int ktot = L.mode == CONV_MODE_STEM ? 256 : L.d.k * L.d.k * L.d.cin;
+      spk_wgrad_plan(M, L.d.cout, ktot, &sp, &pps);
+      max_slab = std::max(max_slab, (size_t)sp * L.d.cout * ktot);
+      int rpb;
+      const int nb = spk_bn_bwd_blocks(M, L.d.cout, &rpb);
+      const size_t fwd_part = (size_t)((M + 63) / 64) * 2 * L.d.cout;  // smallest M tile is 64
+      max_part = std::max(max_part, std::max((size_t)nb * 2 * L.d.cout, fwd_part));
+      max_c = std::max(max_c, (size_t)L.d.cout);
+    } else if (L.d.kind == SPK_OP_MAXPOOL) {
+      t->idx_off = total;
+      total += al256((size_t)n * o.h * o.w * o.c);
+    }
+  }
+  t->dy_off = total;      total += al256(max_conv);
+  t->part_off = total;    total += al256(max_part * 4);
+  t->coef_off = total;    total += al256(max_c * 3 * 4);
+  t->slab_off = total;    total += al256(max_slab * 4);
+  t->part_floats = max_part;
+  t->slab_floats = max_slab;
+  HIP_TRY(hipMalloc(&t->arena, total));
+  t->cap_n = n; t->cap_h = h; t->cap_w = w;
+  return SPK_OK;
+}
+
+static int repack_weights(spk_model* m) {
+  TrainState* t = m->train;
+  if (!t->weights_dirty) return SPK_OK;
+  for (size_t i = 0; i < m->layers.size(); ++i) {
+    const Layer& L = m->layers[i];
+    if (L.d.kind != SPK_OP_CONV) continue;
+    K_TRY(spk_launch_pack_weights(m->P(L.p_w), t->wpack + t->conv[i].wfwd_off, L.d.cout, L.d.k, L.d.k,
+                                  L.d.cin, L.mode, DT_BF16, 0, m->stream), "pack_weights");
+    if (L.mode != CONV_MODE_STEM)
+      K_TRY(spk_launch_pack_dgrad(m->P(L.p_w), t->wpack + t->conv[i].wdg_off, L.d.cout, L.d.k * L.d.k,
+                                  L.d.cin, m->stream), "pack_dgrad");
+  }
+  t->weights_dirty = false;
+  return SPK_OK;
+}
+
+void spk_train_mark_dirty(spk_model* m) {
+  if (m->train) m->train->weights_dirty = true;
+}
+
+static void fill_conv(ConvArgs& a, const bf16_t* x, const bf16_t* w, bf16_t* y, int N, int H, int W,
+                      int Cin, int Ho, int Wo, int Cout, int k, int stride, int pad, int K) {
+  memset(&a, 0, sizeof a);
+  a.x = x; a.w = w; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.kh = a.kw = k; a.stride = stride; a.pad = pad;
+  a.M = N * Ho * Wo;
+  a.K = K;
+  a.dt = DT_BF16;
+  a.x_bytes = (unsigned)((size_t)N * H * W * Cin * 2);
+  a.w_bytes = (unsigned)((size_t)Cout * K * 2);
+}
+
 extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, int h, int w, int layout,
-                                          int dtype, const int64_t* y, float* stats, float* logits) {
-  spk_set_error("spk_train_forward_backward: not built yet");
-  return SPK_ERR_UNSUPPORTED;
+                                          int dtype, const int64_t* y, float* stats, float* logits_out) {
+  if (!m || !x || !y || !stats || n < 2)
+    return tfail(SPK_ERR_ARG, "train step: bad arguments (batch must be >= 2 for train-mode BatchNorm)");
+  if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return tfail(SPK_ERR_ARG, "train step: dtype must be f32 or u8");
+  HIP_TRY(hipSetDevice(m->device));
+  for (const Layer& L : m->layers)
+    if (L.d.kind == SPK_OP_DROPOUT && L.d.p > 0.f)
+      return tfail(SPK_ERR_UNSUPPORTED, "Dropout(p>0) in the head is not implemented on the MI355X training path yet");
+  SPK_TRY(ensure_state(m));
+  SPK_TRY(plan_train(m, n, h, w));
+  SPK_TRY(repack_weights(m));
+  TrainState* t = m->train;
+  hipStream_t s = m->stream;
+  m->act_dt = DT_BF16;
+  float* part = (float*)((char*)t->arena + t->part_off);
+  float* coef = (float*)((char*)t->arena + t->coef_off);
+  float* slabs = (float*)((char*)t->arena + t->slab_off);
+  bf16_t* dy = (bf16_t*)((char*)t->arena + t->dy_off);
+  unsigned char* pool_idx = (unsigned char*)((char*)t->arena + t->idx_off);
+  const int nl = (int)m->layers.size();
+
+  // ------------------------------ forward ------------------------------
+  K_TRY(spk_launch_to_nhwc4(x, layout, dtype, n, m->in_chans, h, w, (bf16_t*)m->T(0), DT_BF16, s), "to_nhwc4");
+  for (int i = 0; i < nl; ++i) {
+    Layer& L = m->layers[i];
+    const TDim& in = m->tdims[L.d.src];
+    const TDim& o = m->tdims[L.d.dst];
+    switch (L.d.kind) {
+      case SPK_OP_CONV: {
+        ConvArgs a;
+        fill_conv(a, (const bf16_t*)m->T(L.d.src), t->wpack + t->conv[i].wfwd_off, t->RAW(i), n, in.h, in.w,
+                  in.c, o.h, o.w, L.d.cout, L.d.k, L.d.stride, L.d.pad, L.kpad);
+        a.stats = part;
+        int m_tiles = 0;
+        K_TRY(spk_conv_launch(a, L.mode, s, &m_tiles), "conv");
+        float* st = t->stats + t->conv[i].stat_off;
+        const int C = L.d.cout;
+        K_TRY(spk_launch_bn_finalize(part, m_tiles, C, (double)a.M, m->P(L.p_g), m->P(L.p_b),
+                                     m->P(L.p_mean), m->P(L.p_var), st, st + C, st + 2 * C, st + 3 * C,
+                                     1e-5f, 0.1f, s), "bn_finalize");
+        L.nbt += 1;
+        K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
+                                  L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
+                                  (bf16_t*)m->T(L.d.dst), (size_t)a.M * C, C, L.d.relu, s), "bn_apply");
+        break;
+      }
+      case SPK_OP_MAXPOOL:
+        K_TRY(spk_launch_maxpool_idx((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), pool_idx, n, in.h,
+                                     in.w, in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s), "maxpool");
+        break;
+      case SPK_OP_GAVGPOOL:
+        K_TRY(spk_launch_gavgpool((const bf16_t*)m->T(L.d.src), (float*)m->T(L.d.dst), n, in.h * in.w, in.c,
+                                  DT_BF16, s), "avgpool");
+        break;
+      case SPK_OP_LINEAR:
+        K_TRY(spk_launch_linear_fwd((const float*)m->T(L.d.src), m->P(L.p_w), m->P(L.p_b),
+                                    (float*)m->T(L.d.dst), n, L.d.cin, L.d.cout, s), "linear");
+        break;
+      default:
+        HIP_TRY(hipMemcpyAsync(m->T(L.d.dst), m->T(L.d.src), (size_t)n * in.c * 4, hipMemcpyDeviceToDevice, s));
+        break;
+    }
+  }
+  m->dirty = true;  // running statistics moved: the eval-BN fold is stale
+
+  // ------------------------- loss + dlogits -------------------------
+  const int last = m->layers.back().d.dst;
+  const float* logits = (const float*)m->T(last);
+  K_TRY(spk_launch_ce(logits, y, n, m->num_classes, stats, (float*)t->G(last), s), "cross-entropy");
+  if (logits_out)
+    HIP_TRY(hipMemcpyAsync(logits_out, logits, (size_t)n * m->num_classes * 4, hipMemcpyDeviceToDevice, s));
+
+  // ------------------------------ backward ------------------------------
+  std::vector<char> has_grad(m->n_tensors, 0);
+  has_grad[last] = 1;
+  for (int i = nl - 1; i >= 0; --i) {
+    Layer& L = m->layers[i];
+    const TDim& in = m->tdims[L.d.src];
+    const TDim& o = m->tdims[L.d.dst];
+    if (!has_grad[L.d.dst]) continue;
+    switch (L.d.kind) {
+      case SPK_OP_LINEAR: {
+        const float* gy = (const float*)t->G(L.d.dst);
+        const float* xin = (const float*)m->T(L.d.src);
+        const int fin = L.d.cin, fout = L.d.cout;
+        if (m->params[L.p_w].requires_grad)  // dW[o][i] = sum_n gy[n][o] * x[n][i]
+          K_TRY(spk_launch_sgemm(gy, 1, fout, xin, 1, fin, nullptr, t->gbuf + m->params[L.p_w].off, fin, 1,
+                                 fout, fin, n, 1.f, 0, s), "linear wgrad");
+        if (m->params[L.p_b].requires_grad)
+          K_TRY(spk_launch_colsum(gy, t->gbuf + m->params[L.p_b].off, n, fout, s), "bias grad");
+        // dX[n][i] = sum_o gy[n][o] * W[o][i]
+        K_TRY(spk_launch_sgemm(gy, fout, 1, m->P(L.p_w), 1, fin, nullptr, (float*)t->G(L.d.src), fin, 1, n,
+                               fin, fout, 1.f, 0, s), "linear dgrad");
+        has_grad[L.d.src] = 1;
+        break;
+      }
+      case SPK_OP_DROPOUT:
+        HIP_TRY(hipMemcpyAsync(t->G(L.d.src), t->G(L.d.dst), (size_t)n * in.c * 4, hipMemcpyDeviceToDevice, s));
+        has_grad[L.d.src] = 1;
+        break;
+      case SPK_OP_GAVGPOOL:
+        K_TRY(spk_launch_gavgpool_bwd((const float*)t->G(L.d.dst), (bf16_t*)t->G(L.d.src), n, in.h * in.w,
+                                      in.c, s), "avgpool bwd");
+        has_grad[L.d.src] = 1;
+        break;
+      case SPK_OP_MAXPOOL:
+        K_TRY(spk_launch_maxpool_bwd((const bf16_t*)t->G(L.d.dst), pool_idx, (bf16_t*)t->G(L.d.src), n, in.h,
+                                     in.w, in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s), "maxpool bwd");
+        has_grad[L.d.src] = 1;
+        break;
+      case SPK_OP_CONV: {
+        const int C = L.d.cout, M = n * o.h * o.w;
+        float* st = t->stats + t->conv[i].stat_off;
+        const Param& pg = m->params[L.p_g];
+        const Param& pb = m->params[L.p_b];
+        bf16_t* g_res = L.d.res >= 0 ? (bf16_t*)t->G(L.d.res) : nullptr;
+        K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), (const bf16_t*)m->T(L.d.dst), t->RAW(i), st,
+                                st + C, m->P(L.p_g), part, coef,
+                                pg.requires_grad ? t->gbuf + pg.off : nullptr,
+                                pb.requires_grad ? t->gbuf + pb.off : nullptr, dy, g_res,
+                                L.d.res >= 0 ? has_grad[L.d.res] : 0, M, C, L.d.relu, s), "bn bwd");
+        if (L.d.res >= 0) has_grad[L.d.res] = 1;
+        if (L.d.src != 0) {
+          // data gradient: implicit GEMM over the dgrad weight image
+          ConvArgs a;
+          fill_conv(a, dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), n, o.h, o.w, C, in.h, in.w,
+                    L.d.cin, L.d.k, L.d.stride, L.d.pad, L.d.k * L.d.k * C);
+          a.res = has_grad[L.d.src] ? (const bf16_t*)t->G(L.d.src) : nullptr;
+          K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
+          has_grad[L.d.src] = 1;
+        }
+        if (m->params[L.p_w].requires_grad) {
+          const bool stem = L.mode == CONV_MODE_STEM;
+          const int ktot = stem ? 256 : L.d.k * L.d.k * L.d.cin;
+          int sp, pps;
+          spk_wgrad_plan(M, C, ktot, &sp, &pps);
+          K_TRY(spk_wgrad_launch((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, L.d.cin, o.h, o.w, C,
+                                 L.d.k, L.d.stride, L.d.pad, stem ? 1 : 0, sp, pps, s), "conv wgrad");
+          float* gw = t->gbuf + m->params[L.p_w].off;
+          if (stem)
+            K_TRY(spk_launch_stem_wgrad_unpack(slabs, gw, C, L.d.k, L.d.k, L.d.cin, sp, s), "stem wgrad unpack");
+          else
+            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)C * ktot, sp, s), "wgrad reduce");
+        }
+        break;
+      }
+    }
+  }
+  return SPK_OK;
 }
+
 extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
-  spk_set_error("spk_optim_step: not built yet");
-  return SPK_ERR_UNSUPPORTED;
+  if (!m || !opt) return tfail(SPK_ERR_ARG, "optim_step: bad arguments");
+  if (opt->kind != SPK_OPT_SGD && opt->kind != SPK_OPT_ADAM)
+    return tfail(SPK_ERR_UNSUPPORTED, "optimizer kind not supported (SGD, Adam)");
+  if (!m->train) return tfail(SPK_ERR_STATE, "optim_step before any training step");
+  HIP_TRY(hipSetDevice(m->device));
+  TrainState* t = m->train;
+  const float gscale = opt->grad_scale == 0.f ? 1.f : opt->grad_scale;
+  OptTable tab;
+  tab.count = 0;
+  auto flush = [&]() -> int {
+    if (tab.count == 0) return 0;
+    const int r = spk_launch_opt_multi(opt->kind == SPK_OPT_ADAM, m->pbuf, t->gbuf, t->m1, t->m2, tab,
+                                       opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->momentum,
+                                       gscale, m->stream);
+    tab.count = 0;
+    return r;
+  };
+  for (Param& p : m->params) {
+    if (!p.trainable || !p.requires_grad || p.group < 0) continue;
+    p.step += 1;
+    OptEntry& e = tab.e[tab.count++];
+    e.off = p.off;
+    e.n = (unsigned)p.numel;
+    e.lr = opt->lr[p.group];
+    e.bc1 = (float)(1.0 - std::pow((double)opt->beta1, (double)p.step));
+    e.bc2s = (float)std::sqrt(1.0 - std::pow((double)opt->beta2, (double)p.step));
+    e.first = p.step == 1;
+    if (tab.count == 64) K_TRY(flush(), "optimizer");
+  }
+  K_TRY(flush(), "optimizer");
+  t->weights_dirty = true;
+  m->dirty = true;
+  return SPK_OK;
 }
+
 extern "C" int spk_model_grad_buffer(spk_model* m, void** dev_ptr, int64_t* numel) {
-  spk_set_error("spk_model_grad_buffer: not built yet");
-  return SPK_ERR_UNSUPPORTED;
+  if (!m || !dev_ptr || !numel) return tfail(SPK_ERR_ARG, "grad_buffer: bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(ensure_state(m));
+  *dev_ptr = m->train->gbuf;
+  *numel = (int64_t)m->n_train;
+  return SPK_OK;
 }
+
 extern "C" int spk_model_read_grad(spk_model* m, const char* key, void* host, int64_t numel) {
-  spk_set_error("spk_model_read_grad: not built yet");
-  return SPK_ERR_UNSUPPORTED;
+  if (!m || !key || !host) return tfail(SPK_ERR_ARG, "read_grad: bad arguments");
+  auto it = m->index.find(key);
+  if (it == m->index.end()) return tfail(SPK_ERR_KEY, std::string("unknown state_dict key: ") + key);
+  const Param& p = m->params[it->second];
+  if (!p.trainable || p.numel != numel) return tfail(SPK_ERR_ARG, std::string("no gradient / size mismatch for ") + key);
+  if (!m->train) return tfail(SPK_ERR_STATE, "read_grad before any training step");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return spk_read_flat(m, m->train->gbuf, p, (float*)host);
+}
+
+// Test hook: gradient w.r.t. activation `t` of the last training step, as
+// float32 NCHW ([n,c,h,w]; [n,c] in the head).
+extern "C" int spk_model_read_activation_grad(spk_model* m, int t, int n, float* host, int64_t numel) {
+  if (!m || !host || !m->train || !m->train->arena || t <= 0 || t >= m->n_tensors || n > m->train->cap_n)
+    return tfail(SPK_ERR_ARG, "read_activation_grad: bad arguments or no training step has run");
+  const TDim& d = m->tdims[t];
+  const size_t cnt = (size_t)n * d.h * d.w * d.c;
+  if ((int64_t)cnt != numel) return tfail(SPK_ERR_ARG, "read_activation_grad: size mismatch");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  if (!d.bf16) {
+    HIP_TRY(hipMemcpy(host, m->train->G(t), cnt * 4, hipMemcpyDeviceToHost));
+    return SPK_OK;
+  }
+  std::vector<bf16_t> tmp(cnt);
+  HIP_TRY(hipMemcpy(tmp.data(), m->train->G(t), cnt * 2, hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i)
+    for (int y = 0; y < d.h; ++y)
+      for (int x = 0; x < d.w; ++x)
+        for (int c = 0; c < d.c; ++c) {
+          const unsigned u = (unsigned)tmp[(((size_t)i * d.h + y) * d.w + x) * d.c + c] << 16;
+          float f;
+          memcpy(&f, &u, 4);
+          host[(((size_t)i * d.c + c) * d.h + y) * d.w + x] = f;
+        }
+  return SPK_OK;
 }

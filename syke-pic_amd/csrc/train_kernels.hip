@@ -1,0 +1,523 @@
+// HBM-bound kernels of the training step (gfx950), bf16 activations, fp32
+// statistics and parameters.  They stand in for the torch autograd pieces the
+// reference reaches through `net(x)` in train mode, `loss.backward()` and
+// `optimizer.step()` (sykepic/train/train.py:240-243): BatchNorm2d (batch
+// statistics, running-stat update, backward), ReLU / residual add, MaxPool2d
+// and AdaptiveAvgPool2d backward, bias gradients, Adam / SGD.
+//
+// Layout: activations NHWC, so a tensor is [M pixels][C] with C contiguous;
+// every kernel moves 16 B (8 channels) per lane.  Per-channel reductions are
+// two-stage and ordered (block partials -> fixed-order finalize), never
+// atomics, so a step is bitwise reproducible.
+#include "spk_common.h"
+
+namespace {
+
+constexpr int DT = DT_BF16;
+
+__device__ __forceinline__ void unpack8(const u32x4_t v, float* f) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = lo_f32<DT>(v[j]); f[2 * j + 1] = hi_f32<DT>(v[j]); }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  u32x4_t v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = pack2<DT>(f[2 * j], f[2 * j + 1]);
+  return v;
+}
+
+// ---- BatchNorm forward (train) ----
+// partials: [m_tiles][2][C] (sum, sum of squares) written by the conv epilogue
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int m_tiles, int C, double M,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   float* __restrict__ scale, float* __restrict__ shift, float eps,
+                                   float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < m_tiles; ++t) {
+    s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
+    s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+  }
+  const double mean = s1 / M;
+  double var = s2 / M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  mean_out[c] = (float)mean;
+  invstd_out[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  // running stats: unbiased variance, momentum 0.1 (torch BatchNorm2d defaults)
+  const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+  rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+  rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+}
+
+// a = relu?(y*scale + shift (+ res))
+__global__ void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const bf16_t* __restrict__ res,
+                                bf16_t* __restrict__ a, size_t n8, int C, int relu) {
+  const int c8 = C >> 3;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8) * 8;
+    float v[8], r[8];
+    unpack8(*(const u32x4_t*)(y + i * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * scale[cc + j] + shift[cc + j];
+    if (res) {
+      unpack8(*(const u32x4_t*)(res + i * 8), r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += r[j];
+    }
+    if (relu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
+    *(u32x4_t*)(a + i * 8) = pack8(v);
+  }
+}
+
+// ---- BatchNorm backward ----
+// stage 1: per-block partial sums over rows of dz = g*(a>0) and dz*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ g, const bf16_t* __restrict__ a, const bf16_t* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partials,
+    int M, int C, int relu, int rows_per_block) {
+  extern __shared__ float sm[];  // [rows_in_flight][2][C]
+  const int c8 = C >> 3;
+  const int tpr = c8 < 256 ? c8 : 256;       // threads per row
+  const int rif = 256 / tpr;                 // rows in flight
+  const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row1 = min(M, row0 + rows_per_block);
+  for (int cc = lane_c; cc < c8; cc += tpr) {
+    float s1[8], s2[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; mu[j] = mean[cc * 8 + j]; is[j] = invstd[cc * 8 + j]; }
+    for (int r = row0 + lane_r; r < row1; r += rif) {
+      const size_t o = (size_t)r * C + cc * 8;
+      float gv[8], yv[8], av[8];
+      unpack8(*(const u32x4_t*)(g + o), gv);
+      unpack8(*(const u32x4_t*)(y + o), yv);
+      if (relu) {
+        unpack8(*(const u32x4_t*)(a + o), av);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] = av[j] > 0.f ? gv[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s1[j] += gv[j]; s2[j] += gv[j] * (yv[j] - mu[j]) * is[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sm[(lane_r * 2 + 0) * C + cc * 8 + j] = s1[j];
+      sm[(lane_r * 2 + 1) * C + cc * 8 + j] = s2[j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rif; ++r) t += sm[r * 2 * C + i];
+    partials[(size_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+// stage 2: dgamma, dbeta (into the flat grad buffer when wanted) + the two
+// per-channel coefficients of the apply pass
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
+                                       double M, const float* __restrict__ gamma,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    s1 += (double)partials[(size_t)b * 2 * C + c];
+    s2 += (double)partials[(size_t)b * 2 * C + C + c];
+  }
+  if (dbeta) dbeta[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s2;
+  coef[c] = (float)(s1 / M);            // mean(dz)
+  coef[C + c] = (float)(s2 / M);        // mean(dz * xhat)
+  coef[2 * C + c] = gamma[c] * invstd[c];
+}
+
+// stage 3: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); the
+// shortcut branch receives dz itself (g_res = dz or += dz).
+__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ a,
+                                    const bf16_t* __restrict__ y, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ coef,
+                                    bf16_t* __restrict__ dy, bf16_t* __restrict__ g_res,
+                                    int res_accumulate, size_t n8, int C, int relu) {
+  const int c8 = C >> 3;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8) * 8;
+    float gv[8], yv[8], av[8], o[8];
+    unpack8(*(const u32x4_t*)(g + i * 8), gv);
+    unpack8(*(const u32x4_t*)(y + i * 8), yv);
+    if (relu) {
+      unpack8(*(const u32x4_t*)(a + i * 8), av);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = av[j] > 0.f ? gv[j] : 0.f;
+    }
+    if (g_res) {
+      if (res_accumulate) {
+        float rv[8];
+        unpack8(*(const u32x4_t*)(g_res + i * 8), rv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rv[j] += gv[j];
+        *(u32x4_t*)(g_res + i * 8) = pack8(rv);
+      } else {
+        *(u32x4_t*)(g_res + i * 8) = pack8(gv);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = (yv[j] - mean[cc + j]) * invstd[cc + j];
+      o[j] = coef[2 * C + cc + j] * (gv[j] - coef[cc + j] - xh * coef[C + cc + j]);
+    }
+    *(u32x4_t*)(dy + i * 8) = pack8(o);
+  }
+}
+
+// ---- MaxPool2d(3,2,1) with saved arg-max, and its backward ----
+__global__ void maxpool_idx_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                   unsigned char* __restrict__ idx, int n, int h, int w, int c, int k,
+                                   int stride, int pad, int ho, int wo) {
+  const int c8 = c >> 3;
+  const size_t total = (size_t)n * ho * wo * c8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    size_t p = i / c8;
+    const int ox = (int)(p % wo);
+    p /= wo;
+    const int oy = (int)(p % ho);
+    const int img = (int)(p / ho);
+    float best[8];
+    unsigned char bi[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+    for (int r = 0; r < k; ++r) {
+      const int iy = oy * stride - pad + r;
+      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int s = 0; s < k; ++s) {
+        const int ix = ox * stride - pad + s;
+        if ((unsigned)ix >= (unsigned)w) continue;
+        float v[8];
+        unpack8(*(const u32x4_t*)(x + (((size_t)img * h + iy) * w + ix) * c + cc * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (v[j] > best[j]) { best[j] = v[j]; bi[j] = (unsigned char)(r * k + s); }  // first max wins
+      }
+    }
+    *(u32x4_t*)(y + i * 8) = pack8(best);
+    u32x2_t pk;
+    pk[0] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | ((unsigned)bi[3] << 24);
+    pk[1] = bi[4] | (bi[5] << 8) | (bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *(u32x2_t*)(idx + i * 8) = pk;
+  }
+}
+
+// gather form: every input pixel sums the gradients of the windows whose
+// saved arg-max points at it (deterministic, no atomics)
+__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ gy, const unsigned char* __restrict__ idx,
+                                   bf16_t* __restrict__ gx, int n, int h, int w, int c, int k,
+                                   int stride, int pad, int ho, int wo) {
+  const int c8 = c >> 3;
+  const size_t total = (size_t)n * h * w * c8;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    size_t p = i / c8;
+    const int ix = (int)(p % w);
+    p /= w;
+    const int iy = (int)(p % h);
+    const int img = (int)(p / h);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < k; ++r) {
+      const int ty = iy + pad - r;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= ho) continue;
+      for (int s = 0; s < k; ++s) {
+        const int tx = ix + pad - s;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= wo) continue;
+        const size_t o = ((((size_t)img * ho + oy) * wo + ox) * c8 + cc) * 8;
+        const u32x2_t pk = *(const u32x2_t*)(idx + o);
+        float gv[8];
+        unpack8(*(const u32x4_t*)(gy + o), gv);
+        const unsigned want = (unsigned)(r * k + s);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned b = (pk[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+          acc[j] += (b == want) ? gv[j] : 0.f;
+        }
+      }
+    }
+    *(u32x4_t*)(gx + i * 8) = pack8(acc);
+  }
+}
+
+// AdaptiveAvgPool2d(1) backward: gx[n,hw,c] = gy[n,c] / hw
+__global__ void gavgpool_bwd_kernel(const float* __restrict__ gy, bf16_t* __restrict__ gx, int n,
+                                    int hw, int c) {
+  const int c8 = c >> 3;
+  const size_t total = (size_t)n * hw * c8;
+  const float inv = 1.0f / (float)hw;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % c8);
+    const int img = (int)(i / ((size_t)hw * c8));
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gy[(size_t)img * c + cc * 8 + j] * inv;
+    *(u32x4_t*)(gx + i * 8) = pack8(v);
+  }
+}
+
+// bias gradient: db[j] = sum_i dy[i][j]   (one thread per column, ordered)
+__global__ void colsum_kernel(const float* __restrict__ dy, float* __restrict__ db, int n, int c) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= c) return;
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += dy[(size_t)i * c + j];
+  db[j] = s;
+}
+
+// split-K wgrad slabs -> gradient, fixed order
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n,
+                                   int splits) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
+    out[i] = s;
+  }
+}
+
+// stem wgrad image [Cout][8 rows][8 taps][4 ch] (x splits) -> [Cout][7][7][3]
+__global__ void stem_wgrad_unpack_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                         int cout, int kh, int kw, int cin, int splits) {
+  const int total = cout * kh * kw * cin;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = i % cin, s = (i / cin) % kw, r = (i / (cin * kw)) % kh, co = i / (cin * kw * kh);
+  const size_t src = (size_t)co * 256 + r * 32 + (s + 1) * 4 + ci;
+  float t = 0.f;
+  for (int k = 0; k < splits; ++k) t += slabs[(size_t)k * cout * 256 + src];
+  out[i] = t;
+}
+
+// master fp32 [Cout][kh][kw][Cin] -> bf16 dgrad image [Cin][kh][kw][Cout]
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout,
+                                  int taps, int cin) {
+  const size_t n = (size_t)cout * taps * cin;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % cout);
+    const int t = (int)((i / cout) % taps);
+    const int ci = (int)(i / ((size_t)cout * taps));
+    out[i] = to_h16<DT>(w[((size_t)co * taps + t) * cin + ci]);
+  }
+}
+
+// ---- optimizers over one tensor of the flat buffers ----
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                           size_t n, float lr, float wd, float momentum, float gscale, int first) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    float d = g[i] * gscale + wd * p[i];
+    if (momentum != 0.f) {
+      const float b = first ? d : momentum * mom[i] + d;
+      mom[i] = b;
+      d = b;
+    }
+    p[i] -= lr * d;
+  }
+}
+
+// torch.optim.Adam (amsgrad=False, maximize=False): bias corrections from the
+// per-tensor step count
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps,
+                            float wd, float gscale, float bc1, float bc2_sqrt) {
+  const float step_size = lr / bc1;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale + wd * p[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+// multi-tensor forms: blockIdx.y selects a tensor of the flat buffers
+__global__ void sgd_multi_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                 float* __restrict__ mom, OptTable t, float wd, float momentum,
+                                 float gscale) {
+  const OptEntry e = t.e[blockIdx.y];
+  float* pp = p + e.off;
+  const float* gg = g + e.off;
+  float* mm = mom ? mom + e.off : nullptr;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < e.n; i += gridDim.x * blockDim.x) {
+    float d = gg[i] * gscale + wd * pp[i];
+    if (momentum != 0.f) {
+      const float b = e.first ? d : momentum * mm[i] + d;
+      mm[i] = b;
+      d = b;
+    }
+    pp[i] -= e.lr * d;
+  }
+}
+
+__global__ void adam_multi_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                  float* __restrict__ m, float* __restrict__ v, OptTable t, float b1,
+                                  float b2, float eps, float wd, float gscale) {
+  const OptEntry e = t.e[blockIdx.y];
+  float* pp = p + e.off;
+  const float* gg = g + e.off;
+  float* mm = m + e.off;
+  float* vv = v + e.off;
+  const float step_size = e.lr / e.bc1;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < e.n; i += gridDim.x * blockDim.x) {
+    const float gi = gg[i] * gscale + wd * pp[i];
+    const float mi = b1 * mm[i] + (1.f - b1) * gi;
+    const float vi = b2 * vv[i] + (1.f - b2) * gi * gi;
+    mm[i] = mi;
+    vv[i] = vi;
+    pp[i] -= step_size * mi / (sqrtf(vi) / e.bc2s + eps);
+  }
+}
+
+inline int grid_for(size_t total, int block) {
+  size_t g = (total + block - 1) / block;
+  if (g > 256 * 8 * 4) g = 256 * 8 * 4;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -1)
+
+int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, const float* gamma,
+                           const float* beta, float* rmean, float* rvar, float* mean, float* invstd,
+                           float* scale, float* shift, float eps, float momentum, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partials, m_tiles, C, M,
+                     gamma, beta, rmean, rvar, mean, invstd, scale, shift, eps, momentum);
+  return LAUNCH_OK();
+}
+
+int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift, const bf16_t* res,
+                        bf16_t* a, size_t numel, int C, int relu, hipStream_t s) {
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(numel / 8, 256)), dim3(256), 0, s, y, scale, shift,
+                     res, a, numel / 8, C, relu);
+  return LAUNCH_OK();
+}
+
+int spk_bn_bwd_blocks(int M, int C, int* rows_per_block) {
+  int rpb = 1024;
+  while (rpb > 64 && (M + rpb - 1) / rpb < 1024) rpb >>= 1;
+  *rows_per_block = rpb;
+  return (M + rpb - 1) / rpb;
+}
+
+int spk_launch_bn_bwd(const bf16_t* g, const bf16_t* a, const bf16_t* y, const float* mean,
+                      const float* invstd, const float* gamma, float* partials, float* coef,
+                      float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
+                      int C, int relu, hipStream_t s) {
+  int rpb;
+  const int nb = spk_bn_bwd_blocks(M, C, &rpb);
+  const int c8 = C / 8;
+  const int tpr = c8 < 256 ? c8 : 256;
+  const size_t lds = (size_t)(256 / tpr) * 2 * C * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), lds, s, g, a, y, mean, invstd, partials,
+                     M, C, relu, rpb);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partials, nb, C,
+                     (double)M, gamma, invstd, dgamma, dbeta, coef);
+  const size_t n8 = (size_t)M * C / 8;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, s, g, a, y, mean,
+                     invstd, coef, dy, g_res, res_accumulate, n8, C, relu);
+  return LAUNCH_OK();
+}
+
+int spk_launch_maxpool_idx(const bf16_t* x, bf16_t* y, unsigned char* idx, int n, int h, int w, int c,
+                           int k, int stride, int pad, int ho, int wo, hipStream_t s) {
+  const size_t total = (size_t)n * ho * wo * (c / 8);
+  hipLaunchKernelGGL(maxpool_idx_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, x, y, idx, n, h, w,
+                     c, k, stride, pad, ho, wo);
+  return LAUNCH_OK();
+}
+
+int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* gx, int n, int h, int w,
+                           int c, int k, int stride, int pad, int ho, int wo, hipStream_t s) {
+  const size_t total = (size_t)n * h * w * (c / 8);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, gy, idx, gx, n, h,
+                     w, c, k, stride, pad, ho, wo);
+  return LAUNCH_OK();
+}
+
+int spk_launch_gavgpool_bwd(const float* gy, bf16_t* gx, int n, int hw, int c, hipStream_t s) {
+  const size_t total = (size_t)n * hw * (c / 8);
+  hipLaunchKernelGGL(gavgpool_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, gy, gx, n, hw, c);
+  return LAUNCH_OK();
+}
+
+int spk_launch_colsum(const float* dy, float* db, int n, int c, hipStream_t s) {
+  hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64), dim3(64), 0, s, dy, db, n, c);
+  return LAUNCH_OK();
+}
+
+int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, slabs, out, n, splits);
+  return LAUNCH_OK();
+}
+
+int spk_launch_stem_wgrad_unpack(const float* slabs, float* out, int cout, int kh, int kw, int cin,
+                                 int splits, hipStream_t s) {
+  const int total = cout * kh * kw * cin;
+  hipLaunchKernelGGL(stem_wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slabs, out,
+                     cout, kh, kw, cin, splits);
+  return LAUNCH_OK();
+}
+
+int spk_launch_pack_dgrad(const float* w, bf16_t* out, int cout, int taps, int cin, hipStream_t s) {
+  const size_t n = (size_t)cout * taps * cin;
+  hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, out, cout, taps, cin);
+  return LAUNCH_OK();
+}
+
+int spk_launch_opt_multi(int adam, float* p, const float* g, float* m, float* v, const OptTable& t,
+                         float b1, float b2, float eps, float wd, float momentum, float gscale,
+                         hipStream_t s) {
+  if (t.count <= 0) return 0;
+  dim3 grid(96, t.count);
+  if (adam)
+    hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, s, p, g, m, v, t, b1, b2, eps, wd, gscale);
+  else
+    hipLaunchKernelGGL(sgd_multi_kernel, grid, dim3(256), 0, s, p, g, m, t, wd, momentum, gscale);
+  return LAUNCH_OK();
+}
+
+int spk_launch_sgd(float* p, const float* g, float* mom, size_t n, float lr, float wd, float momentum,
+                   float gscale, int first, hipStream_t s) {
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, mom, n, lr, wd, momentum,
+                     gscale, first);
+  return LAUNCH_OK();
+}
+
+int spk_launch_adam(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2,
+                    float eps, float wd, float gscale, float bc1, float bc2_sqrt, hipStream_t s) {
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
+                     wd, gscale, bc1, bc2_sqrt);
+  return LAUNCH_OK();
+}

@@ -66,6 +66,7 @@ SYMBOLS = {
     "spk_model_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
     "spk_model_read_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "spk_model_read_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
+    "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_model_profile_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(LayerTime), C.c_int]),
 }

@@ -417,6 +417,12 @@ class HipNet:
                                                       C.c_void_p(buf.ctypes.data), int(buf.size)))
         return torch.from_numpy(buf)
 
+    def read_activation_grad(self, tensor_id, n, shape):
+        buf = np.empty(shape, dtype=np.float32)
+        lib.check(self._lib.spk_model_read_activation_grad(self._h, int(tensor_id), int(n),
+                                                           C.c_void_p(buf.ctypes.data), int(buf.size)))
+        return torch.from_numpy(buf)
+
     def profile_layers(self, x, iters=5):
         x, n, h, w, layout, dtype = self._prep(x)
         cap = len(self.graph.ops) + 4
