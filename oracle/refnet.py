@@ -146,7 +146,7 @@ def train_step(net, opt, x, y):
     loss.backward()
     opt.step()
     correct = int((out.argmax(1) == y).sum())
-    return float(loss), correct, out.detach()
+    return float(loss.detach()), correct, out.detach()
 
 
 def eval_step(net, x, y):

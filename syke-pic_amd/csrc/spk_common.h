@@ -132,14 +132,15 @@ struct OptTable {
 
 int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, const float* gamma,
                            const float* beta, float* rmean, float* rvar, float* mean, float* invstd,
-                           float* scale, float* shift, float eps, float momentum, hipStream_t s);
+                           float* scale, float* shift, float eps, float momentum, float* tmp,
+                           hipStream_t s);
 int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift, const bf16_t* res,
                         bf16_t* a, size_t numel, int C, int relu, hipStream_t s);
 int spk_bn_bwd_blocks(int M, int C, int* rows_per_block);
 int spk_launch_bn_bwd(const bf16_t* g, const bf16_t* a, const bf16_t* y, const float* mean,
                       const float* invstd, const float* gamma, float* partials, float* coef,
                       float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
-                      int C, int relu, hipStream_t s);
+                      int C, int relu, float* tmp, hipStream_t s);
 int spk_launch_maxpool_idx(const bf16_t* x, bf16_t* y, unsigned char* idx, int n, int h, int w, int c,
                            int k, int stride, int pad, int ho, int wo, hipStream_t s);
 int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* gx, int n, int h, int w,

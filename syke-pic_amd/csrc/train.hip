@@ -53,7 +53,7 @@ struct TrainState {
   void* arena = nullptr;
   int cap_n = 0, cap_h = 0, cap_w = 0;
   std::vector<size_t> goff;   // gradient tensor per activation id
-  size_t dy_off = 0, idx_off = 0, part_off = 0, coef_off = 0, slab_off = 0;
+  size_t dy_off = 0, idx_off = 0, part_off = 0, coef_off = 0, slab_off = 0, tmp_off = 0;
   size_t part_floats = 0, slab_floats = 0;
 
   void* G(int t) const { return (char*)arena + goff[t]; }
@@ -149,6 +149,7 @@ static int plan_train(spk_model* m, int n, int h, int w) {
   t->dy_off = total;      total += al256(max_conv);
   t->part_off = total;    total += al256(max_part * 4);
   t->coef_off = total;    total += al256(max_c * 3 * 4);
+  t->tmp_off = total;     total += al256(max_c * 2 * 64 * 4);
   t->slab_off = total;    total += al256(max_slab * 4);
   t->part_floats = max_part;
   t->slab_floats = max_slab;
@@ -207,6 +208,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   m->act_dt = DT_BF16;
   float* part = (float*)((char*)t->arena + t->part_off);
   float* coef = (float*)((char*)t->arena + t->coef_off);
+  float* tmp = (float*)((char*)t->arena + t->tmp_off);
   float* slabs = (float*)((char*)t->arena + t->slab_off);
   bf16_t* dy = (bf16_t*)((char*)t->arena + t->dy_off);
   unsigned char* pool_idx = (unsigned char*)((char*)t->arena + t->idx_off);
@@ -230,7 +232,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         const int C = L.d.cout;
         K_TRY(spk_launch_bn_finalize(part, m_tiles, C, (double)a.M, m->P(L.p_g), m->P(L.p_b),
                                      m->P(L.p_mean), m->P(L.p_var), st, st + C, st + 2 * C, st + 3 * C,
-                                     1e-5f, 0.1f, s), "bn_finalize");
+                                     1e-5f, 0.1f, tmp, s), "bn_finalize");
         L.nbt += 1;
         K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
                                   L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
@@ -311,7 +313,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                 st + C, m->P(L.p_g), part, coef,
                                 pg.requires_grad ? t->gbuf + pg.off : nullptr,
                                 pb.requires_grad ? t->gbuf + pb.off : nullptr, dy, g_res,
-                                L.d.res >= 0 ? has_grad[L.d.res] : 0, M, C, L.d.relu, s), "bn bwd");
+                                L.d.res >= 0 ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
         if (L.d.res >= 0) has_grad[L.d.res] = 1;
         if (L.d.src != 0) {
           // data gradient: implicit GEMM over the dgrad weight image

@@ -26,21 +26,56 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return v;
 }
 
+// Ordered parallel sum of `count` partial rows for 64 channels at a time:
+// block = 64 channels x 16 row groups; thread (c, r) adds rows r, r+16, ...
+// (coalesced 256-B rows), then the 16 group sums are added in index order.
+// Deterministic for a given `count`.  which: 0 / 1 selects [row][which][C].
+__device__ __forceinline__ double colsum64(const float* __restrict__ partials, int count, int C,
+                                           int which, int c, int r, bool valid, double* sm) {
+  double acc = 0.0;
+  if (valid)
+    for (int t = r; t < count; t += 16) acc += (double)partials[((size_t)t * 2 + which) * C + c];
+  sm[r * 64 + (threadIdx.x & 63)] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  if (r == 0)
+    for (int k = 0; k < 16; ++k) tot += sm[k * 64 + (threadIdx.x & 63)];
+  __syncthreads();
+  return tot;
+}
+
+// Stage 1 of the two-stage ordered reduction: blockIdx.y takes a contiguous
+// slice of the `count` partial rows and writes one row of out[slices][2][C].
+__global__ __launch_bounds__(1024) void partial_rows_kernel(const float* __restrict__ partials,
+                                                            int count, int C, int rows_per_slice,
+                                                            float* __restrict__ out) {
+  __shared__ double sm[16 * 64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const bool valid = c < C;
+  const int t0 = blockIdx.y * rows_per_slice;
+  const int cnt = max(0, min(count - t0, rows_per_slice));
+  const float* base = partials + (size_t)t0 * 2 * C;
+  const double s1 = colsum64(base, cnt, C, 0, c, r, valid, sm);
+  const double s2 = colsum64(base, cnt, C, 1, c, r, valid, sm);
+  if (r == 0 && valid) {
+    out[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)s1;
+    out[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)s2;
+  }
+}
+
 // ---- BatchNorm forward (train) ----
 // partials: [m_tiles][2][C] (sum, sum of squares) written by the conv epilogue
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int m_tiles, int C, double M,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                   float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   float* __restrict__ scale, float* __restrict__ shift, float eps,
-                                   float momentum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int t = 0; t < m_tiles; ++t) {
-    s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
-    s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
-  }
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(
+    const float* __restrict__ partials, int m_tiles, int C, double M, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+    float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale,
+    float* __restrict__ shift, float eps, float momentum) {
+  __shared__ double sm[16 * 64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const bool valid = c < C;
+  const double s1 = colsum64(partials, m_tiles, C, 0, c, r, valid, sm);
+  const double s2 = colsum64(partials, m_tiles, C, 1, c, r, valid, sm);
+  if (r != 0 || !valid) return;
   const double mean = s1 / M;
   double var = s2 / M - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -127,17 +162,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 
 // stage 2: dgamma, dbeta (into the flat grad buffer when wanted) + the two
 // per-channel coefficients of the apply pass
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblocks, int C,
-                                       double M, const float* __restrict__ gamma,
-                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s1 += (double)partials[(size_t)b * 2 * C + c];
-    s2 += (double)partials[(size_t)b * 2 * C + C + c];
-  }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partials, int nblocks, int C, double M, const float* __restrict__ gamma,
+    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ coef) {
+  __shared__ double sm[16 * 64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const bool valid = c < C;
+  const double s1 = colsum64(partials, nblocks, C, 0, c, r, valid, sm);
+  const double s2 = colsum64(partials, nblocks, C, 1, c, r, valid, sm);
+  if (r != 0 || !valid) return;
   if (dbeta) dbeta[c] = (float)s1;
   if (dgamma) dgamma[c] = (float)s2;
   coef[c] = (float)(s1 / M);            // mean(dz)
@@ -409,10 +443,23 @@ inline int grid_for(size_t total, int block) {
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -1)
 
+// collapses `count` partial rows to <= 64 rows in `tmp` when that pays
+static const float* presum(const float* partials, int* count, int C, float* tmp, hipStream_t s) {
+  if (*count <= 128 || !tmp) return partials;
+  const int slices = 64;
+  const int rps = (*count + slices - 1) / slices;
+  hipLaunchKernelGGL(partial_rows_kernel, dim3((C + 63) / 64, slices), dim3(1024), 0, s, partials, *count, C,
+                     rps, tmp);
+  *count = slices;
+  return tmp;
+}
+
 int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, const float* gamma,
                            const float* beta, float* rmean, float* rvar, float* mean, float* invstd,
-                           float* scale, float* shift, float eps, float momentum, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partials, m_tiles, C, M,
+                           float* scale, float* shift, float eps, float momentum, float* tmp,
+                           hipStream_t s) {
+  partials = presum(partials, &m_tiles, C, tmp, s);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, m_tiles, C, M,
                      gamma, beta, rmean, rvar, mean, invstd, scale, shift, eps, momentum);
   return LAUNCH_OK();
 }
@@ -434,15 +481,16 @@ int spk_bn_bwd_blocks(int M, int C, int* rows_per_block) {
 int spk_launch_bn_bwd(const bf16_t* g, const bf16_t* a, const bf16_t* y, const float* mean,
                       const float* invstd, const float* gamma, float* partials, float* coef,
                       float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
-                      int C, int relu, hipStream_t s) {
+                      int C, int relu, float* tmp, hipStream_t s) {
   int rpb;
-  const int nb = spk_bn_bwd_blocks(M, C, &rpb);
+  int nb = spk_bn_bwd_blocks(M, C, &rpb);
   const int c8 = C / 8;
   const int tpr = c8 < 256 ? c8 : 256;
   const size_t lds = (size_t)(256 / tpr) * 2 * C * sizeof(float);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), lds, s, g, a, y, mean, invstd, partials,
                      M, C, relu, rpb);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, partials, nb, C,
+  const float* fin = presum(partials, &nb, C, tmp, s);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, fin, nb, C,
                      (double)M, gamma, invstd, dgamma, dbeta, coef);
   const size_t n8 = (size_t)M * C / 8;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, s, g, a, y, mean,

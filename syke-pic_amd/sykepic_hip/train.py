@@ -1,0 +1,274 @@
+"""`sykepic train`: the training workflow on MI355X.
+
+Host-side mirror of the reference's ``sykepic/train/train.py`` (``main`` :17,
+``train_net`` :201, ``test_net`` :323): same ``train.ini`` keys, same model
+directory artefacts (``config.ini``, ``class_names.txt``,
+``class_distribution.csv``, ``best_state.pth``, ``test_report*.txt``), same
+``[STAT]``/``[INFO]`` lines, same checkpoint-on-val-accuracy and
+early-stop-on-val-loss rules (quirk Q4), same swallowed exceptions (Q5).
+The five-line hot loop (zero_grad/forward/loss/backward/step, :239-243)
+becomes ``net.forward_backward(x, y)`` + ``optimizer.step()``: fused kernels
+in libsykepic_hip.so; loss and accuracy accumulate on the GPU and are read
+once per epoch instead of twice per step.
+
+Data parallelism: launched under ``torch.distributed.run`` (one process per
+GPU) every rank trains on its shard, gradients are all-reduced over RCCL and
+rank 0 alone prints, checkpoints and writes reports.
+"""
+
+import os
+import shutil
+from configparser import ConfigParser
+from pathlib import Path
+
+import torch
+
+from . import data, schedule
+from .config import get_img_shape, get_network, get_transforms
+from .dp import GradSync
+from .optim import HipOptimizer
+
+
+def _dist():
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, 1, 0
+    import torch.distributed as dist
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    return dist, rank, world, local
+
+
+def main(args):
+    config = ConfigParser()
+    config.read(args.config)
+    dist, rank, world, local = _dist()
+    chief = rank == 0
+
+    # [dataset]
+    dataset = Path(config.get("dataset", "path"))
+    split = tuple(float(i) for i in config.get("dataset", "split").split(","))
+    if (s := sum(split)) != 1.0:
+        raise ValueError(f"Dataset split does not add up to 1.0. Got {s}")
+    if len(split) < 2:
+        raise ValueError("Dataset split needs to cover at least train and validation")
+    test_split = len(split) == 3
+    min_N = config.get("dataset", "min_N")
+    min_N = int(min_N) if min_N else None
+    max_N = config.get("dataset", "max_N")
+    max_N = int(max_N) if max_N else None
+    exclude = [name.strip() for name in config.get("dataset", "exclude").split(",")]
+    random_seed = config.getint("dataset", "random_seed")
+    model_data = data.ModelData(dataset, split, min_N, max_N, exclude, random_seed)
+
+    if getattr(args, "save_images", None):
+        root = Path(args.save_images)
+        for name, paths in (("train", model_data.train_x), ("val", model_data.val_x),
+                            ("test", model_data.test_x if test_split else [])):
+            if paths:
+                (root / name).mkdir(exist_ok=True, parents=True)
+                for p in paths:
+                    shutil.copy(p, root / name / p.name)
+    if getattr(args, "dist", None):
+        from . import plots
+        out_file = Path(args.dist)
+        out_file = out_file if out_file.suffix else out_file.with_suffix(".png")
+        plots.dataset_distribution(model_data, out_file)
+        print(f"[INFO] Distribution plot saved to {out_file}")
+        return
+
+    if oversample_until := config.get("dataset", "oversample_until", fallback=""):
+        model_data.oversample(int(oversample_until), None)
+    elif oversample_with_decay := config.get("dataset", "oversample_with_decay", fallback=""):
+        model_data.oversample(None, float(oversample_with_decay))
+
+    # [image]
+    img_shape = get_img_shape(config)
+    batch_size = config.getint("image", "batch_size")
+    num_workers = config.getint("image", "num_workers")
+    train_transform, eval_transform = get_transforms(config, img_shape)
+    if getattr(args, "collage", None):
+        from . import plots
+        height, width, out_file = int(args.collage[0]), int(args.collage[1]), Path(args.collage[2])
+        model_data.set_data_loaders(height * width, num_workers, train_transform, eval_transform, img_shape[0])
+        out_file = out_file if out_file.suffix else out_file.with_suffix(".png")
+        plots.view_batch(model_data.train_loader, height, width, out_file)
+        print(f"[INFO] Image collage saved to {out_file}")
+        return
+    model_data.set_data_loaders(batch_size, num_workers, train_transform, eval_transform, img_shape[0],
+                                rank=rank, world=world)
+    num_classes = len(model_data.le.classes_)
+    external_test = config.get("dataset", "external_test", fallback="")
+    if external_test:
+        extra_loader = data.extra_eval_dataloader(external_test, model_data, exclude=["Unclassified"])
+
+    # [model]
+    model_network = config.get("model", "network")
+    model_id = config.get("model", "id")
+    model_dir = Path(config.get("model", "path"))
+    if model_id == "auto":
+        model_id = data.auto_id(model_network, model_dir)
+    model_name = model_network + (f"_{model_id}" if model_id else "")
+    model_dir = model_dir / model_name
+    if chief:
+        model_dir.mkdir(parents=True, exist_ok=config.getboolean("model", "exist_ok"))
+        model_data.save(model_dir)
+        shutil.copy(args.config, model_dir / "config.ini")
+    if dist is not None:
+        dist.barrier()
+
+    # [train]
+    if not config.getboolean("train", "gpu"):
+        raise RuntimeError("this build trains on the MI355X only; for `gpu = no` use the reference itself")
+    device = torch.device("cuda", local)
+    max_epochs = config.getint("train", "max_epochs")
+    early_stop_patience = config.getint("train", "early_stop_patience")
+    lr = config.getfloat("train", "learning_rate")
+    optimizer_name = config.get("train", "optimizer")
+
+    net = get_network(config, num_classes, device=device)
+    schedule.freeze(net.base)
+    initial = [p for p in net.parameters() if p.requires_grad]
+    optimizer = HipOptimizer(net, optimizer_name, [{"params": initial, "lr": lr},
+                                                   {"params": [], "lr": 0.0}, {"params": [], "lr": 0.0}])
+    if chief:
+        print("---- Network Head ----")
+        print(net.head)
+
+    lr_warmup = None
+    if config.getboolean("lr_warmup", "use"):
+        lr_warmup = schedule.LRWarmup(
+            net, optimizer, config.getfloat("lr_warmup", "factor_1"), config.getfloat("lr_warmup", "factor_2"),
+            config.getint("lr_warmup", "step_1"), config.getint("lr_warmup", "step_2"),
+            config.getint("lr_warmup", "step_3"), config.getboolean("lr_warmup", "verbose") and chief)
+    lr_scheduler = None
+    if config.getboolean("lr_reduction", "use"):
+        # quirk Q3: the reference passes `verbose` positionally into `threshold`
+        lr_scheduler = schedule.ReduceLROnPlateau(
+            optimizer, "min", config.getfloat("lr_reduction", "factor"), config.getint("lr_reduction", "patience"),
+            config.getboolean("lr_reduction", "verbose"))
+
+    best_state = train_net(net, model_data.train_loader, model_data.val_loader, optimizer, None, max_epochs,
+                           early_stop_patience, model_dir, device, lr_scheduler, lr_warmup, dist=dist)
+    if dist is not None:
+        dist.barrier()
+    net.load_state_dict(torch.load(best_state, map_location="cpu"))
+    if chief and test_split:
+        report = test_net(net, model_data.test_loader, model_data.le.classes_, device)
+        print(report)
+        (model_dir / "test_report.txt").write_text(report)
+    if chief and external_test:
+        name = Path(external_test).name
+        report = test_net(net, extra_loader, model_data.le.classes_, device, test_name=name)
+        print(report)
+        (model_dir / f"test_report_{name}.txt").write_text(report)
+
+
+def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epochs, early_stop_patience,
+              model_dir, device, lr_scheduler=None, lr_warmup=None, dist=None):
+    """loss_fn is accepted for signature compatibility; CrossEntropyLoss is
+    fused into the training step (the only loss the reference constructs)."""
+    net = net.to(device)
+    chief = dist is None or dist.get_rank() == 0
+    sync = GradSync(net, dist)
+    max_val_acc, min_val_loss, no_improvement = 0, 0, 0
+    train_accs, train_losses, val_accs, val_losses = [], [], [], []
+    best_state = Path(model_dir) / "best_state.pth"
+    try:
+        from tqdm import tqdm
+    except ImportError:  # pragma: no cover
+        def tqdm(x, **kw):
+            return x
+    try:
+        for epoch in range(1, max_epochs + 1):
+            if chief:
+                print(f"\n----- Epoch {epoch} -----")
+            if lr_warmup:
+                lr_warmup(epoch)
+            net.train()
+            net.reset_stats()
+            seen = 0
+            for batch in (tqdm(train_dataloader) if chief else train_dataloader):
+                x, y = batch[0], batch[1]
+                optimizer.zero_grad()
+                net.forward_backward(x, y)
+                sync.all_reduce(optimizer)
+                optimizer.step()
+                seen += len(y)
+            loss_sum, correct = net.read_stats()          # one device sync per epoch
+            loss_sum, correct, seen = sync.reduce_stats(loss_sum, correct, seen)
+            train_acc, train_loss = correct / seen, loss_sum / seen
+            train_accs.append(train_acc)
+            train_losses.append(train_loss)
+            if chief:
+                print(f"[STAT] Train Acc: {train_acc:.3f}, Train Loss: {train_loss:.3f}")
+
+            net.eval()
+            net.reset_stats()
+            seen = 0
+            for batch in val_dataloader:
+                net.eval_step(batch[0], batch[1])
+                seen += len(batch[1])
+            loss_sum, correct = net.read_stats()
+            val_acc, val_loss = correct / seen, loss_sum / seen
+            val_accs.append(val_acc)
+            val_losses.append(val_loss)
+            if chief:
+                print(f"[STAT] Val Acc: {val_acc:.3f}, Val Loss: {val_loss:.3f}")
+                _plot(train_accs, train_losses, val_accs, val_losses, Path(model_dir), epoch)
+            if val_acc > max_val_acc:
+                max_val_acc = val_acc
+                if chief:
+                    print("[INFO] Increased accuracy, saving model state")
+                    torch.save(net.state_dict(), best_state)
+            if val_loss < min_val_loss or epoch == 1:
+                no_improvement = 0
+                min_val_loss = val_loss
+            else:
+                no_improvement += 1
+                if chief:
+                    print(f"[INFO] No reduction in loss for {no_improvement} epochs")
+            if no_improvement >= early_stop_patience:
+                if chief:
+                    print("[INFO] Stopping early")
+                break
+            if lr_scheduler and (not lr_warmup or epoch > lr_warmup.step_3):
+                lr_scheduler.step(val_loss)
+    except KeyboardInterrupt:
+        print("[INFO] Stopping early")
+    except Exception as e:  # the reference swallows every error here (quirk Q5)
+        print(f"[ERROR] {e}")
+    return best_state
+
+
+def _plot(train_accs, train_losses, val_accs, val_losses, model_dir, epoch):
+    try:
+        from . import plots
+        plots.plot_stats(train_accs, train_losses, val_accs, val_losses, outfile=model_dir / "train_stats.png",
+                         first_epoch=1, epoch_step=3)
+        if epoch >= 11:
+            plots.plot_stats(train_accs[10:], train_losses[10:], val_accs[10:], val_losses[10:],
+                             outfile=model_dir / "train_stats_zoomed.png", first_epoch=11, epoch_step=2)
+    except Exception:  # plotting is cosmetic (out of scope)
+        pass
+
+
+def test_net(net, dataloader, classes, device, test_name=None):
+    net = net.to(device)
+    net.eval()
+    print(f"\n----- Model Evaluation ({test_name}) -----" if test_name else "\n----- Model Evaluation -----")
+    true_labels, predicted = [], []
+    pending = []
+    for batch in dataloader:
+        x, y = batch[0], batch[1]
+        pending.append((net(x).argmax(1), y))
+    for preds, y in pending:
+        predicted.extend(preds.tolist())
+        true_labels.extend(torch.as_tensor(y).tolist())
+    acc = sum(int(a == b) for a, b in zip(true_labels, predicted)) / max(1, len(true_labels))
+    print(f"[STAT] Test Accuracy: {acc:.3f}\n")
+    from sklearn.metrics import classification_report
+    return classification_report(true_labels, predicted, target_names=list(classes), zero_division=0)

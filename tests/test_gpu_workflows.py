@@ -1,0 +1,175 @@
+"""End-to-end workflows through the drop-in entry points on the GPU:
+`sykepic prob` on the reference's own raw fixture (counterpart of the
+reference's tests/test_probability.py:10-37, plus numerical parity with the
+oracle) and `sykepic train` on a tiny synthetic dataset."""
+
+import shutil
+from collections import namedtuple
+from configparser import ConfigParser
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from sykepic_hip import arch, synth
+
+pytestmark = pytest.mark.gpu
+
+Args = namedtuple("Args", "raw samples image_dir images model out batch_size num_workers force")
+
+
+def _model_dir(tmp_path, golden_dir):
+    d = tmp_path / "model"
+    d.mkdir()
+    shutil.copy(golden_dir / "ref_data" / "class_names.txt", d / "class_names.txt")
+    shutil.copy(golden_dir / "ref_data" / "config.ini", d / "config.ini")   # legacy file: no `weights` key (Q7)
+    g = arch.build_graph("resnet18", 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, d / "best_state.pth")
+    return d, sd
+
+
+def test_prob_call_on_reference_fixture(tmp_path, golden_dir):
+    from sykepic_hip import prob
+    raw = tmp_path / "raw" / "valid"
+    raw.mkdir(parents=True)
+    for ext in ("adc", "hdr", "roi"):
+        shutil.copy(golden_dir / "ref_data" / f"D20180712T065600_IFCB114.{ext}", raw)
+    model, sd = _model_dir(tmp_path, golden_dir)
+    out_dir = tmp_path / "out"
+    prob.call(Args(raw=str(raw), samples=None, image_dir=None, images=None, model=str(model), out=out_dir,
+                   batch_size=64, num_workers=2, force=False))
+    # --- the reference test's assertions, verbatim in meaning ---
+    out_csvs = list(out_dir.glob("**/*.csv"))
+    assert len(out_csvs) == 1
+    assert out_csvs[0] == out_dir / "2018" / "07" / "12" / "D20180712T065600_IFCB114.prob.csv"
+    lines = out_csvs[0].read_text().splitlines(keepends=True)
+    assert len(lines) == 3
+    header = lines[0].split(",")
+    assert len(header) == 51 and header[0] == "roi"
+    roi_2 = list(filter(None, lines[1].split(",")))
+    roi_3 = list(filter(None, lines[2].split(",")))
+    assert len(roi_2) == len(header) and len(roi_3) == len(header)
+    assert int(roi_2[0]) == 2 and int(roi_3[0]) == 3
+    # --- no PNGs left beside the raw data (quirk Q8) ---
+    assert sorted(p.name for p in raw.iterdir()) == sorted(f"D20180712T065600_IFCB114.{e}" for e in ("adc", "hdr", "roi"))
+    # --- numbers: same preprocessing, oracle forward ---
+    from oracle import refnet
+    from sykepic_hip import ifcb
+    from sykepic_hip.config import get_img_shape, get_transforms
+    cfg = ConfigParser()
+    cfg.read(model / "config.ini")
+    _, ev = get_transforms(cfg, get_img_shape(cfg))
+    rois = ifcb.read_rois(raw / "D20180712T065600_IFCB114.adc", raw / "D20180712T065600_IFCB114.roi")
+    x = torch.stack([ev(np.repeat(img[:, :, None], 3, axis=2)) for _, img in rois])
+    ref = refnet.probabilities(refnet.load_numpy_state(refnet.RefNet("resnet18", 50), sd), x).numpy()
+    got = np.array([[float(v) for v in ln.split(",")[1:]] for ln in lines[1:]])
+    assert np.abs(got - ref).max() <= 1e-3 + 5e-6          # 5 printed decimals
+    # second run without --force keeps the file; with --force rewrites it
+    stamp = out_csvs[0].stat().st_mtime_ns
+    prob.call(Args(str(raw), None, None, None, str(model), out_dir, 64, 2, False))
+    assert out_csvs[0].stat().st_mtime_ns == stamp
+
+
+def test_prob_from_png_images(tmp_path, golden_dir):
+    from sykepic_hip import ifcb, prob
+    model, _ = _model_dir(tmp_path, golden_dir)
+    img_dir = tmp_path / "imgs"
+    ifcb.raw_to_png(golden_dir / "ref_data" / "D20180712T065600_IFCB114.adc",
+                    golden_dir / "ref_data" / "D20180712T065600_IFCB114.roi", out_dir=img_dir, force=True)
+    assert sorted(p.name for p in img_dir.iterdir()) == ["D20180712T065600_IFCB114_00002.png",
+                                                        "D20180712T065600_IFCB114_00003.png"]
+    out = tmp_path / "o"
+    prob.call(Args(None, None, str(img_dir), None, str(model), out, 64, 0, False))
+    text = (out / "D20180712T065600_IFCB114.prob.csv").read_text().splitlines()
+    assert len(text) == 3 and text[1].startswith("2,") and text[2].startswith("3,")
+
+
+INI = """[dataset]
+path = {ds}
+split = 0.6, 0.2, 0.2
+external_test =
+min_N =
+max_N =
+exclude =
+random_seed = 42
+oversample_until = 12
+oversample_with_decay =
+[model]
+path = {models}
+network = resnet18
+weights =
+id = auto
+exist_ok = no
+head = 32, 16
+dropout =
+[image]
+shape = 3, 64, 64
+augmentations = flip, translate, zoom, brightness
+imagenet_normalization = no
+border = mode
+zoom_range = 0.8, 1.2
+brightness_range = 0.95, 1.1
+max_rotation = 10
+batch_size = 16
+num_workers = 0
+[train]
+gpu = yes
+max_epochs = 4
+early_stop_patience = 12
+learning_rate = 0.01
+optimizer = Adam
+[lr_warmup]
+use = yes
+factor_1 = 0.1
+factor_2 = 0.5
+step_1 = 2
+step_2 = 3
+step_3 = 4
+verbose = no
+[lr_reduction]
+use = yes
+factor = 0.1
+patience = 4
+verbose = yes
+"""
+
+
+def test_train_main_end_to_end(tmp_path, capsys):
+    """4 epochs on 3 synthetic classes: artefacts, checkpoint interchangeable
+    with the torch module of the reference, loss goes down."""
+    from oracle import refnet
+    from sykepic_hip import train
+    rng = np.random.RandomState(0)
+    ds = tmp_path / "ds"
+    for ci, name in enumerate(("blob", "bars", "flat")):
+        (ds / name).mkdir(parents=True)
+        for i in range(20):
+            h, w = rng.randint(30, 70), rng.randint(30, 90)
+            img = np.full((h, w), 180, np.uint8)
+            if ci == 0:
+                img[h // 4: h // 2, w // 4: w // 2] = 40
+            elif ci == 1:
+                img[:, ::6] = 60
+            img = np.clip(img.astype(np.int32) + rng.randint(-10, 10, (h, w)), 0, 255).astype(np.uint8)
+            Image.fromarray(img).save(ds / name / f"{name}_{i:02d}.png")
+    ini = tmp_path / "train.ini"
+    ini.write_text(INI.format(ds=ds, models=tmp_path / "models"))
+    train.main(namedtuple("A", "config collage dist save_images")(str(ini), None, None, None))
+    out = capsys.readouterr().out
+    assert "[ERROR]" not in out, out
+    mdir = tmp_path / "models" / "resnet18_1"
+    for f in ("config.ini", "class_names.txt", "class_distribution.csv", "best_state.pth", "test_report.txt"):
+        assert (mdir / f).is_file(), f
+    assert (mdir / "class_names.txt").read_text().split("\n") == ["bars", "blob", "flat"]
+    stats = [ln for ln in out.splitlines() if ln.startswith("[STAT] Train")]
+    assert len(stats) == 4
+    losses = [float(s.split("Train Loss: ")[1]) for s in stats]
+    assert losses[-1] < losses[0]
+    # the checkpoint is a plain state_dict the reference's torch module accepts
+    sd = torch.load(mdir / "best_state.pth")
+    ref = refnet.RefNet("resnet18", 3, head=(32, 16))
+    ref.load_state_dict(sd)
+    assert int(sd["base.1.num_batches_tracked"]) > 0
+    assert "accuracy" in (mdir / "test_report.txt").read_text()
