@@ -166,6 +166,25 @@ def main():
     # ---- roofline of the dominant kernel, HIP events on the launch stream ----
     roof = None
     layers = []
+    if rank == 0 and args.mode == "train":
+        phases = net.profile_train(x, y, iters=3)
+        conv = [(n_, ms, fl) for n_, ms, fl, _ in phases if fl > 0]
+        conv_ms = sum(ms for _, ms, _ in conv)
+        conv_fl = sum(fl for _, _, fl in conv)
+        all_ms = sum(ms for _, ms, _, _ in phases)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd, dgrad) + conv_wgrad_kernel",
+                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": int(sum(l for n_, _, fl, l in phases if fl > 0)),
+                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
+                "phases_ms": {n_: round(ms, 3) for n_, ms, _, _ in phases}}
+        if args.layers_out:
+            Path(args.layers_out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.layers_out).write_text(json.dumps(
+                [{"phase": n_, "ms": round(ms, 4), "gflop": round(fl / 1e9, 2), "launches": l,
+                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 and fl > 0 else None}
+                 for n_, ms, fl, l in phases], indent=1))
     if rank == 0 and args.mode == "infer":
         layers = net.profile_layers(x, iters=5)
         conv = [(n, ms, fl, by) for n, ms, fl, by in layers if fl > 0 and not n.startswith("head.")]

@@ -181,6 +181,13 @@ typedef struct {
 int spk_model_profile_infer(spk_model* m, const void* x_dev, int n, int h, int w, int layout,
                             int dtype, int iters, spk_layer_time* out, int cap);
 
+/* Per-phase timing of spk_train_forward_backward (same event method): one
+ * record per kernel group (conv fwd / dgrad / wgrad, BN, pooling, head...);
+ * `flops` = algorithmic FLOPs of the phase, `bytes` = launches per step. */
+int spk_model_profile_train(spk_model* m, const void* x_dev, int n, int h, int w, int layout,
+                            int dtype, const int64_t* y_dev, float* stats_dev, int iters,
+                            spk_layer_time* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,7 +38,21 @@ struct ConvTrain {
   size_t wdg_off = 0;       // bf16 [Cin][taps][Cout] dgrad image
 };
 
+struct PhaseProf {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<std::pair<int, int>> marks;  // (phase id, event index)
+  int used = 0;
+};
+enum { PH_INPUT, PH_CONV_FWD, PH_BN_FWD, PH_POOL_FWD, PH_HEAD_FWD, PH_LOSS, PH_HEAD_BWD, PH_POOL_BWD,
+       PH_BN_BWD, PH_CONV_DGRAD, PH_CONV_WGRAD, PH_WGRAD_REDUCE, PH_COUNT };
+static const char* kPhaseName[PH_COUNT] = {
+    "input.to_nhwc4", "conv_fwd (conv_igemm_kernel)", "bn_fwd (finalize+apply)", "pool_fwd", "head_fwd",
+    "cross_entropy", "head_bwd", "pool_bwd", "bn_bwd (reduce+finalize+apply)",
+    "conv_dgrad (conv_igemm_kernel)", "conv_wgrad (conv_wgrad_kernel)", "wgrad_slab_reduce"};
+
 struct TrainState {
+  PhaseProf prof;
   // persistent across plans
   float* gbuf = nullptr;   // flat gradients   [n_train]
   float* m1 = nullptr;     // Adam exp_avg / SGD momentum [n_train]
@@ -74,6 +88,20 @@ void spk_train_free(spk_model* m) {
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// records an event AFTER the work of `phase` was enqueued (profiling runs only)
+static void mark(spk_model* m, int phase) {
+  PhaseProf& p = m->train->prof;
+  if (!p.on) return;
+  if (p.used == (int)p.pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    p.pool.push_back(e);
+  }
+  hipEventRecord(p.pool[p.used], m->stream);
+  p.marks.push_back({phase, p.used});
+  ++p.used;
+}
 
 static int ensure_state(spk_model* m) {
   if (m->train) return SPK_OK;
@@ -215,7 +243,9 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   const int nl = (int)m->layers.size();
 
   // ------------------------------ forward ------------------------------
+  mark(m, -1);
   K_TRY(spk_launch_to_nhwc4(x, layout, dtype, n, m->in_chans, h, w, (bf16_t*)m->T(0), DT_BF16, s), "to_nhwc4");
+  mark(m, PH_INPUT);
   for (int i = 0; i < nl; ++i) {
     Layer& L = m->layers[i];
     const TDim& in = m->tdims[L.d.src];
@@ -228,6 +258,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         a.stats = part;
         int m_tiles = 0;
         K_TRY(spk_conv_launch(a, L.mode, s, &m_tiles), "conv");
+        mark(m, PH_CONV_FWD);
         float* st = t->stats + t->conv[i].stat_off;
         const int C = L.d.cout;
         K_TRY(spk_launch_bn_finalize(part, m_tiles, C, (double)a.M, m->P(L.p_g), m->P(L.p_b),
@@ -237,19 +268,23 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
                                   L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
                                   (bf16_t*)m->T(L.d.dst), (size_t)a.M * C, C, L.d.relu, s), "bn_apply");
+        mark(m, PH_BN_FWD);
         break;
       }
       case SPK_OP_MAXPOOL:
         K_TRY(spk_launch_maxpool_idx((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), pool_idx, n, in.h,
                                      in.w, in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s), "maxpool");
+        mark(m, PH_POOL_FWD);
         break;
       case SPK_OP_GAVGPOOL:
         K_TRY(spk_launch_gavgpool((const bf16_t*)m->T(L.d.src), (float*)m->T(L.d.dst), n, in.h * in.w, in.c,
                                   DT_BF16, s), "avgpool");
+        mark(m, PH_POOL_FWD);
         break;
       case SPK_OP_LINEAR:
         K_TRY(spk_launch_linear_fwd((const float*)m->T(L.d.src), m->P(L.p_w), m->P(L.p_b),
                                     (float*)m->T(L.d.dst), n, L.d.cin, L.d.cout, s), "linear");
+        mark(m, PH_HEAD_FWD);
         break;
       default:
         HIP_TRY(hipMemcpyAsync(m->T(L.d.dst), m->T(L.d.src), (size_t)n * in.c * 4, hipMemcpyDeviceToDevice, s));
@@ -262,6 +297,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   const int last = m->layers.back().d.dst;
   const float* logits = (const float*)m->T(last);
   K_TRY(spk_launch_ce(logits, y, n, m->num_classes, stats, (float*)t->G(last), s), "cross-entropy");
+  mark(m, PH_LOSS);
   if (logits_out)
     HIP_TRY(hipMemcpyAsync(logits_out, logits, (size_t)n * m->num_classes * 4, hipMemcpyDeviceToDevice, s));
 
@@ -286,6 +322,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         // dX[n][i] = sum_o gy[n][o] * W[o][i]
         K_TRY(spk_launch_sgemm(gy, fout, 1, m->P(L.p_w), 1, fin, nullptr, (float*)t->G(L.d.src), fin, 1, n,
                                fin, fout, 1.f, 0, s), "linear dgrad");
+        mark(m, PH_HEAD_BWD);
         has_grad[L.d.src] = 1;
         break;
       }
@@ -296,11 +333,13 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
       case SPK_OP_GAVGPOOL:
         K_TRY(spk_launch_gavgpool_bwd((const float*)t->G(L.d.dst), (bf16_t*)t->G(L.d.src), n, in.h * in.w,
                                       in.c, s), "avgpool bwd");
+        mark(m, PH_POOL_BWD);
         has_grad[L.d.src] = 1;
         break;
       case SPK_OP_MAXPOOL:
         K_TRY(spk_launch_maxpool_bwd((const bf16_t*)t->G(L.d.dst), pool_idx, (bf16_t*)t->G(L.d.src), n, in.h,
                                      in.w, in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s), "maxpool bwd");
+        mark(m, PH_POOL_BWD);
         has_grad[L.d.src] = 1;
         break;
       case SPK_OP_CONV: {
@@ -314,6 +353,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                 pg.requires_grad ? t->gbuf + pg.off : nullptr,
                                 pb.requires_grad ? t->gbuf + pb.off : nullptr, dy, g_res,
                                 L.d.res >= 0 ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
+        mark(m, PH_BN_BWD);
         if (L.d.res >= 0) has_grad[L.d.res] = 1;
         if (L.d.src != 0) {
           // data gradient: implicit GEMM over the dgrad weight image
@@ -322,6 +362,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                     L.d.cin, L.d.k, L.d.stride, L.d.pad, L.d.k * L.d.k * C);
           a.res = has_grad[L.d.src] ? (const bf16_t*)t->G(L.d.src) : nullptr;
           K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
+          mark(m, PH_CONV_DGRAD);
           has_grad[L.d.src] = 1;
         }
         if (m->params[L.p_w].requires_grad) {
@@ -331,11 +372,13 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           spk_wgrad_plan(M, C, ktot, &sp, &pps);
           K_TRY(spk_wgrad_launch((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, L.d.cin, o.h, o.w, C,
                                  L.d.k, L.d.stride, L.d.pad, stem ? 1 : 0, sp, pps, s), "conv wgrad");
+          mark(m, PH_CONV_WGRAD);
           float* gw = t->gbuf + m->params[L.p_w].off;
           if (stem)
             K_TRY(spk_launch_stem_wgrad_unpack(slabs, gw, C, L.d.k, L.d.k, L.d.cin, sp, s), "stem wgrad unpack");
           else
             K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)C * ktot, sp, s), "wgrad reduce");
+          mark(m, PH_WGRAD_REDUCE);
         }
         break;
       }
@@ -427,4 +470,49 @@ extern "C" int spk_model_read_activation_grad(spk_model* m, int t, int n, float*
           host[(((size_t)i * d.c + c) * d.h + y) * d.w + x] = f;
         }
   return SPK_OK;
+}
+
+// Per-phase timing of the training step (HIP events on the model's stream
+// between kernel groups), averaged over `iters` steps after one warm-up.
+extern "C" int spk_model_profile_train(spk_model* m, const void* x, int n, int h, int w, int layout,
+                                       int dtype, const int64_t* y, float* stats, int iters,
+                                       spk_layer_time* out, int cap) {
+  if (!m || !out || cap < PH_COUNT || iters <= 0) return tfail(SPK_ERR_ARG, "profile_train: bad arguments");
+  SPK_TRY(spk_train_forward_backward(m, x, n, h, w, layout, dtype, y, stats, nullptr));  // warm-up + plan
+  TrainState* t = m->train;
+  std::vector<double> ms(PH_COUNT, 0.0);
+  std::vector<int> launches(PH_COUNT, 0);
+  for (int it = 0; it < iters; ++it) {
+    t->prof.on = true;
+    t->prof.marks.clear();
+    t->prof.used = 0;
+    const int rc = spk_train_forward_backward(m, x, n, h, w, layout, dtype, y, stats, nullptr);
+    t->prof.on = false;
+    if (rc != SPK_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    for (size_t k = 1; k < t->prof.marks.size(); ++k) {
+      float dt = 0.f;
+      HIP_TRY(hipEventElapsedTime(&dt, t->prof.pool[t->prof.marks[k - 1].second], t->prof.pool[t->prof.marks[k].second]));
+      const int ph = t->prof.marks[k].first;
+      if (ph >= 0) { ms[ph] += dt; launches[ph] += 1; }
+    }
+  }
+  // algorithmic work of the conv phases
+  double f_fwd = 0, f_dg = 0, f_wg = 0;
+  for (const Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV) continue;
+    const TDim& o = m->tdims[L.d.dst];
+    const double f = 2.0 * n * o.h * o.w * (double)L.d.cout * L.d.cin * L.d.k * L.d.k;
+    f_fwd += f;
+    if (L.d.src != 0) f_dg += f;
+    if (m->params[L.p_w].requires_grad) f_wg += f;
+  }
+  for (int ph = 0; ph < PH_COUNT; ++ph) {
+    memset(&out[ph], 0, sizeof out[ph]);
+    strncpy(out[ph].name, kPhaseName[ph], sizeof out[ph].name - 1);
+    out[ph].ms = (float)(ms[ph] / iters);
+    out[ph].flops = ph == PH_CONV_FWD ? f_fwd : ph == PH_CONV_DGRAD ? f_dg : ph == PH_CONV_WGRAD ? f_wg : 0.0;
+    out[ph].bytes = (double)launches[ph] / iters;  // launches per step
+  }
+  return PH_COUNT;
 }

@@ -69,6 +69,8 @@ SYMBOLS = {
     "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_model_profile_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(LayerTime), C.c_int]),
+    "spk_model_profile_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+                                          C.c_int, C.POINTER(LayerTime), C.c_int]),
 }
 
 _lib = None

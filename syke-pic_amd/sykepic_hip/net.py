@@ -423,6 +423,20 @@ class HipNet:
                                                            C.c_void_p(buf.ctypes.data), int(buf.size)))
         return torch.from_numpy(buf)
 
+    def profile_train(self, x, y, iters=3):
+        """[(phase, ms per step, algorithmic FLOPs, launches per step)]."""
+        x, n, h, w, layout, dtype = self._prep(x)
+        y = y.to(self.device, dtype=torch.int64).contiguous()
+        recs = (lib.LayerTime * 32)()
+        with torch.cuda.device(self.device):
+            lib.check(self._lib.spk_model_set_stream(self._h, self._stream()))
+            cnt = self._lib.spk_model_profile_train(self._h, C.c_void_p(x.data_ptr()), n, h, w, layout, dtype,
+                                                    C.c_void_p(y.data_ptr()),
+                                                    C.c_void_p(self._stats_buf().data_ptr()), iters, recs, 32)
+        if cnt < 0:
+            lib.check(cnt)
+        return [(r.name.decode(), r.ms, r.flops, r.bytes) for r in recs[:cnt]]
+
     def profile_layers(self, x, iters=5):
         x, n, h, w, layout, dtype = self._prep(x)
         cap = len(self.graph.ops) + 4
