@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=50)
-    ap.add_argument("--mode", default="infer", choices=["infer", "train"])
+    ap.add_argument("--mode", default="both", choices=["both", "infer", "train"])
     ap.add_argument("--precision", default="precise", choices=["precise", "fast", "bf16"],
                     help="precise: fp16 + hi/lo split weights (passes the 1e-3 parity tolerance); "
                          "fast: plain fp16; bf16")
@@ -89,6 +89,113 @@ def cpu_baseline(network, classes, size, mode, budget_s):
                       f"({iters * bs} images, {dt:.1f} s)"}
 
 
+def run_mode(mode, args, net, x, y, dist, dev, rank, world):
+    """Times K steps of one mode; returns the result dict on rank 0."""
+    if mode == "train":
+        from sykepic_hip.dp import GradSync
+        from sykepic_hip.optim import HipOptimizer
+        net.train()
+        for p in net.parameters():   # post-step_3 state: everything unfrozen (the most expensive phase)
+            p.requires_grad = True
+        opt = HipOptimizer(net, "Adam", [
+            {"params": [p for p in net.parameters()], "lr": 1e-4}, {"params": [], "lr": 0.0},
+            {"params": [], "lr": 0.0}])
+        sync = GradSync(net, dist) if world > 1 else None
+
+        def step():
+            net.forward_backward(x, y)
+            if sync:
+                sync.all_reduce(opt)
+            opt.step()
+        dtype = "bf16"
+    else:
+        net.eval()
+
+        def step():
+            return net.probabilities(x)
+        dtype = "bf16" if args.precision == "bf16" else "f16"
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return None
+
+    # ---- roofline of the dominant kernel, HIP events on the launch stream ----
+    layers_out = args.layers_out and (args.layers_out if mode == args.mode or args.mode == "both" and mode == "infer"
+                                      else args.layers_out + "." + mode)
+    if mode == "train":
+        phases = net.profile_train(x, y, iters=3)
+        conv = [(n_, ms, fl) for n_, ms, fl, _ in phases if fl > 0]
+        conv_ms = sum(ms for _, ms, _ in conv)
+        conv_fl = sum(fl for _, _, fl in conv)
+        all_ms = sum(ms for _, ms, _, _ in phases)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd, dgrad) + conv_wgrad_kernel",
+                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": int(sum(l for n_, _, fl, l in phases if fl > 0)),
+                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
+                "phases_ms": {n_: round(ms, 3) for n_, ms, _, _ in phases}}
+        table = [{"phase": n_, "ms": round(ms, 4), "gflop": round(fl / 1e9, 2), "launches": l,
+                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 and fl > 0 else None}
+                 for n_, ms, fl, l in phases]
+    else:
+        layers = net.profile_layers(x, iters=5)
+        conv = [(n, ms, fl, by) for n, ms, fl, by in layers if fl > 0 and not n.startswith("head.")]
+        conv_ms = sum(ms for _, ms, _, _ in conv)
+        conv_fl = sum(fl for _, _, fl, _ in conv)
+        all_ms = sum(ms for _, ms, _, _ in layers)
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
+                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
+                "hbm_GBs_algorithmic": round(sum(by for _, _, _, by in layers) / (all_ms * 1e-3) / 1e9, 1)}
+        table = [{"layer": n, "ms": round(ms, 4), "gflop": round(fl / 1e9, 3), "mbytes": round(by / 1e6, 2),
+                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+                  "gbs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+                 for n, ms, fl, by in layers]
+    if layers_out:
+        Path(layers_out).parent.mkdir(parents=True, exist_ok=True)
+        Path(layers_out).write_text(json.dumps(table, indent=1))
+
+    total_images = args.batch * world * args.steps
+    out = {
+        "metric": f"IFCB images/sec, {args.network} 224x224 {mode} step",
+        "value": round(total_images / dt, 1), "unit": "images/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+        "data": "synthetic",
+        "config": {"workload": f"{args.network}_{mode}_b{args.batch}x{world}_"
+                               f"{args.size}x{args.size}x3_{args.classes}cls_head256-128",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "precision": args.precision if mode == "infer" else "bf16",
+                   "parallelism": f"dp{world}"},
+        "roofline": roof,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.network, args.classes, args.size, mode,
+                                           args.cpu_seconds if mode == "infer" else args.cpu_seconds / 2)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,110 +227,18 @@ def main():
     x = torch.from_numpy(synth.synth_images(args.batch, 3, args.size, args.size, seed=rank)).to(dev)
     y = torch.from_numpy(synth.synth_labels(args.batch, args.classes, seed=1000 + rank)).to(dev)
 
-    if args.mode == "train":
-        from sykepic_hip.optim import HipOptimizer
-        from sykepic_hip.dp import GradSync
-        net.train()
-        for p in net.parameters():   # post-step_3 state: everything unfrozen (most expensive phase)
-            p.requires_grad = True
-        opt = HipOptimizer(net, "Adam", [
-            {"params": [p for p in net.parameters()], "lr": 1e-4}, {"params": [], "lr": 0.0},
-            {"params": [], "lr": 0.0}])
-        sync = GradSync(net, dist) if world > 1 else None
-
-        def step():
-            net.forward_backward(x, y)
-            if sync:
-                sync.all_reduce()
-            opt.step()
-        dtype = "bf16"
-    else:
-        net.eval()
-
-        def step():
-            return net.probabilities(x)
-        dtype = "bf16" if args.precision == "bf16" else "f16"
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- roofline of the dominant kernel, HIP events on the launch stream ----
-    roof = None
-    layers = []
-    if rank == 0 and args.mode == "train":
-        phases = net.profile_train(x, y, iters=3)
-        conv = [(n_, ms, fl) for n_, ms, fl, _ in phases if fl > 0]
-        conv_ms = sum(ms for _, ms, _ in conv)
-        conv_fl = sum(fl for _, _, fl in conv)
-        all_ms = sum(ms for _, ms, _, _ in phases)
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd, dgrad) + conv_wgrad_kernel",
-                "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "launches": int(sum(l for n_, _, fl, l in phases if fl > 0)),
-                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
-                "phases_ms": {n_: round(ms, 3) for n_, ms, _, _ in phases}}
-        if args.layers_out:
-            Path(args.layers_out).parent.mkdir(parents=True, exist_ok=True)
-            Path(args.layers_out).write_text(json.dumps(
-                [{"phase": n_, "ms": round(ms, 4), "gflop": round(fl / 1e9, 2), "launches": l,
-                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 and fl > 0 else None}
-                 for n_, ms, fl, l in phases], indent=1))
-    if rank == 0 and args.mode == "infer":
-        layers = net.profile_layers(x, iters=5)
-        conv = [(n, ms, fl, by) for n, ms, fl, by in layers if fl > 0 and not n.startswith("head.")]
-        conv_ms = sum(ms for _, ms, _, _ in conv)
-        conv_fl = sum(fl for _, _, fl, _ in conv)
-        all_ms = sum(ms for _, ms, _, _ in layers)
-        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2),
-                "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
-                "launches": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
-                "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
-                "hbm_GBs_algorithmic": round(sum(by for _, _, _, by in layers) / (all_ms * 1e-3) / 1e9, 1)}
-        if args.layers_out:
-            Path(args.layers_out).parent.mkdir(parents=True, exist_ok=True)
-            Path(args.layers_out).write_text(json.dumps(
-                [{"layer": n, "ms": round(ms, 4), "gflop": round(fl / 1e9, 3), "mbytes": round(by / 1e6, 2),
-                  "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
-                  "gbs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
-                 for n, ms, fl, by in layers], indent=1))
-
+    # headline = the inference step (net_pass body); the training step of the
+    # same model/config rides along under "train" (BASELINE metric names both)
+    modes = ["infer", "train"] if args.mode == "both" else [args.mode]
+    results = [run_mode(m, args, net, x, y, dist, dev, rank, world) for m in modes]
     if rank == 0:
-        total_images = args.batch * world * args.steps
-        out = {
-            "metric": f"IFCB images/sec, {args.network} 224x224 {args.mode} step",
-            "value": round(total_images / dt, 1), "unit": "images/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
-            "data": "synthetic",
-            "config": {"workload": f"{args.network}_{args.mode}_b{args.batch}x{world}_"
-                                   f"{args.size}x{args.size}x3_{args.classes}cls_head256-128",
-                       "per_gpu_batch": args.batch, "global_batch": args.batch * world,
-                       "precision": args.precision if args.mode == "infer" else "bf16",
-                       "parallelism": f"dp{world}"},
-            "roofline": roof,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.network, args.classes, args.size, args.mode,
-                                               args.cpu_seconds)
+        out = results[0]
+        if len(results) > 1:
+            t = results[1]
+            out["train"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")
+                            if k in t}
+            if "cpu_baseline" in t:
+                out["train"]["cpu_baseline"] = t["cpu_baseline"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

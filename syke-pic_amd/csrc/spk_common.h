@@ -76,6 +76,7 @@ struct ConvArgs {
   int relu;
   int dt;               // DT_BF16 / DT_F16
   int splitw;           // w holds [2][Cout][K]: hi then lo halves (f16 eval only)
+  int cfg, dma;         // tile config / main-loop flavour; -1 = autotuned or heuristic
   unsigned int x_bytes, w_bytes;
 };
 

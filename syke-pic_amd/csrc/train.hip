@@ -209,6 +209,7 @@ void spk_train_mark_dirty(spk_model* m) {
 static void fill_conv(ConvArgs& a, const bf16_t* x, const bf16_t* w, bf16_t* y, int N, int H, int W,
                       int Cin, int Ho, int Wo, int Cout, int k, int stride, int pad, int K) {
   memset(&a, 0, sizeof a);
+  a.cfg = a.dma = -1;
   a.x = x; a.w = w; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.kh = a.kw = k; a.stride = stride; a.pad = pad;
