@@ -208,6 +208,7 @@ void spk_wgrad_plan(int M, int Cout, int Ktot, int* splits, int* pix_per_split) 
   int sp = (1024 + tiles - 1) / tiles;
   const int max_sp = (M + 511) / 512;
   if (sp > max_sp) sp = max_sp;
+  if (sp > 96) sp = 96;  // slab traffic + the ordered reduce grow with the split count
   if (sp < 1) sp = 1;
   int pps = ((M + sp - 1) / sp + 63) / 64 * 64;
   sp = (M + pps - 1) / pps;

@@ -325,14 +325,21 @@ __global__ void colsum_kernel(const float* __restrict__ dy, float* __restrict__ 
   db[j] = s;
 }
 
-// split-K wgrad slabs -> gradient, fixed order
+// split-K wgrad slabs -> gradient, fixed order.  8 independent partial sums
+// keep 8 loads in flight per thread (the slabs are read exactly once); they
+// are combined in a fixed tree, so the result is reproducible.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n,
                                    int splits) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * n + i];
-    out[i] = s;
+    float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(k + u) * n + i];
+    }
+    for (int u = 0; k < splits; ++k, ++u) p[u] += slabs[(size_t)k * n + i];
+    out[i] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
   }
 }
 

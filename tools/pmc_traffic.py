@@ -1,0 +1,48 @@
+"""HBM traffic of the dominant kernel from two rocprofv3 --pmc passes
+(FETCH_SIZE, WRITE_SIZE; separate runs of the same bench command), corrected
+as MI355X_MICROARCH.md prescribes for gfx950: both counters are in KiB,
+FETCH_SIZE reports exactly 1/2 of a wide coalesced read stream (checked on
+to_nhwc4_kernel, whose byte counts are known), WRITE_SIZE is exact.
+
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json
+Takes the conv_igemm_kernel dispatches of ONE steady-state forward pass (the
+dispatches between the last two to_nhwc4_kernel launches), so autotuning
+launches are excluded."""
+import csv
+import json
+import sys
+
+
+def one_pass(path):
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    marks = [i for i, r in enumerate(rows) if "to_nhwc4_kernel" in r["Kernel_Name"]]
+    seg = rows[marks[-2]:marks[-1]]
+    return seg
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    f, w = one_pass(fetch), one_pass(write)
+    cal_f = [float(r["Counter_Value"]) for r in f if "to_nhwc4_kernel" in r["Kernel_Name"]]
+    cal_w = [float(r["Counter_Value"]) for r in w if "to_nhwc4_kernel" in r["Kernel_Name"]]
+    conv_f = [float(r["Counter_Value"]) for r in f if "conv_igemm_kernel" in r["Kernel_Name"]]
+    conv_w = [float(r["Counter_Value"]) for r in w if "conv_igemm_kernel" in r["Kernel_Name"]]
+    all_f = sum(float(r["Counter_Value"]) for r in f)
+    all_w = sum(float(r["Counter_Value"]) for r in w)
+    res = {
+        "kernel": "conv_igemm_kernel",
+        "launches_per_step": len(conv_f),
+        "fetch_bytes_per_step": sum(conv_f) * 1024 * 2,
+        "write_bytes_per_step": sum(conv_w) * 1024,
+        "calibration": {"to_nhwc4 FETCH_SIZE KiB (raw)": cal_f, "to_nhwc4 WRITE_SIZE KiB": cal_w,
+                        "note": "batch 256 x 3 x 224 x 224 fp32 in = 154,140,672 B; NHWC4 16-bit out = 102,760,448 B"},
+        "all_kernels_bytes_per_step": all_f * 2048 + all_w * 1024,
+    }
+    res["traffic_bytes_per_launch"] = (res["fetch_bytes_per_step"] + res["write_bytes_per_step"]) / max(1, len(conv_f))
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
