@@ -166,8 +166,14 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "traffic": None,
                 "launches": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
+                "algorithmic_bytes_per_launch": round(sum(by for _, _, _, by in conv) / len(conv)),
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
                 "hbm_GBs_algorithmic": round(sum(by for _, _, _, by in layers) / (all_ms * 1e-3) / 1e9, 1)}
+        pmc = ROOT / "profiles" / f"r01_pmc_traffic_infer_{args.precision}.json"
+        if pmc.is_file() and args.batch == 256 and args.network == "resnet50":
+            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+            roof["traffic"] = round(json.loads(pmc.read_text())["traffic_bytes_per_launch"])
+            roof["traffic_source"] = str(pmc.relative_to(ROOT))
         table = [{"layer": n, "ms": round(ms, 4), "gflop": round(fl / 1e9, 3), "mbytes": round(by / 1e6, 2),
                   "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
                   "gbs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
@@ -204,9 +210,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SPK_DIST_BACKEND", "nccl")  # "gloo": single-GPU rehearsal of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         dist = None
         torch.cuda.set_device(local_rank)
