@@ -52,17 +52,40 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(network, classes, size, mode, budget_s):
-    """The reference's CPU path (torch fp32 NCHW kernels driven by the
-    net_pass / train-step logic) timed on this host; oracle = its restatement."""
-    from oracle import refnet
-    from sykepic_hip import arch, synth
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup
+    CPU quota (a GPU box hands out a share of a large host; using every
+    visible core would oversubscribe it)."""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    cores = min(cores, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if q > 0:
+                    cores = min(cores, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(cores, 64))
+
+
+def cpu_baseline(network, classes, size, mode, budget_s):
+    """The reference's CPU path (torch fp32 NCHW kernels driven by the
+    net_pass / train-step logic) timed on this host; oracle = its restatement."""
+    from oracle import refnet
+    from sykepic_hip import arch, synth
+    cores = host_cores()
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: {network} {mode} on {cores} host threads", file=sys.stderr, flush=True)
     g = arch.build_graph(network, classes)
     sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
     net = refnet.load_numpy_state(refnet.RefNet(network, classes), sd)
@@ -241,7 +264,11 @@ def main():
     # headline = the inference step (net_pass body); the training step of the
     # same model/config rides along under "train" (BASELINE metric names both)
     modes = ["infer", "train"] if args.mode == "both" else [args.mode]
-    results = [run_mode(m, args, net, x, y, dist, dev, rank, world) for m in modes]
+    results = []
+    for m in modes:
+        if rank == 0:
+            print(f"[bench] {m}: {args.warmup} warm-up + {args.steps} timed steps", file=sys.stderr, flush=True)
+        results.append(run_mode(m, args, net, x, y, dist, dev, rank, world))
     if rank == 0:
         out = results[0]
         if len(results) > 1:

@@ -136,9 +136,10 @@ int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, 
                            float* scale, float* shift, float eps, float momentum, float* tmp,
                            hipStream_t s);
 int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift, const bf16_t* res,
-                        bf16_t* a, size_t numel, int C, int relu, hipStream_t s);
+                        bf16_t* a, unsigned char* mask, size_t numel, int C, int relu, hipStream_t s);
 int spk_bn_bwd_blocks(int M, int C, int* rows_per_block);
-int spk_launch_bn_bwd(const bf16_t* g, const bf16_t* a, const bf16_t* y, const float* mean,
+// `mask`: one ReLU bit per element ([M][C/8] bytes) written by spk_launch_bn_apply
+int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* mask, const bf16_t* y, const float* mean,
                       const float* invstd, const float* gamma, float* partials, float* coef,
                       float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
                       int C, int relu, float* tmp, hipStream_t s);

@@ -33,6 +33,7 @@ static int tfail(int code, const std::string& msg) {
 
 struct ConvTrain {
   size_t raw_off = 0;       // bf16 raw conv output (pre-BN), same shape as dst
+  size_t mask_off = 0;      // ReLU mask, 1 bit per element
   size_t stat_off = 0;      // floats: mean[C], invstd[C], scale[C], shift[C]
   size_t wfwd_off = 0;      // bf16 [Cout][K] forward image
   size_t wdg_off = 0;       // bf16 [Cin][taps][Cout] dgrad image
@@ -72,6 +73,7 @@ struct TrainState {
 
   void* G(int t) const { return (char*)arena + goff[t]; }
   bf16_t* RAW(int layer) const { return (bf16_t*)((char*)arena + conv[layer].raw_off); }
+  unsigned char* MASK(int layer) const { return (unsigned char*)arena + conv[layer].mask_off; }
 };
 
 void spk_train_free(spk_model* m) {
@@ -158,6 +160,8 @@ static int plan_train(spk_model* m, int n, int h, int w) {
       const size_t bytes = (size_t)n * o.h * o.w * o.c * 2;
       t->conv[i].raw_off = total;
       total += al256(bytes);
+      t->conv[i].mask_off = total;
+      total += al256(bytes / 16);
       max_conv = std::max(max_conv, bytes);
       const int M = n * o.h * o.w;
       int sp, pps;
@@ -268,7 +272,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         L.nbt += 1;
         K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
                                   L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
-                                  (bf16_t*)m->T(L.d.dst), (size_t)a.M * C, C, L.d.relu, s), "bn_apply");
+                                  (bf16_t*)m->T(L.d.dst), t->MASK(i), (size_t)a.M * C, C, L.d.relu, s), "bn_apply");
         mark(m, PH_BN_FWD);
         break;
       }
@@ -349,7 +353,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         const Param& pg = m->params[L.p_g];
         const Param& pb = m->params[L.p_b];
         bf16_t* g_res = L.d.res >= 0 ? (bf16_t*)t->G(L.d.res) : nullptr;
-        K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), (const bf16_t*)m->T(L.d.dst), t->RAW(i), st,
+        K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st,
                                 st + C, m->P(L.p_g), part, coef,
                                 pg.requires_grad ? t->gbuf + pg.off : nullptr,
                                 pb.requires_grad ? t->gbuf + pb.off : nullptr, dy, g_res,

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(
 // a = relu?(y*scale + shift (+ res))
 __global__ void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const bf16_t* __restrict__ res,
-                                bf16_t* __restrict__ a, size_t n8, int C, int relu) {
+                                bf16_t* __restrict__ a, unsigned char* __restrict__ mask, size_t n8, int C,
+                                int relu) {
   const int c8 = C >> 3;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -109,8 +110,14 @@ __global__ void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __res
       for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
     if (relu) {
+      // one mask bit per element (1/16 of re-reading `a` in the two backward passes)
+      unsigned bits = 0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      for (int j = 0; j < 8; ++j) {
+        bits |= (v[j] > 0.f ? 1u : 0u) << j;
+        v[j] = fmaxf(v[j], 0.f);
+      }
+      if (mask) mask[i] = (unsigned char)bits;
     }
     *(u32x4_t*)(a + i * 8) = pack8(v);
   }
@@ -119,7 +126,7 @@ __global__ void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __res
 // ---- BatchNorm backward ----
 // stage 1: per-block partial sums over rows of dz = g*(a>0) and dz*xhat
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const bf16_t* __restrict__ g, const bf16_t* __restrict__ a, const bf16_t* __restrict__ y,
+    const bf16_t* __restrict__ g, const unsigned char* __restrict__ mask, const bf16_t* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partials,
     int M, int C, int relu, int rows_per_block) {
   extern __shared__ float sm[];  // [rows_in_flight][2][C]
@@ -135,13 +142,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; mu[j] = mean[cc * 8 + j]; is[j] = invstd[cc * 8 + j]; }
     for (int r = row0 + lane_r; r < row1; r += rif) {
       const size_t o = (size_t)r * C + cc * 8;
-      float gv[8], yv[8], av[8];
+      float gv[8], yv[8];
       unpack8(*(const u32x4_t*)(g + o), gv);
       unpack8(*(const u32x4_t*)(y + o), yv);
       if (relu) {
-        unpack8(*(const u32x4_t*)(a + o), av);
+        const unsigned bits = mask[o >> 3];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gv[j] = av[j] > 0.f ? gv[j] : 0.f;
+        for (int j = 0; j < 8; ++j) gv[j] = (bits >> j) & 1u ? gv[j] : 0.f;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s1[j] += gv[j]; s2[j] += gv[j] * (yv[j] - mu[j]) * is[j]; }
@@ -181,7 +188,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
 
 // stage 3: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); the
 // shortcut branch receives dz itself (g_res = dz or += dz).
-__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ a,
+__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ g, const unsigned char* __restrict__ mask,
                                     const bf16_t* __restrict__ y, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ coef,
                                     bf16_t* __restrict__ dy, bf16_t* __restrict__ g_res,
@@ -190,13 +197,13 @@ __global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ g, const bf16_t* 
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8;
        i += (size_t)gridDim.x * blockDim.x) {
     const int cc = (int)(i % c8) * 8;
-    float gv[8], yv[8], av[8], o[8];
+    float gv[8], yv[8], o[8];
     unpack8(*(const u32x4_t*)(g + i * 8), gv);
     unpack8(*(const u32x4_t*)(y + i * 8), yv);
     if (relu) {
-      unpack8(*(const u32x4_t*)(a + i * 8), av);
+      const unsigned bits = mask[i];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gv[j] = av[j] > 0.f ? gv[j] : 0.f;
+      for (int j = 0; j < 8; ++j) gv[j] = (bits >> j) & 1u ? gv[j] : 0.f;
     }
     if (g_res) {
       if (res_accumulate) {
@@ -472,9 +479,9 @@ int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, 
 }
 
 int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift, const bf16_t* res,
-                        bf16_t* a, size_t numel, int C, int relu, hipStream_t s) {
+                        bf16_t* a, unsigned char* mask, size_t numel, int C, int relu, hipStream_t s) {
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(numel / 8, 256)), dim3(256), 0, s, y, scale, shift,
-                     res, a, numel / 8, C, relu);
+                     res, a, mask, numel / 8, C, relu);
   return LAUNCH_OK();
 }
 
@@ -485,7 +492,7 @@ int spk_bn_bwd_blocks(int M, int C, int* rows_per_block) {
   return (M + rpb - 1) / rpb;
 }
 
-int spk_launch_bn_bwd(const bf16_t* g, const bf16_t* a, const bf16_t* y, const float* mean,
+int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* a, const bf16_t* y, const float* mean,
                       const float* invstd, const float* gamma, float* partials, float* coef,
                       float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
                       int C, int relu, float* tmp, hipStream_t s) {
