@@ -61,6 +61,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   unsigned char* const sA = smem;                    // [nbuf][BM][128 B]   (DMA: stage s at s*STAGE_BYTES)
   unsigned char* const sB = smem + (DMA ? A_BYTES : nbuf * A_BYTES);   // [nbuf][NB*BN][128 B]
 
+  const bool cls = MODE == CONV_MODE_DGRAD && a.cls_ph >= 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,8 +102,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
     } else if (MODE == CONV_MODE_DGRAD) {
       // rows are pixels of the forward conv's INPUT; the "input" tensor is dy.
       // tap (r,s) reads dy[(h+pad-r)/stride][(w+pad-s)/stride] when divisible.
-      a_h0[i] = (m < a.M) ? ho + a.pad : -(1 << 20);
-      a_w0[i] = wo + a.pad;
+      // stride 2 is decomposed by output parity (cls_ph, cls_pw): the GEMM rows
+      // of one launch are the pixels h = 2*ho + ph, w = 2*wo + pw, and only the
+      // taps r = (ph+pad)&1, +2, ... can hit them — no MFMA work on taps that
+      // never divide.
+      const int hh = cls ? 2 * ho + a.cls_ph : ho, ww = cls ? 2 * wo + a.cls_pw : wo;
+      a_h0[i] = (m < a.M) ? hh + a.pad : -(1 << 20);
+      a_w0[i] = ww + a.pad;
       a_base[i] = img * a.H * a.W * a.Cin + chunk * 8;
     } else {
       const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
@@ -119,10 +125,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
     b_off[i] = ((half * a.Cout + n0 + rr - half * BN) * a.K + chunk * 8) * 2;
   }
 
-  const int KT = a.K / BK;
+  const int KT = a.kt_count > 0 ? a.kt_count : a.K / BK;
 
   // scalar walk over (tap row r, tap col s, channel block c0) for generic mode
-  int kr = 0, ks_ = 0, kc0 = 0;
+  const int r_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_ph + a.pad) & 1) : 0;
+  const int s_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_pw + a.pad) & 1) : 0;
+  const int tap_step = (MODE == CONV_MODE_DGRAD && cls) ? 2 : 1;
+  int kr = r_first, ks_ = s_first, kc0 = 0;
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   int dma_stage = 0;  // LDS stage the next issue_loads() call fills (DMA mode)
@@ -157,10 +166,16 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
             ok ? (unsigned)((a_base[i] + ((t >> sh) * a.W + (u >> sh)) * a.Cin + kc0) * 2) : 0x80000000u;
         put(rx, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
       }
+      // weights of this tap: K offset in the [Cin][kh][kw][Cout] image
+      const int wk = ((kr * a.kw + ks_) * a.Cin + kc0) * 2;
+#pragma unroll
+      for (int i = 0; i < B_ITERS; ++i)
+        put(rw, (unsigned)(b_off[i] + wk), rb[i], dB + i * (ROWS_PER_PASS * ROW_BYTES));
       kc0 += BK;
       if (kc0 >= a.Cin) {
         kc0 = 0;
-        if (++ks_ == a.kw) { ks_ = 0; ++kr; }
+        ks_ += tap_step;
+        if (ks_ >= a.kw) { ks_ = s_first; kr += tap_step; }
       }
     } else {
       const int tap_off = (kr * a.W + ks_) * a.Cin + kc0;
@@ -177,9 +192,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
         if (++ks_ == a.kw) { ks_ = 0; ++kr; }
       }
     }
+    if (MODE != CONV_MODE_DGRAD) {
 #pragma unroll
-    for (int i = 0; i < B_ITERS; ++i)
-      put(rw, (unsigned)(b_off[i] + kt * (BK * 2)), rb[i], dB + i * (ROWS_PER_PASS * ROW_BYTES));
+      for (int i = 0; i < B_ITERS; ++i)
+        put(rw, (unsigned)(b_off[i] + kt * (BK * 2)), rb[i], dB + i * (ROWS_PER_PASS * ROW_BYTES));
+    }
     if (DMA) dma_stage = dma_stage + 1 == STAGES ? 0 : dma_stage + 1;
   };
 
@@ -246,6 +263,17 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
     issue_loads(0, ra0, rb0);
   }
 
+  // GEMM row -> pixel index of the output tensor (identity except for the
+  // parity classes of a stride-2 dgrad, whose rows are every other pixel)
+  auto out_pixel = [&](int m) -> size_t {
+    if (!cls) return (size_t)m;
+    const int img = m / HoWo;
+    const int rem = m - img * HoWo;
+    const int ho = rem / a.Wo;
+    const int wo = rem - ho * a.Wo;
+    return ((size_t)img * a.oH + 2 * ho + a.cls_ph) * a.oW + 2 * wo + a.cls_pw;
+  };
+
   // epilogue operand prefetch: the shortcut tensor is independent of the K
   // loop, so its loads are issued now and land under the MFMAs
   constexpr int EPI_LD = WN + 4;          // floats per staged row (pad: conflict-free writes)
@@ -264,7 +292,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) {
         const int m = m0 + wm * WM + i * 16 + erow + p * RPP;
-        rres[i][p] = m < a.M ? *(const u32x4_t*)(a.res + (size_t)m * a.Cout + gcol) : u32x4_t{0, 0, 0, 0};
+        rres[i][p] = m < a.M ? *(const u32x4_t*)(a.res + out_pixel(m) * a.Cout + gcol) : u32x4_t{0, 0, 0, 0};
       }
   }
 
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
       const f32x4_t v1 = *(const f32x4_t*)(epi + row * EPI_LD + ecol + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (m < a.M) {
-        const size_t o = (size_t)m * a.Cout + gcol;
+        const size_t o = out_pixel(m) * a.Cout + gcol;
         if (a.stats) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
@@ -525,12 +553,14 @@ bool autotune_on() {
 
 int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_out) {
   if (a_in.K % BK || a_in.Cout % 64) return -2;
+  if (mode == CONV_MODE_DGRAD && a_in.stride != 1 && a_in.cls_ph < 0) return -2;  // stride 2 goes by parity class
   ConvArgs a = a_in;
   if (env_cfg() >= 0 || !autotune_on() || a.cfg >= 0) {
     const int cfg = a.cfg >= 0 ? a.cfg : (env_cfg() >= 0 ? env_cfg() : pick_cfg(a.M, a.Cout));
     return launch_with(a, mode, cfg, s, m_tiles_out);
   }
-  const TuneKey key(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, a.pad,
+  const int pad_cls = a.pad * 16 + (a.cls_ph >= 0 ? 1 + a.cls_ph * 2 + a.cls_pw : 0);
+  const TuneKey key(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
                     a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y));
   auto it = g_tuned.find(key);
   if (it == g_tuned.end()) {
@@ -538,7 +568,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       // in-place accumulation (dgrad into an existing gradient): re-running it
       // would add twice — use the heuristic now; the first-writer launch of the
       // same problem tunes it
-      const TuneKey k2(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, a.pad,
+      const TuneKey k2(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
                        a.stats != nullptr, false);
       auto it2 = g_tuned.find(k2);
       if (it2 == g_tuned.end()) return launch_with(a, mode, pick_cfg(a.M, a.Cout), s, m_tiles_out);

@@ -426,6 +426,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.cfg = a.dma = -1;
+  a.cls_ph = a.cls_pw = -1;
   a.x = (const bf16_t*)m->T(L.d.src);
   a.w = m->wpack + L.wpack_off;
   a.y = (bf16_t*)m->T(L.d.dst);

@@ -214,6 +214,7 @@ static void fill_conv(ConvArgs& a, const bf16_t* x, const bf16_t* w, bf16_t* y, 
                       int Cin, int Ho, int Wo, int Cout, int k, int stride, int pad, int K) {
   memset(&a, 0, sizeof a);
   a.cfg = a.dma = -1;
+  a.cls_ph = a.cls_pw = -1;
   a.x = x; a.w = w; a.y = y;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   a.kh = a.kw = k; a.stride = stride; a.pad = pad;
@@ -365,8 +366,38 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           ConvArgs a;
           fill_conv(a, dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), n, o.h, o.w, C, in.h, in.w,
                     L.d.cin, L.d.k, L.d.stride, L.d.pad, L.d.k * L.d.k * C);
-          a.res = has_grad[L.d.src] ? (const bf16_t*)t->G(L.d.src) : nullptr;
-          K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
+          const bool accumulate = has_grad[L.d.src] != 0;
+          a.res = accumulate ? (const bf16_t*)t->G(L.d.src) : nullptr;
+          if (L.d.stride == 1) {
+            K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
+          } else if (L.d.stride == 2) {
+            // one launch per output parity class; a class that no tap can reach
+            // (1x1 stride 2: three of four) is all zeros
+            bool need_zero = false;
+            for (int cl = 0; cl < 4; ++cl) {
+              const int ph = cl >> 1, pw = cl & 1;
+              const int nr = (L.d.k - ((ph + L.d.pad) & 1) + 1) / 2, ns = (L.d.k - ((pw + L.d.pad) & 1) + 1) / 2;
+              if (nr * ns == 0 && (in.h - ph + 1) / 2 > 0 && (in.w - pw + 1) / 2 > 0) need_zero = true;
+            }
+            if (need_zero && !accumulate)
+              HIP_TRY(hipMemsetAsync(t->G(L.d.src), 0, (size_t)n * in.h * in.w * L.d.cin * 2, s));
+            for (int cl = 0; cl < 4; ++cl) {
+              const int ph = cl >> 1, pw = cl & 1;
+              const int r0 = (ph + L.d.pad) & 1, s0 = (pw + L.d.pad) & 1;
+              const int nr = r0 < L.d.k ? (L.d.k - r0 + 1) / 2 : 0, ns = s0 < L.d.k ? (L.d.k - s0 + 1) / 2 : 0;
+              const int h2 = (in.h - ph + 1) / 2, w2 = (in.w - pw + 1) / 2;
+              if (nr * ns == 0 || h2 <= 0 || w2 <= 0) continue;
+              ConvArgs c = a;
+              c.cls_ph = ph; c.cls_pw = pw;
+              c.oH = in.h; c.oW = in.w;
+              c.Ho = h2; c.Wo = w2;
+              c.M = n * h2 * w2;
+              c.kt_count = nr * ns * (C / 64);
+              K_TRY(spk_conv_launch(c, CONV_MODE_DGRAD, s, nullptr), "conv dgrad (parity class)");
+            }
+          } else {
+            return tfail(SPK_ERR_UNSUPPORTED, "conv stride must be 1 or 2 on the training path");
+          }
           mark(m, PH_CONV_DGRAD);
           has_grad[L.d.src] = 1;
         }
