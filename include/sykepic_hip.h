@@ -119,7 +119,9 @@ int spk_model_set_param_group(spk_model* m, const char* key, int group);
  * accumulation either way. Training always runs bf16. */
 int spk_model_set_infer_dtype(spk_model* m, int bf16);
 /* Precision knobs of the fp16 eval path (defaults: split_weights = 1,
- * precise_residual = 0).  split_weights: every conv weight is carried as
+ * precise_residual = 0).  split_weights = 2 splits only the convs that write
+ * the residual trunk (stem, block-closing convs, downsample branches).
+ * split_weights = 1: every conv weight is carried as
  * hi + lo fp16 halves and both products are accumulated (2x MFMA work, weight
  * rounding error ~2^-22) — weight rounding is the dominant logit error at
  * 16-bit storage.  precise_residual: shortcut tensors keep their fp16

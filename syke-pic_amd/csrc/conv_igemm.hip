@@ -554,6 +554,14 @@ bool autotune_on() {
 int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_out) {
   if (a_in.K % BK || a_in.Cout % 64) return -2;
   if (mode == CONV_MODE_DGRAD && a_in.stride != 1 && a_in.cls_ph < 0) return -2;  // stride 2 goes by parity class
+  if (mode == CONV_MODE_STEM) {
+    // dedicated weights-resident kernel (conv_stem.hip); SPK_STEM_GENERIC=1 forces the implicit GEMM
+    static const bool generic = getenv("SPK_STEM_GENERIC") && atoi(getenv("SPK_STEM_GENERIC"));
+    if (!generic) {
+      const int r = spk_conv_stem_launch(a_in, s, m_tiles_out);
+      if (r != -2) return r;
+    }
+  }
   ConvArgs a = a_in;
   if (env_cfg() >= 0 || !autotune_on() || a.cfg >= 0) {
     const int cfg = a.cfg >= 0 ? a.cfg : (env_cfg() >= 0 ? env_cfg() : pick_cfg(a.M, a.Cout));

@@ -1,0 +1,230 @@
+// 7x7 stride-2 stem convolution (Cin <= 4 -> 64) for gfx950: persistent blocks,
+// weights resident in LDS, input patch staged once per 16x16 output tile.
+//
+// The first layer of every torchvision ResNet the reference instantiates
+// (`base.0`, reached through `net(x)`: sykepic/compute/probability.py:189,
+// sykepic/train/train.py:240).  As an implicit GEMM it has K = 147 (padded to
+// 256) and every input pixel is fetched by ~12 output positions, so the generic
+// kernel is bound by L1/L2 gather traffic (measured 1.9 TB/s algorithmic, 2.6x
+// off the HBM floor).  Here each input pixel crosses L2 once:
+//   * the block keeps all weights ([64][8 rows][8 taps][4 ch], 32 KB; 64 KB with
+//     the hi/lo split) in LDS for its whole life and walks a list of output tiles;
+//   * per tile the 37 x 40-pixel input patch (11.8 KB, NHWC4) is loaded with
+//     coalesced 16-B buffer loads (borders = buffer range check -> zeros),
+//     double buffered against the MFMAs of the previous tile;
+//   * MFMA A fragments are read STRAIGHT from the patch: K step r is filter row
+//     r, the lane's 16-B chunk is the pixel pair (2*ox-4+2q, +1) of input row
+//     2*oy-3+r — consecutive lanes are 16 B apart, conflict-free;
+//   * B fragments come from the resident weights (512-B rows, 16-B chunk index
+//     XOR-swizzled with the cout so 16 couts hit 16 slots).
+// Epilogue as in conv_igemm.hip: per-wave LDS staging, BN scale/shift (eval) or
+// raw + per-channel sum / sum-of-squares partials (train), ReLU, 16-bit rows.
+#include "spk_common.h"
+
+namespace {
+
+constexpr int TILE = 16;                 // output tile edge (pixels)
+constexpr int PH = 2 * TILE + 5;         // 37 input rows
+constexpr int PWP = TILE + 4;            // 20 pixel pairs per patch row (40 pixels)
+constexpr int PATCH_BYTES = PH * PWP * 16;
+constexpr int W_ROW_BYTES = 512;         // 256 k-elements per cout
+
+template <int DT, int SPLITW>
+__global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
+  constexpr int NW = SPLITW ? 2 : 1;
+  constexpr int W_BYTES = 64 * W_ROW_BYTES;
+  constexpr int EPI_LD = 68;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const sW = smem;                          // [NW][64][512 B]
+  unsigned char* const sP = smem + NW * W_BYTES;           // [2][PATCH_BYTES]
+  float* const sE = (float*)(sP + 2 * PATCH_BYTES);        // [4 waves][16][EPI_LD]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fq = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+
+  // ---- weights -> LDS, once ----
+  for (int c = tid; c < NW * 64 * 32; c += 256) {
+    const int ch = c & 31, row = (c >> 5) & 63, half = c >> 11;
+    const u32x4_t v = *(const u32x4_t*)(a.w + ((size_t)(half * 64 + row) * 256 + ch * 8));
+    *(u32x4_t*)(sW + half * W_BYTES + row * W_ROW_BYTES + ((ch ^ (row & 15)) << 4)) = v;
+  }
+
+  // ---- per-thread patch chunks (PH*PWP = 740 chunks of 16 B, 3 per thread) ----
+  constexpr int P_IT = (PH * PWP + 255) / 256;
+  u32x4_t rp[P_IT];
+  auto issue_patch = [&](int tile) {
+    const int img = tile / (tiles_x * tiles_y);
+    const int rem = tile - img * tiles_x * tiles_y;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const int iy0 = ty * TILE * 2 - 3, ix0 = tx * TILE * 2 - 4;
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int c = tid + i * 256;
+      const int pr = c / PWP, pp = c - pr * PWP;
+      const int iy = iy0 + pr, ix = ix0 + 2 * pp;
+      const bool ok = c < PH * PWP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const unsigned off = ok ? (unsigned)((((img * a.H + iy) * a.W) + ix) * 8) : 0x80000000u;
+      rp[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    }
+  };
+  auto store_patch = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int c = tid + i * 256;
+      if (c < PH * PWP) *(u32x4_t*)(sP + buf * PATCH_BYTES + c * 16) = rp[i];
+    }
+  };
+
+  // epilogue constants (8 lanes per output pixel, 8 channels each)
+  const int ecol = (lane & 7) * 8, erow = lane >> 3;
+  float sc[8], bi[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = a.scale ? a.scale[ecol + j] : 1.f;
+    bi[j] = a.bias ? a.bias[ecol + j] : 0.f;
+    s1[j] = s2[j] = 0.f;
+  }
+  float* const epi = sE + wave * (16 * EPI_LD);
+
+  int tile = blockIdx.x;
+  int buf = 0;
+  if (tile < n_tiles) {
+    issue_patch(tile);
+    store_patch(0);
+  }
+  __syncthreads();
+  for (; tile < n_tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < n_tiles) issue_patch(next);
+
+    const int img = tile / (tiles_x * tiles_y);
+    const int rem = tile - img * tiles_x * tiles_y;
+    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+    const unsigned char* patch = sP + buf * PATCH_BYTES;
+
+    // wave w: output rows 4w..4w+3 of the tile (one 16-pixel MFMA row tile each), all 64 couts
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      u32x4_t fa[4], fb[4], fl[SPLITW ? 4 : 1];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = wave * 4 + i;
+        fa[i] = *(const u32x4_t*)(patch + ((2 * oy + r) * PWP + frow + fq) * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = j * 16 + frow;
+        fb[j] = *(const u32x4_t*)(sW + n * W_ROW_BYTES + (((r * 4 + fq) ^ (n & 15)) << 4));
+        if (SPLITW) fl[j] = *(const u32x4_t*)(sW + W_BYTES + n * W_ROW_BYTES + (((r * 4 + fq) ^ (n & 15)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
+          if (SPLITW) acc[i][j] = mfma16<DT>(fa[i], fl[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: one output row (16 pixels x 64 couts) per i ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) epi[(fq * 4 + rr) * EPI_LD + j * 16 + frow] = acc[i][j][rr];
+      __builtin_amdgcn_wave_barrier();
+      const int oy = ty * TILE + wave * 4 + i;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int px = erow + p * 8;
+        const int ox = tx * TILE + px;
+        const f32x4_t v0 = *(const f32x4_t*)(epi + px * EPI_LD + ecol);
+        const f32x4_t v1 = *(const f32x4_t*)(epi + px * EPI_LD + ecol + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        if (oy < a.Ho && ox < a.Wo) {
+          if (a.stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] = v[j] * sc[j] + bi[j];
+            if (a.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+          u32x4_t ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = pack2<DT>(v[2 * j], v[2 * j + 1]);
+          *(u32x4_t*)(a.y + (((size_t)img * a.Ho + oy) * a.Wo + ox) * 64 + ecol) = ov;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    if (next < n_tiles) store_patch(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (a.stats) {
+    // per-channel partials of everything this block produced: lanes with equal
+    // ecol (stride 8), then the 4 waves, fixed order
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      for (int d = 8; d < 64; d <<= 1) {
+        s1[j] += __shfl_xor(s1[j], d);
+        s2[j] += __shfl_xor(s2[j], d);
+      }
+    float* red = sE;  // [4][2][64]
+    __syncthreads();
+    if (erow == 0) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wave * 2 + 0) * 64 + ecol + j] = s1[j];
+        red[(wave * 2 + 1) * 64 + ecol + j] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const float t = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+      a.stats[(size_t)blockIdx.x * 128 + tid] = t;  // [block][2][64]
+    }
+  }
+}
+
+template <int DT, int SPLITW>
+int launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
+  const int tiles_x = (a.Wo + TILE - 1) / TILE, tiles_y = (a.Ho + TILE - 1) / TILE;
+  const int n_tiles = a.N * tiles_x * tiles_y;
+  const size_t lds = (SPLITW ? 2 : 1) * 64 * W_ROW_BYTES + 2 * PATCH_BYTES + 4 * 16 * 68 * 4;
+  int grid = 256 * 2;  // 2 blocks per CU fit (74 / 107 KB of LDS)
+  if (SPLITW) grid = 256;
+  if (grid > n_tiles) grid = n_tiles;
+  auto k = conv_stem_kernel<DT, SPLITW>;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  if (m_tiles_out) *m_tiles_out = grid;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+// Stem forward (7x7/2 pad 3, Cout = 64, NHWC4 input).  Returns -2 when the
+// problem is not this shape (the caller then uses the generic kernel).
+int spk_conv_stem_launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
+  if (a.Cout != 64 || a.kh != 7 || a.stride != 2 || a.pad != 3 || a.res) return -2;
+  if (a.dt == DT_F16) return a.splitw ? launch<DT_F16, 1>(a, s, m_tiles_out) : launch<DT_F16, 0>(a, s, m_tiles_out);
+  return launch<DT_BF16, 0>(a, s, m_tiles_out);
+}

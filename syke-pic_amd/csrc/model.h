@@ -33,6 +33,7 @@ struct Layer {
   int p_w = -1, p_g = -1, p_b = -1, p_mean = -1, p_var = -1, p_nbt = -1;
   size_t wpack_off = 0, sb_off = 0;
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
+  bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
 };
 
 struct TrainState;
@@ -54,7 +55,7 @@ struct spk_model {
   int infer_dt = DT_F16;       // 16-bit storage type of the eval path
   int packed_dt = -1;          // dtype the packed weights currently hold
   int packed_split = -1;
-  bool splitw = true;          // eval: hi+lo 16-bit weights (2x MFMA, ~fp32-exact weights)
+  int splitw = 1;              // eval: hi+lo fp16 weights. 0 none, 1 every conv (default), 2 trunk writers only
   int act_dt = DT_F16;         // dtype of the activations now in the arena
 
   // activations of one (n,h,w) plan

@@ -113,6 +113,15 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       L.kpad = stem ? 256 : L.d.k * L.d.k * L.d.cin;
     }
   }
+  // Layers whose rounding errors enter the residual trunk undamped: the stem,
+  // every block-closing conv (it has a shortcut operand) and every conv whose
+  // output some other layer adds as a shortcut (downsample branches).
+  for (Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV) continue;
+    if (L.mode == CONV_MODE_STEM || L.d.res >= 0) L.trunk_writer = true;
+    for (const Layer& Q : m->layers)
+      if (Q.d.kind == SPK_OP_CONV && Q.d.res == L.d.dst) L.trunk_writer = true;
+  }
   for (int oi : order) {
     Layer& L = m->layers[oi];
     const std::string nm = L.d.name, bn = L.d.bn;
@@ -301,7 +310,7 @@ extern "C" int spk_model_set_infer_dtype(spk_model* m, int bf16) {
 
 extern "C" int spk_model_set_precision(spk_model* m, int split_weights, int precise_residual) {
   if (!m) return fail(SPK_ERR_ARG, "null model");
-  m->splitw = split_weights != 0;
+  m->splitw = split_weights < 0 ? 0 : (split_weights > 2 ? 2 : split_weights);
   if ((precise_residual != 0) != m->precise_res) {
     m->precise_res = precise_residual != 0;
     m->cap_n = 0;  // re-plan: remainder tensors appear / disappear
@@ -318,6 +327,12 @@ extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
 // ---------------------------------------------------------------------------
 // commit: fold eval-BN into per-channel scale/bias, pack bf16 weights
 // ---------------------------------------------------------------------------
+// does this conv run with hi/lo split weights in the eval path?
+static int layer_split(const spk_model* m, const Layer& L) {
+  if (m->infer_dt != DT_F16 || m->splitw == 0) return 0;
+  return m->splitw == 1 || L.trunk_writer ? 1 : 0;
+}
+
 int spk_commit(spk_model* m) {
   if (!m->dirty && m->packed_dt == m->infer_dt && m->packed_split == (int)m->splitw) return SPK_OK;
   for (Layer& L : m->layers) {
@@ -328,7 +343,7 @@ int spk_commit(spk_model* m) {
                            L.d.cout, m->stream))
       return fail(SPK_ERR_HIP, "bn_fold launch failed");
     if (spk_launch_pack_weights(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
-                                L.mode, m->infer_dt, m->splitw && m->infer_dt == DT_F16, m->stream))
+                                L.mode, m->infer_dt, layer_split(m, L), m->stream))
       return fail(SPK_ERR_HIP, "pack_weights launch failed");
   }
   m->packed_dt = m->infer_dt;
@@ -442,7 +457,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   a.K = L.kpad;
   a.relu = L.d.relu;
   a.dt = m->infer_dt;
-  a.splitw = m->splitw && m->infer_dt == DT_F16;
+  a.splitw = layer_split(m, L);
   a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
   a.w_bytes = (unsigned)((size_t)L.d.cout * L.kpad * 2 * (a.splitw ? 2 : 1));
   if (spk_conv_launch(a, L.mode, m->stream, nullptr))

@@ -87,6 +87,7 @@ struct ConvArgs {
 // (needed to size/finalize the stats partials)
 int spk_conv_launch(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out);
 int spk_conv_m_tiles(int M, int Cout, int mode);
+int spk_conv_stem_launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out);  // conv_stem.hip
 const char* spk_conv_last_config();
 
 // ---------------------------------------------------------------------------

@@ -156,11 +156,10 @@ class HipNet:
         self._build_views()
         self._stats = None
 
-    def set_precision(self, split_weights=True, precise_residual=False, bf16=False):
+    def set_precision(self, split_weights=1, precise_residual=False, bf16=False):
         """Eval-path precision knobs (see include/sykepic_hip.h)."""
         lib.check(self._lib.spk_model_set_infer_dtype(self._h, int(bool(bf16))))
-        lib.check(self._lib.spk_model_set_precision(self._h, int(bool(split_weights)),
-                                                    int(bool(precise_residual))))
+        lib.check(self._lib.spk_model_set_precision(self._h, int(split_weights), int(bool(precise_residual))))
         return self
 
     # ---- lifetime ----

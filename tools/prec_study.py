@@ -20,7 +20,8 @@ for network, hw in (("resnet18", 224), ("resnet50", 224)):
     order = np.argsort(gold[f"{tag}_rois_in"])
     for name, kw in (("bf16", dict(bf16=True, split_weights=False)), ("f16", dict(split_weights=False)),
                      ("f16+res_lo", dict(split_weights=False, precise_residual=True)),
-                     ("f16+w_lo", dict(split_weights=True)), ("f16+w_lo+res_lo", dict(split_weights=True, precise_residual=True))):
+                     ("f16+w_lo(trunk)", dict(split_weights=2)),
+                     ("f16+w_lo", dict(split_weights=1)), ("f16+w_lo+res_lo", dict(split_weights=1, precise_residual=True))):
         net.set_precision(**kw)
         p = net.probabilities(x).cpu().numpy()[order]
         z = net.forward(x).cpu().numpy()
