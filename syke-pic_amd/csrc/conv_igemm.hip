@@ -31,7 +31,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvArgs a, int m_tiles,
                                                                             int n_tiles) {
   constexpr int NTHREADS = WARPS_M * WARPS_N * 64;
@@ -67,12 +67,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WARPS_N, wn = wave % WARPS_N;
 
-  // XCD-aware, bijective block -> tile map
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int nt_idx = swz % n_tiles, mt_idx = swz / n_tiles;
-  const int m0 = mt_idx * BM, n0 = nt_idx * BN;
+  // Work items: tile w of m_tiles*n_tiles, w = blockIdx.x, += gridDim.x (the
+  // register-staged flavour may run persistent: the first loads of the next
+  // tile are issued before the epilogue of the current one).  XCD-aware,
+  // bijective item -> tile map: items w and w+8 share an XCD and take
+  // neighbouring tiles, N tiles of one M tile adjacent.
+  const int ntiles = m_tiles * n_tiles;
+  int m0 = 0, n0 = 0, mt_idx = 0, nt_idx = 0;
 
   const __amdgpu_buffer_rsrc_t rx =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
@@ -85,53 +86,63 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   // row in slot l&7, so that lane must FETCH the chunk whose slot that is
   const int chunk = DMA ? ((tid & 7) ^ ((srow >> 1) & 7)) : (tid & 7);
   int a_base[A_ITERS], a_h0[A_ITERS], a_w0[A_ITERS];
-  const int HoWo = a.Ho * a.Wo;
-#pragma unroll
-  for (int i = 0; i < A_ITERS; ++i) {
-    const int m = m0 + srow + i * ROWS_PER_PASS;
-    const int img = m / HoWo;
-    const int rem = m - img * HoWo;
-    const int ho = rem / a.Wo;
-    const int wo = rem - ho * a.Wo;
-    if (MODE == CONV_MODE_STEM) {
-      // K row = one filter row: 8 taps x 4 channels starting at pixel 2*wo-4
-      const int h0 = ho * 2 - 3, p0 = wo * 2 - 4;
-      a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
-      a_w0[i] = p0;
-      a_base[i] = ((img * a.H + h0) * a.W + p0) * 4;
-    } else if (MODE == CONV_MODE_DGRAD) {
-      // rows are pixels of the forward conv's INPUT; the "input" tensor is dy.
-      // tap (r,s) reads dy[(h+pad-r)/stride][(w+pad-s)/stride] when divisible.
-      // stride 2 is decomposed by output parity (cls_ph, cls_pw): the GEMM rows
-      // of one launch are the pixels h = 2*ho + ph, w = 2*wo + pw, and only the
-      // taps r = (ph+pad)&1, +2, ... can hit them — no MFMA work on taps that
-      // never divide.
-      const int hh = cls ? 2 * ho + a.cls_ph : ho, ww = cls ? 2 * wo + a.cls_pw : wo;
-      a_h0[i] = (m < a.M) ? hh + a.pad : -(1 << 20);
-      a_w0[i] = ww + a.pad;
-      a_base[i] = img * a.H * a.W * a.Cin + chunk * 8;
-    } else {
-      const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
-      a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
-      a_w0[i] = w0;
-      a_base[i] = ((img * a.H + h0) * a.W + w0) * a.Cin + chunk * 8;
-    }
-  }
   int b_off[B_ITERS];
-#pragma unroll
-  for (int i = 0; i < B_ITERS; ++i) {
-    const int rr = srow + i * ROWS_PER_PASS;  // [0, NB*BN): hi rows then lo rows
-    const int half = rr / BN;
-    b_off[i] = ((half * a.Cout + n0 + rr - half * BN) * a.K + chunk * 8) * 2;
-  }
-
+  const int HoWo = a.Ho * a.Wo;
   const int KT = a.kt_count > 0 ? a.kt_count : a.K / BK;
-
   // scalar walk over (tap row r, tap col s, channel block c0) for generic mode
   const int r_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_ph + a.pad) & 1) : 0;
   const int s_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_pw + a.pad) & 1) : 0;
   const int tap_step = (MODE == CONV_MODE_DGRAD && cls) ? 2 : 1;
   int kr = r_first, ks_ = s_first, kc0 = 0;
+
+  auto set_tile = [&](int w) {
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = w & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (w >> 3);
+    nt_idx = swz % n_tiles;
+    mt_idx = swz / n_tiles;
+    m0 = mt_idx * BM;
+    n0 = nt_idx * BN;
+    kr = r_first; ks_ = s_first; kc0 = 0;
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) {
+      const int m = m0 + srow + i * ROWS_PER_PASS;
+      const int img = m / HoWo;
+      const int rem = m - img * HoWo;
+      const int ho = rem / a.Wo;
+      const int wo = rem - ho * a.Wo;
+      if (MODE == CONV_MODE_STEM) {
+        // K row = one filter row: 8 taps x 4 channels starting at pixel 2*wo-4
+        const int h0 = ho * 2 - 3, p0 = wo * 2 - 4;
+        a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
+        a_w0[i] = p0;
+        a_base[i] = ((img * a.H + h0) * a.W + p0) * 4;
+      } else if (MODE == CONV_MODE_DGRAD) {
+        // rows are pixels of the forward conv's INPUT; the "input" tensor is dy.
+        // tap (r,s) reads dy[(h+pad-r)/stride][(w+pad-s)/stride] when divisible.
+        // stride 2 is decomposed by output parity (cls_ph, cls_pw): the GEMM rows
+        // of one launch are the pixels h = 2*ho + ph, w = 2*wo + pw, and only the
+        // taps r = (ph+pad)&1, +2, ... can hit them — no MFMA work on taps that
+        // never divide.
+        const int hh = cls ? 2 * ho + a.cls_ph : ho, ww = cls ? 2 * wo + a.cls_pw : wo;
+        a_h0[i] = (m < a.M) ? hh + a.pad : -(1 << 20);
+        a_w0[i] = ww + a.pad;
+        a_base[i] = img * a.H * a.W * a.Cin + chunk * 8;
+      } else {
+        const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
+        a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
+        a_w0[i] = w0;
+        a_base[i] = ((img * a.H + h0) * a.W + w0) * a.Cin + chunk * 8;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+      const int rr = srow + i * ROWS_PER_PASS;  // [0, NB*BN): hi rows then lo rows
+      const int half = rr / BN;
+      b_off[i] = ((half * a.Cout + n0 + rr - half * BN) * a.K + chunk * 8) * 2;
+    }
+  };
+  int work = blockIdx.x;
+  set_tile(work);
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   int dma_stage = 0;  // LDS stage the next issue_loads() call fills (DMA mode)
@@ -210,10 +221,6 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   };
 
   f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fq = lane >> 4;
 
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   // tile kt is multiplied out of LDS and written to the other LDS stage after
   // the MFMAs.  (A variant with two tiles in flight in two register sets was
   // measured 10-35 % SLOWER on every ResNet-50 layer as compiled by hipcc 7.2
-  // and was removed; deeper pipelining is left to an LDS-DMA main loop.)
+  // and was removed; deeper pipelining is the job of the LDS-DMA flavour.)
   u32x4_t ra0[A_ITERS], rb0[B_ITERS];
   if (DMA) {
 #pragma unroll
@@ -274,8 +281,6 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
     return ((size_t)img * a.oH + 2 * ho + a.cls_ph) * a.oW + 2 * wo + a.cls_pw;
   };
 
-  // epilogue operand prefetch: the shortcut tensor is independent of the K
-  // loop, so its loads are issued now and land under the MFMAs
   constexpr int EPI_LD = WN + 4;          // floats per staged row (pad: conflict-free writes)
   constexpr int LPR = WN / 8;             // lanes per output row (8 columns each)
   constexpr int RPP = 64 / LPR;           // rows per pass
@@ -283,20 +288,36 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   static_assert(PASSES >= 1, "WN too large");
   const int ecol = (lane % LPR) * 8;
   const int erow = lane / LPR;
-  const int gcol = n0 + wn * WN + ecol;
   constexpr bool PREFETCH_RES = MT * PASSES <= 8;
-  u32x4_t rres[PREFETCH_RES ? MT : 1][PREFETCH_RES ? PASSES : 1];
-  if (PREFETCH_RES && a.res) {
+  float* const epi = (float*)smem + wave * (16 * EPI_LD);
+  static_assert(WARPS_M * WARPS_N * 16 * EPI_LD * 4 <= (A_BYTES + B_BYTES), "epilogue LDS");
+
+  for (;;) {
+    // the epilogue of THIS tile runs after the staging coordinates have moved on
+    // to the next tile: keep its origin
+    const int em0 = m0, emt = mt_idx, en0 = n0;
+    const int gcol = en0 + wn * WN + ecol;
+    const int next = work + (int)gridDim.x;
+    const bool has_next = PERSIST && !DMA && next < ntiles;
+
+    // epilogue operand prefetch: the shortcut tensor is independent of the K
+    // loop, so its loads are issued now and land under the MFMAs
+    u32x4_t rres[PREFETCH_RES ? MT : 1][PREFETCH_RES ? PASSES : 1];
+    if (PREFETCH_RES && a.res) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+          const int m = em0 + wm * WM + i * 16 + erow + p * RPP;
+          rres[i][p] = m < a.M ? *(const u32x4_t*)(a.res + out_pixel(m) * a.Cout + gcol) : u32x4_t{0, 0, 0, 0};
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        const int m = m0 + wm * WM + i * 16 + erow + p * RPP;
-        rres[i][p] = m < a.M ? *(const u32x4_t*)(a.res + out_pixel(m) * a.Cout + gcol) : u32x4_t{0, 0, 0, 0};
-      }
-  }
+      for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (DMA) {
+    if (DMA) {
     // One barrier per K step.  At the top of step kt the wave waits until its own
     // pieces of tile kt have landed (all but the STAGES-2 younger tiles' DMAs
     // retired), the barrier then (a) publishes every wave's pieces of tile kt and
@@ -314,33 +335,38 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
       cs = cs + 1 == STAGES ? 0 : cs + 1;
     }
     __builtin_amdgcn_s_barrier();  // tile buffers are reused by the epilogue
-  } else {
-    store_lds(0, ra0, rb0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < KT) issue_loads(kt + 1, ra0, rb0);
-      compute(buf);
-      if (kt + 1 < KT) store_lds(buf ^ 1, ra0, rb0);
+    } else {
+      store_lds(0, ra0, rb0);
       __syncthreads();
+      for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) {
+          issue_loads(kt + 1, ra0, rb0);
+        } else if (has_next) {
+          // last K step: start the next tile's first loads; they fly under this
+          // tile's MFMAs and its whole epilogue
+          set_tile(next);
+          issue_loads(0, ra0, rb0);
+        }
+        compute(buf);
+        if (kt + 1 < KT) store_lds(buf ^ 1, ra0, rb0);
+        __syncthreads();
+      }
     }
-  }
 
-  // ---- epilogue: acc -> LDS (fp32, per-wave region) -> fused pointwise -> 16-bit rows ----
-  // Each wave stages through its OWN LDS region: LDS operations of one wave
-  // execute in order, so no workgroup barrier is needed inside the loop (the
-  // K loop's final barrier already retired every read of the tile buffers).
-  float* const epi = (float*)smem + wave * (16 * EPI_LD);
-  static_assert(WARPS_M * WARPS_N * 16 * EPI_LD * 4 <= (A_BYTES + B_BYTES), "epilogue LDS");
-  float sc[8], bi[8];
+    // ---- epilogue: acc -> LDS (fp32, per-wave region) -> fused pointwise -> 16-bit rows ----
+    // Each wave stages through its OWN LDS region: LDS operations of one wave
+    // execute in order, so no workgroup barrier is needed inside the loop (the
+    // K loop's final barrier already retired every read of the tile buffers).
+    float sc[8], bi[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    sc[j] = a.scale ? a.scale[gcol + j] : 1.f;
-    bi[j] = a.bias ? a.bias[gcol + j] : 0.f;
-  }
-  float s1[8], s2[8];
+    for (int j = 0; j < 8; ++j) {
+      sc[j] = a.scale ? a.scale[gcol + j] : 1.f;
+      bi[j] = a.bias ? a.bias[gcol + j] : 0.f;
+    }
+    float s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int row = erow + p * RPP;
-      const int m = m0 + wm * WM + i * 16 + row;
+      const int m = em0 + wm * WM + i * 16 + row;
       const f32x4_t v0 = *(const f32x4_t*)(epi + row * EPI_LD + ecol);
       const f32x4_t v1 = *(const f32x4_t*)(epi + row * EPI_LD + ecol + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -426,8 +452,13 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
 #pragma unroll
       for (int w = 0; w < WARPS_M; ++w) t += red[(w * 2) * BN + c];
       const int which = c / BN, col = c - which * BN;
-      a.stats[((size_t)mt_idx * 2 + which) * a.Cout + n0 + col] = t;
+      a.stats[((size_t)emt * 2 + which) * a.Cout + en0 + col] = t;
     }
+  }
+
+    if (!has_next) break;
+    work = next;
+    __syncthreads();  // staging regions alias the tile buffers the next tile is about to fill
   }
 }
 
@@ -443,20 +474,27 @@ bool use_dma() {
 
 thread_local char g_cfg_name[64] = "";
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST = 0>
 int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   const size_t stage = (size_t)(BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES;
   const int stages = !DMA ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
   const size_t lds_full = stages * stage;
   const int kt = a.K / BK;
   const size_t lds = (kt < stages ? kt : stages) * stage;
-  auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA>;
+  auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA, PERSIST>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(m_tiles * n_tiles), dim3(WARPS_M * WARPS_N * 64), lds, s, a, m_tiles, n_tiles);
+  int grid = m_tiles * n_tiles;
+  if (PERSIST) {
+    // persistent: as many blocks as stay resident (LDS-limited, at most 4 per CU)
+    int bpc = (int)(163840 / (lds ? lds : 1));
+    bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
+    if (grid > 256 * bpc) grid = 256 * bpc;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WARPS_M * WARPS_N * 64), lds, s, a, m_tiles, n_tiles);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -468,7 +506,8 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
   snprintf(g_cfg_name, sizeof g_cfg_name, "%dx%d%s", BM, BN, a.splitw ? "+wlo" : "");
 #define SPK_GO(MODE, DT, SW)                                                                   \
   do {                                                                                         \
-    if (a.dma >= 0 ? a.dma != 0 : use_dma()) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 1>(a, s, m_tiles, n_tiles); \
+    if (a.dma >= 0 ? a.dma == 1 : use_dma()) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 1>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 2) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0, 1>(a, s, m_tiles, n_tiles); \
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0>(a, s, m_tiles, n_tiles);      \
   } while (0)
   if (mode == CONV_MODE_STEM) {
@@ -595,7 +634,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
-      for (int dma = 0; dma < 2; ++dma) {
+      for (int dma = 0; dma < 3; ++dma) {  // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
         (void)hipEventRecord(e0, s);

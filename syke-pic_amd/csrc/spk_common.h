@@ -76,7 +76,7 @@ struct ConvArgs {
   int relu;
   int dt;               // DT_BF16 / DT_F16
   int splitw;           // w holds [2][Cout][K]: hi then lo halves (f16 eval only)
-  int cfg, dma;         // tile config / main-loop flavour; -1 = autotuned or heuristic
+  int cfg, dma;         // tile config / main loop (0 register-staged, 1 LDS-DMA, 2 register-staged persistent); -1 = autotuned or heuristic
   int cls_ph, cls_pw;   // dgrad of a stride-2 conv: output parity class of this launch (-1: none)
   int oH, oW;           // ... and the full output height/width (Ho/Wo are then the class grid)
   int kt_count;         // K steps of this launch when not K/64 (parity classes use a tap subset)
