@@ -171,6 +171,22 @@ int spk_model_read_activation(spk_model* m, int tensor_id, int n, float* host, i
  * spk_train_forward_backward, float32 NCHW like spk_model_read_activation. */
 int spk_model_read_activation_grad(spk_model* m, int tensor_id, int n, float* host, int64_t numel);
 
+/* --- ROI preprocessing straight from the .roi blob ---
+ * One ROI of an IFCB sample: byte offset into the .roi blob, width, height
+ * (columns 17/15/16 of the .adc line, sykepic/utils/ifcb.py:100-110). */
+typedef struct {
+  int64_t offset;
+  int32_t width, height;
+} spk_roi;
+/* blob -> [n, out_h, out_w, 3] uint8 (mode/black/white border, aspect-preserving
+ * OpenCV-style fixed-point bilinear resize), replacing the PNG round trip +
+ * ImageDataset + Compose of the reference (sykepic/utils/ifcb.py:76-118,
+ * sykepic/train/data.py:210-231, sykepic/train/image.py:25-56).  border: -1 =
+ * the ROI's modal grey level, else a grey value 0..255.  The result feeds
+ * spk_forward_infer(layout NHWC, dtype U8).  All pointers are device memory. */
+int spk_preprocess_rois(const unsigned char* blob_dev, int64_t blob_bytes, const spk_roi* rois_dev,
+                        int n, int out_h, int out_w, int border, unsigned char* out_dev, void* hip_stream);
+
 /* Per-layer timing of the last spk_forward_infer call (HIP events on the
  * model's stream); used by bench.py for the roofline line. Returns the
  * number of records written. */

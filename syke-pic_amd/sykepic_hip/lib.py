@@ -29,6 +29,10 @@ class OptimDesc(C.Structure):
     ]
 
 
+class Roi(C.Structure):
+    _fields_ = [("offset", C.c_int64), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 class LayerTime(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -67,6 +71,7 @@ SYMBOLS = {
     "spk_model_read_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "spk_model_read_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
+    "spk_preprocess_rois": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "spk_model_profile_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(LayerTime), C.c_int]),
     "spk_model_profile_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,

@@ -94,6 +94,21 @@ def process_sample(sample_path, net, params, out_dir, force=False):
             log.warning(f"{csv_path.name} already exists, skipping")
             return sample
     log.debug(f"Computing probabilities for {sample}")
+    from . import gpu_preprocess
+    if gpu_preprocess.supported(params.transform, params.img_shape[0]):
+        # .roi bytes -> GPU -> resized/bordered uint8 batches -> forward: no PNGs, no per-ROI host work
+        gs = gpu_preprocess.SampleOnGpu(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"),
+                                        params.device)
+        th, tw = params.transform.target_dims
+        code = gpu_preprocess.border_code(params.transform)
+
+        def gpu_batches():
+            for b in range(0, len(gs), params.batch_size):
+                e = min(len(gs), b + params.batch_size)
+                yield gs.batch(b, e, th, tw, code), [f"{sample}_{num:05d}.png" for num in gs.numbers[b:e]]
+        probabilities = net_pass(net, gpu_batches(), params.device)
+        probabilities_to_csv(probabilities, params.classes, csv_path)
+        return sample
     rois = ifcb.read_rois(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"))
     items = [(f"{sample}_{num:05d}.png", _as_chans(img, params.img_shape[0])) for num, img in rois]
     probabilities = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
