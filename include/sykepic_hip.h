@@ -187,6 +187,16 @@ typedef struct {
 int spk_preprocess_rois(const unsigned char* blob_dev, int64_t blob_bytes, const spk_roi* rois_dev,
                         int n, int out_h, int out_w, int border, unsigned char* out_dev, void* hip_stream);
 
+/* --- prediction from probabilities and thresholds ---
+ * row_prediction of sykepic/compute/prediction.py:49-71 for n rows at once:
+ * thresholds_dev = float[num_classes] (+inf for a class without a threshold):
+ * the highest-probability class with p >= its own threshold, classified = 1;
+ * if none, arg-max with classified = 0.  thresholds_dev == NULL: arg-max and
+ * classified = p > scalar_threshold.  pred_dev int32[n], classified_dev u8[n]. */
+int spk_predict_rows(const float* probs_dev, int n, int num_classes, const float* thresholds_dev,
+                     float scalar_threshold, int32_t* pred_dev, unsigned char* classified_dev,
+                     void* hip_stream);
+
 /* Per-layer timing of the last spk_forward_infer call (HIP events on the
  * model's stream); used by bench.py for the roofline line. Returns the
  * number of records written. */

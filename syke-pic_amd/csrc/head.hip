@@ -185,7 +185,49 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ z,
   }
 }
 
+// SURVEY.md §8f rank 2 — per-ROI prediction from probabilities and per-class
+// thresholds (reference sykepic/compute/prediction.py:49-71): the
+// highest-probability class that clears ITS OWN threshold wins (lowest index on
+// ties); if none does, arg-max with classified = 0.  thr == nullptr: scalar
+// rule, classified = p[argmax] > scalar_thr.  One wave per row.
+__global__ void predict_kernel(const float* __restrict__ p, int n, int c, const float* __restrict__ thr,
+                               float scalar_thr, int* __restrict__ pred, unsigned char* __restrict__ ok) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const float* pr = p + (size_t)row * c;
+  float best = -1.f, bestq = -1.f;
+  int arg = 0x7fffffff, argq = 0x7fffffff;
+  for (int j = lane; j < c; j += 64) {
+    const float v = pr[j];
+    if (v > best) { best = v; arg = j; }
+    if (thr && v >= thr[j] && v > bestq) { bestq = v; argq = j; }
+  }
+  for (int d = 32; d; d >>= 1) {
+    const float ob = __shfl_xor(best, d), oq = __shfl_xor(bestq, d);
+    const int oa = __shfl_xor(arg, d), oaq = __shfl_xor(argq, d);
+    if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    if (oq > bestq || (oq == bestq && oaq < argq)) { bestq = oq; argq = oaq; }
+  }
+  if (lane == 0) {
+    if (thr) {
+      const bool any = argq != 0x7fffffff;
+      pred[row] = any ? argq : arg;
+      ok[row] = any ? 1 : 0;
+    } else {
+      pred[row] = arg;
+      ok[row] = best > scalar_thr ? 1 : 0;
+    }
+  }
+}
+
 }  // namespace
+
+int spk_launch_predict(const float* p, int n, int c, const float* thr, float scalar_thr, int* pred,
+                       unsigned char* ok, hipStream_t s) {
+  hipLaunchKernelGGL(predict_kernel, dim3((n + 3) / 4), dim3(256), 0, s, p, n, c, thr, scalar_thr, pred, ok);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 int spk_launch_sgemm(const float* A, long sai, long sak, const float* B, long sbj, long sbk,
                      const float* bias, float* C, long sci, long scj, int M, int N, int K,

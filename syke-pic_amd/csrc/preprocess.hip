@@ -146,3 +146,22 @@ extern "C" int spk_preprocess_rois(const unsigned char* blob_dev, int64_t blob_b
   }
   return SPK_OK;
 }
+
+int spk_launch_predict(const float* p, int n, int c, const float* thr, float scalar_thr, int* pred,
+                       unsigned char* ok, hipStream_t s);
+
+extern "C" int spk_predict_rows(const float* probs_dev, int n, int num_classes, const float* thresholds_dev,
+                                float scalar_threshold, int32_t* pred_dev, unsigned char* classified_dev,
+                                void* stream) {
+  if (!probs_dev || !pred_dev || !classified_dev || n < 0 || num_classes <= 0) {
+    spk_set_error("spk_predict_rows: bad arguments");
+    return SPK_ERR_ARG;
+  }
+  if (n == 0) return SPK_OK;
+  if (spk_launch_predict(probs_dev, n, num_classes, thresholds_dev, scalar_threshold, pred_dev, classified_dev,
+                         (hipStream_t)stream)) {
+    spk_set_error("spk_predict_rows: launch failed");
+    return SPK_ERR_HIP;
+  }
+  return SPK_OK;
+}

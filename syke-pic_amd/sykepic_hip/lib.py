@@ -72,6 +72,7 @@ SYMBOLS = {
     "spk_model_read_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_preprocess_rois": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "spk_predict_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P]),
     "spk_model_profile_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(LayerTime), C.c_int]),
     "spk_model_profile_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,

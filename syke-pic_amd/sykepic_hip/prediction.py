@@ -67,3 +67,31 @@ def prediction_dataframe(probabilities, thresholds=0.0):
     if not df.empty:
         insert_prediction(df, thresholds)
     return df
+
+
+def predict_gpu(probs, classes, thresholds):
+    """GPU form of predict_arrays for a CUDA float32 [n, C] tensor
+    (spk_predict_rows): returns (int32 class index [n], bool classified [n])
+    tensors on the same device — fused after net_pass, no pandas apply."""
+    import ctypes as C
+
+    import torch
+
+    from . import lib
+    so = lib.load()
+    probs = probs.contiguous().float()
+    n, c = probs.shape
+    pred = torch.empty(n, dtype=torch.int32, device=probs.device)
+    ok = torch.empty(n, dtype=torch.uint8, device=probs.device)
+    if isinstance(thresholds, (int, float)):
+        thr, scalar = None, float(thresholds)
+    else:
+        thr = torch.tensor([thresholds.get(k, float("inf")) for k in classes], dtype=torch.float32,
+                           device=probs.device)
+        scalar = 0.0
+    with torch.cuda.device(probs.device):
+        stream = C.c_void_p(torch.cuda.current_stream(probs.device).cuda_stream)
+        lib.check(so.spk_predict_rows(C.c_void_p(probs.data_ptr()), n, c,
+                                      C.c_void_p(thr.data_ptr()) if thr is not None else None, scalar,
+                                      C.c_void_p(pred.data_ptr()), C.c_void_p(ok.data_ptr()), stream))
+    return pred, ok.bool()

@@ -72,3 +72,30 @@ def test_reference_fixture_and_forward(golden_dir):
     net.eval()
     xf = (x8.permute(0, 3, 1, 2).float() / 255.0).contiguous()
     assert float((net.probabilities(x8) - net.probabilities(xf)).abs().max()) < 2e-5
+
+
+def test_gpu_prediction_matches_reference_golden(golden_dir):
+    """spk_predict_rows vs the golden the reference's prediction module produced
+    and vs the host implementation on random probabilities."""
+    import json
+
+    import pandas as pd
+
+    from sykepic_hip import prediction
+    gold = json.loads((golden_dir / "prediction.json").read_text())
+    d = golden_dir / "ref_data"
+    df = pd.read_csv(d / "D20180712T065600_IFCB114.prob.csv", index_col=0)
+    classes = list(df.columns)
+    probs = torch.tensor(df.to_numpy(), dtype=torch.float32).cuda()
+    for key, want in gold.items():
+        thr = prediction.threshold_dictionary(d / key) if key.endswith(".txt") else float(key)
+        pred, ok = prediction.predict_gpu(probs, classes, thr)
+        assert [classes[i] for i in pred.tolist()] == want["prediction"]
+        assert ok.tolist() == want["classified"]
+    rng = np.random.RandomState(0)
+    p = rng.dirichlet(np.ones(50) * 0.3, size=4000).astype(np.float32)
+    thr = {c: float(t) for c, t in zip(classes, rng.uniform(0.05, 0.9, 50)) if rng.rand() < 0.8}
+    for t in (thr, 0.3, 0.0):
+        want_i, want_ok = prediction.predict_arrays(p, classes, t)
+        got_i, got_ok = prediction.predict_gpu(torch.from_numpy(p).cuda(), classes, t)
+        assert np.array_equal(got_i.cpu().numpy(), want_i) and np.array_equal(got_ok.cpu().numpy(), want_ok)

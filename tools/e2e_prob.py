@@ -1,0 +1,37 @@
+"""End-to-end `sykepic prob` throughput on a synthetic IFCB sample (disk ->
+.roi blob -> GPU preprocessing -> ResNet forward -> CSV)."""
+import sys, time, shutil, tempfile
+from collections import namedtuple
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
+import numpy as np, torch
+from sykepic_hip import arch, synth, prob
+n_roi = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+network = sys.argv[2] if len(sys.argv) > 2 else "resnet18"
+tmp = Path(tempfile.mkdtemp())
+rng = np.random.RandomState(0)
+adc, blobs, off = [], [], 0
+for i in range(n_roi):
+    h, w = int(rng.randint(20, 120)), int(rng.randint(30, 300))
+    cols = ["0"] * 24; cols[15], cols[16], cols[17] = str(w), str(h), str(off)
+    adc.append(",".join(cols)); blobs.append(rng.randint(0, 256, h * w).astype(np.uint8)); off += h * w
+raw = tmp / "raw"; raw.mkdir()
+(raw / "D20200101T000000_IFCB114.adc").write_text("\n".join(adc) + "\n")
+np.concatenate(blobs).tofile(raw / "D20200101T000000_IFCB114.roi")
+model = tmp / "model"; model.mkdir()
+g = arch.build_graph(network, 50)
+sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, model / "best_state.pth")
+(model / "class_names.txt").write_text("\n".join(f"class_{i}" for i in range(50)))
+cfg = (ROOT / "tests/golden/ref_data/config.ini").read_text().replace("network = resnet18", f"network = {network}")
+(model / "config.ini").write_text(cfg)
+Args = namedtuple("Args", "raw samples image_dir images model out batch_size num_workers force")
+for bs in (64, 512):
+    out = tmp / f"out{bs}"
+    t0 = time.perf_counter()
+    prob.call(Args(str(raw), None, None, None, str(model), out, bs, 2, True))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{network} 180x180, {n_roi} ROIs ({off/1e6:.0f} MB .roi), batch {bs}: {dt:.2f} s end to end = {n_roi/dt:.0f} ROI/s", flush=True)
+shutil.rmtree(tmp)
