@@ -50,7 +50,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   // ds_write pass.  The LDS image must be lane-linear per wave instruction
   // (8 rows x 128 B), so the bank swizzle is applied to the SOURCE chunk.
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int STAGES = !DMA ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2));
+  // DMA == 2: two stages only (half the LDS -> two blocks per CU whose phases interleave)
+  constexpr int STAGES = (!DMA || DMA == 2) ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2));
   constexpr int PER_TILE = A_ITERS + B_ITERS;  // DMA instructions per wave per tile
   static_assert(!DMA || ROWS_PER_PASS % 16 == 0, "swizzle must not depend on the pass");
 
@@ -477,7 +478,7 @@ thread_local char g_cfg_name[64] = "";
 template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST = 0>
 int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   const size_t stage = (size_t)(BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES;
-  const int stages = !DMA ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
+  const int stages = (!DMA || DMA == 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
   const size_t lds_full = stages * stage;
   const int kt = a.K / BK;
   const size_t lds = (kt < stages ? kt : stages) * stage;
@@ -508,6 +509,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
   do {                                                                                         \
     if (a.dma >= 0 ? a.dma == 1 : use_dma()) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 1>(a, s, m_tiles, n_tiles); \
     if (a.dma == 2) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0, 1>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 2>(a, s, m_tiles, n_tiles); \
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0>(a, s, m_tiles, n_tiles);      \
   } while (0)
   if (mode == CONV_MODE_STEM) {
@@ -634,7 +636,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
-      for (int dma = 0; dma < 3; ++dma) {  // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent
+      for (int dma = 0; dma < 4; ++dma) {  // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
         (void)hipEventRecord(e0, s);
