@@ -51,7 +51,12 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   // (8 rows x 128 B), so the bank swizzle is applied to the SOURCE chunk.
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   // DMA == 2: two stages only (half the LDS -> two blocks per CU whose phases interleave)
+  // DMA == 3: "staggered" flavour for 8-wave blocks, one block per CU.  Each K step is split by
+  // two barriers into a load phase (all operand fragments of the step LDS -> VGPR, the DMA of a
+  // later tile issued) and an MFMA phase; waves 4-7 run one barrier behind waves 0-3, so on
+  // every SIMD one wave issues MFMAs while its partner loads.  Needs >= 3 stages.
   constexpr int STAGES = (!DMA || DMA == 2) ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2));
+  static_assert(DMA != 3 || (STAGES >= 3 && WARPS_M * WARPS_N == 8), "staggered flavour: 8 waves, >= 3 stages");
   constexpr int PER_TILE = A_ITERS + B_ITERS;  // DMA instructions per wave per tile
   static_assert(!DMA || ROWS_PER_PASS % 16 == 0, "swizzle must not depend on the pass");
 
@@ -318,7 +323,73 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    if (DMA) {
+    if (DMA == 3) {
+      const bool g1 = wave >= 4;  // the group that runs one barrier behind
+      auto wait_tile = [&](int kt) {  // this wave's pieces of tile kt+1 have landed
+        if (kt + 1 >= KT) return;
+        if (kt + STAGES - 1 < KT)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_TILE) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      };
+      if (STAGES - 1 <= KT)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_TILE) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // tile 0 is complete
+      if (g1) __builtin_amdgcn_s_barrier();
+      int cs = 0;
+      for (int kt = 0; kt < KT; ++kt) {
+        // ---- load phase ----
+        const unsigned char* pa = sA + cs * STAGE_BYTES;
+        const unsigned char* pb = sB + cs * STAGE_BYTES;
+        u32x4_t fa[2][MT], fb[2][NT], fl[2][SPLITW ? NT : 1];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            fa[ks][i] = *(const u32x4_t*)(pa + lds_off(wm * WM + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            fb[ks][j] = *(const u32x4_t*)(pb + lds_off(wn * WN + j * 16 + frow, ks * 4 + fq));
+          if (SPLITW) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              fl[ks][j] = *(const u32x4_t*)(pb + lds_off(BN + wn * WN + j * 16 + frow, ks * 4 + fq));
+          }
+        }
+        // the stage of tile kt-1 was last read in the partner group's previous load phase
+        if (kt + STAGES - 1 < KT) issue_loads(kt + STAGES - 1, ra0, rb0);
+        if (g1) wait_tile(kt);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA phase ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT>(fa[ks][i], fb[ks][j], acc[i][j]);
+          if (SPLITW) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT>(fa[ks][i], fl[ks][j], acc[i][j]);
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!g1) wait_tile(kt);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cs = cs + 1 == STAGES ? 0 : cs + 1;
+      }
+      if (!g1) __builtin_amdgcn_s_barrier();  // every wave has executed 2*KT + 2 barriers
+      __builtin_amdgcn_s_barrier();           // tile buffers are reused by the epilogue
+    } else if (DMA) {
     // One barrier per K step.  At the top of step kt the wave waits until its own
     // pieces of tile kt have landed (all but the STAGES-2 younger tiles' DMAs
     // retired), the barrier then (a) publishes every wave's pieces of tile kt and
@@ -499,6 +570,15 @@ int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// the staggered flavour exists for 8-wave tiles whose stage leaves room for three
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW>
+int launch_stagger(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
+  if constexpr (WARPS_M * WARPS_N == 8 && (BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES <= 49152)
+    return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, 3>(a, s, m_tiles, n_tiles);
+  else
+    return -3;
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
   const int m_tiles = (a.M + BM - 1) / BM;
@@ -510,6 +590,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.dma >= 0 ? a.dma == 1 : use_dma()) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 1>(a, s, m_tiles, n_tiles); \
     if (a.dma == 2) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0, 1>(a, s, m_tiles, n_tiles); \
     if (a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 2>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 4) return launch_stagger<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0>(a, s, m_tiles, n_tiles);      \
   } while (0)
   if (mode == CONV_MODE_STEM) {
@@ -550,7 +631,7 @@ int spk_conv_m_tiles(int M, int Cout, int mode) {
   int cfg = env_cfg() >= 0 ? env_cfg() : pick_cfg(M, Cout);
   if (cfg == 5 && Cout % 256) cfg = 4;
   if ((cfg == 0 || cfg == 4) && Cout % 128) cfg = 3;
-  const int bm = (cfg == 0 || cfg == 3) ? 128 : ((cfg == 1 || cfg == 4 || cfg == 5) ? 256 : 64);
+  const int bm = (cfg == 0 || cfg == 3) ? 128 : ((cfg == 1 || cfg == 4 || cfg == 5 || cfg == 6) ? 256 : 64);
   return (M + bm - 1) / bm;
 }
 
@@ -563,6 +644,7 @@ static int launch_with(const ConvArgs& a, int mode, int cfg, hipStream_t s, int*
     case 3: return launch_cfg<128, 64, 2, 2>(a, mode, s, m_tiles_out);
     case 4: return launch_cfg<256, 128, 4, 2>(a, mode, s, m_tiles_out);
     case 5: return launch_cfg<256, 256, 2, 4>(a, mode, s, m_tiles_out);
+    case 6: return launch_cfg<256, 64, 4, 2>(a, mode, s, m_tiles_out);
     default: return launch_cfg<64, 64, 2, 2>(a, mode, s, m_tiles_out);
   }
 }
@@ -606,6 +688,10 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
   ConvArgs a = a_in;
   if (env_cfg() >= 0 || !autotune_on() || a.cfg >= 0) {
     const int cfg = a.cfg >= 0 ? a.cfg : (env_cfg() >= 0 ? env_cfg() : pick_cfg(a.M, a.Cout));
+    if (a.dma < 0 && getenv("SPK_CONV_DMA")) a.dma = atoi(getenv("SPK_CONV_DMA"));  // flavour 0..4
+    const int r = launch_with(a, mode, cfg, s, m_tiles_out);
+    if (r != -3) return r;
+    a.dma = 3;  // the forced flavour does not exist for this tile
     return launch_with(a, mode, cfg, s, m_tiles_out);
   }
   const int pad_cls = a.pad * 16 + (a.cls_ph >= 0 ? 1 + a.cls_ph * 2 + a.cls_pw : 0);
@@ -628,7 +714,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
     float best = 1e30f;
     std::pair<int, int> win(pick_cfg(a.M, a.Cout), 0);
-    const int cands[] = {0, 1, 2, 3, 4, 5};
+    const int cands[] = {0, 1, 2, 3, 4, 5, 6};
     for (int cfg : cands) {
       const int bn = cfg == 5 ? 256 : ((cfg == 0 || cfg == 4) ? 128 : 64);
       const int bm = (cfg == 0 || cfg == 3) ? 128 : (cfg == 2 ? 64 : 256);
@@ -636,7 +722,8 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
-      for (int dma = 0; dma < 4; ++dma) {  // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage
+      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 LDS-DMA staggered
+      for (int dma = (cfg == 6 ? 3 : 0); dma < 5; ++dma) {
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
         (void)hipEventRecord(e0, s);
@@ -645,6 +732,9 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
         if (hipEventSynchronize(e1) != hipSuccess) continue;
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
+        if (getenv("SPK_TUNE_LOG") && atoi(getenv("SPK_TUNE_LOG")) > 1)
+          fprintf(stderr, "[spk cand] %dx%d C%d->%d k%d s%d sw%d: cfg %d dma %d %.1f us\n", a.H, a.W, a.Cin, a.Cout,
+                  a.kh, a.stride, a.splitw, cfg, dma, ms * 1000.f / 3.f);
         if (ms < best) { best = ms; win = {cfg, dma}; }
       }
     }
