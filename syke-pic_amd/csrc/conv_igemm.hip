@@ -32,7 +32,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST>
-__global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvArgs a, int m_tiles,
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_igemm_kernel(ConvArgs a, int m_tiles,
                                                                             int n_tiles) {
   constexpr int NTHREADS = WARPS_M * WARPS_N * 64;
   constexpr int ROWS_PER_PASS = NTHREADS / 8;  // 8 chunks per 128-B row
@@ -51,12 +51,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   // (8 rows x 128 B), so the bank swizzle is applied to the SOURCE chunk.
   constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
   // DMA == 2: two stages only (half the LDS -> two blocks per CU whose phases interleave)
-  // DMA == 3: "staggered" flavour for 8-wave blocks, one block per CU.  Each K step is split by
-  // two barriers into a load phase (all operand fragments of the step LDS -> VGPR, the DMA of a
-  // later tile issued) and an MFMA phase; waves 4-7 run one barrier behind waves 0-3, so on
-  // every SIMD one wave issues MFMAs while its partner loads.  Needs >= 3 stages.
-  constexpr int STAGES = (!DMA || DMA == 2) ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2));
-  static_assert(DMA != 3 || (STAGES >= 3 && WARPS_M * WARPS_N == 8), "staggered flavour: 8 waves, >= 3 stages");
+  // DMA == 3: hybrid, two stages: weights by LDS-DMA, activations through two register sets whose
+  // LDS stores are interleaved with the MFMA rows (the LDS-DMA path sustains ~70 GB/s per CU, half
+  // of what register loads get from L2: splitting the tile over both paths relieves it)
+  constexpr int STAGES = (!DMA || DMA >= 2) ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2));
+  static_assert(DMA != 3 || MODE != CONV_MODE_STEM, "no hybrid stem");
   constexpr int PER_TILE = A_ITERS + B_ITERS;  // DMA instructions per wave per tile
   static_assert(!DMA || ROWS_PER_PASS % 16 == 0, "swizzle must not depend on the pass");
 
@@ -90,7 +89,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   const int srow = tid >> 3;
   // register staging writes chunk c to its swizzled slot; DMA lands lane l of a
   // row in slot l&7, so that lane must FETCH the chunk whose slot that is
-  const int chunk = DMA ? ((tid & 7) ^ ((srow >> 1) & 7)) : (tid & 7);
+  const int chunk_a = tid & 7;                               // register path: plain chunk, swizzled store
+  const int chunk_b = (tid & 7) ^ ((srow >> 1) & 7);         // DMA path: swizzled source chunk
+  const int chunk = (DMA && DMA != 3) ? chunk_b : chunk_a;  // chunk of the ACTIVATION loads
   int a_base[A_ITERS], a_h0[A_ITERS], a_w0[A_ITERS];
   int b_off[B_ITERS];
   const int HoWo = a.Ho * a.Wo;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   const int s_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_pw + a.pad) & 1) : 0;
   const int tap_step = (MODE == CONV_MODE_DGRAD && cls) ? 2 : 1;
   int kr = r_first, ks_ = s_first, kc0 = 0;
+  int wr = r_first, ws = s_first, wc0 = 0;  // tap walk of the weight tiles (dgrad)
 
   auto set_tile = [&](int w) {
     const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = w & 7;
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
     m0 = mt_idx * BM;
     n0 = nt_idx * BN;
     kr = r_first; ks_ = s_first; kc0 = 0;
+    wr = r_first; ws = s_first; wc0 = 0;
 #pragma unroll
     for (int i = 0; i < A_ITERS; ++i) {
       const int m = m0 + srow + i * ROWS_PER_PASS;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
     for (int i = 0; i < B_ITERS; ++i) {
       const int rr = srow + i * ROWS_PER_PASS;  // [0, NB*BN): hi rows then lo rows
       const int half = rr / BN;
-      b_off[i] = ((half * a.Cout + n0 + rr - half * BN) * a.K + chunk * 8) * 2;
+      b_off[i] = ((half * a.Cout + n0 + rr - half * BN) * a.K + (DMA ? chunk_b : chunk_a) * 8) * 2;
     }
   };
   int work = blockIdx.x;
@@ -152,16 +155,28 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
 
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   int dma_stage = 0;  // LDS stage the next issue_loads() call fills (DMA mode)
-  auto put = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, u32x4_t& reg, unsigned char* lds_row0) {
-    if (DMA)
+  constexpr bool A_LDS = DMA && DMA != 3;  // activations by LDS-DMA (else into registers)
+  constexpr bool B_LDS = DMA != 0;         // weights by LDS-DMA
+  auto put_a = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, u32x4_t& reg, unsigned char* lds_row0) {
+    if (A_LDS)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_row0, 16, off, 0, 0, 0);
     else
       reg = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
   };
-  auto issue_loads = [&](int kt, u32x4_t (&ra)[A_ITERS], u32x4_t (&rb)[B_ITERS]) {
+  auto put_b = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, u32x4_t& reg, unsigned char* lds_row0) {
+    if (B_LDS)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)lds_row0, 16, off, 0, 0, 0);
+    else
+      reg = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+  };
+  // Activation tile: the next tile of the (kr, ks_, kc0) walk into stage `stage` / registers `ra`.
+  // `live` false: the same instructions against a zero-length resource (every lane is range-
+  // checked away and reads zeros) - the hybrid loop issues them past the last tile.
+  auto issue_a = [&](int kt, u32x4_t (&ra)[A_ITERS], int stage, bool live = true) {
+    const __amdgpu_buffer_rsrc_t rs =
+        DMA == 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, live ? a.x_bytes : 0, 0x00020000) : rx;
     // wave-uniform LDS row of this wave's 8-row piece in pass i: wave*8 + i*ROWS_PER_PASS
-    unsigned char* const dA = sA + dma_stage * STAGE_BYTES + wave * (8 * ROW_BYTES);
-    unsigned char* const dB = sB + dma_stage * STAGE_BYTES + wave * (8 * ROW_BYTES);
+    unsigned char* const dA = sA + stage * STAGE_BYTES + wave * (8 * ROW_BYTES);
     if (MODE == CONV_MODE_STEM) {
       const int krow = kt * 2 + (chunk >> 2);
       const int qq = chunk & 3;
@@ -170,7 +185,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
         const int hi = a_h0[i] + krow, px = a_w0[i] + 2 * qq;
         const bool ok = (krow < 7) && ((unsigned)hi < (unsigned)a.H) && ((unsigned)px < (unsigned)a.W);
         const unsigned off = ok ? (unsigned)((a_base[i] + (krow * a.W + 2 * qq) * 4) * 2) : 0x80000000u;
-        put(rx, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
+        put_a(rs, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
       }
     } else if (MODE == CONV_MODE_DGRAD) {
       const int sh = a.stride == 2 ? 1 : 0;
@@ -181,13 +196,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
                         ((u >> sh) < a.W);
         const unsigned off =
             ok ? (unsigned)((a_base[i] + ((t >> sh) * a.W + (u >> sh)) * a.Cin + kc0) * 2) : 0x80000000u;
-        put(rx, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
+        put_a(rs, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
       }
-      // weights of this tap: K offset in the [Cin][kh][kw][Cout] image
-      const int wk = ((kr * a.kw + ks_) * a.Cin + kc0) * 2;
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i)
-        put(rw, (unsigned)(b_off[i] + wk), rb[i], dB + i * (ROWS_PER_PASS * ROW_BYTES));
       kc0 += BK;
       if (kc0 >= a.Cin) {
         kc0 = 0;
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
         const bool ok = ((unsigned)(a_h0[i] + kr) < (unsigned)a.H) &&
                         ((unsigned)(a_w0[i] + ks_) < (unsigned)a.W);
         const unsigned off = ok ? (unsigned)((a_base[i] + tap_off) * 2) : 0x80000000u;
-        put(rx, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
+        put_a(rs, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
       }
       kc0 += BK;
       if (kc0 >= a.Cin) {
@@ -209,11 +219,30 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
         if (++ks_ == a.kw) { ks_ = 0; ++kr; }
       }
     }
-    if (MODE != CONV_MODE_DGRAD) {
-#pragma unroll
-      for (int i = 0; i < B_ITERS; ++i)
-        put(rw, (unsigned)(b_off[i] + kt * (BK * 2)), rb[i], dB + i * (ROWS_PER_PASS * ROW_BYTES));
+  };
+  // Weight tile kt.  Dgrad walks the taps of the [Cin][kh][kw][Cout] image with its own
+  // (wr, ws, wc0) state, so that the two operands of a tile may be issued in different steps.
+  auto issue_b = [&](int kt, u32x4_t (&rb)[B_ITERS], int stage, bool live = true) {
+    const __amdgpu_buffer_rsrc_t rs =
+        DMA == 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, live ? a.w_bytes : 0, 0x00020000) : rw;
+    unsigned char* const dB = sB + stage * STAGE_BYTES + wave * (8 * ROW_BYTES);
+    int wk = kt * (BK * 2);
+    if (MODE == CONV_MODE_DGRAD) {
+      wk = ((wr * a.kw + ws) * a.Cin + wc0) * 2;
+      wc0 += BK;
+      if (wc0 >= a.Cin) {
+        wc0 = 0;
+        ws += tap_step;
+        if (ws >= a.kw) { ws = s_first; wr += tap_step; }
+      }
     }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i)
+      put_b(rs, (unsigned)(b_off[i] + wk), rb[i], dB + i * (ROWS_PER_PASS * ROW_BYTES));
+  };
+  auto issue_loads = [&](int kt, u32x4_t (&ra)[A_ITERS], u32x4_t (&rb)[B_ITERS]) {
+    issue_a(kt, ra, dma_stage);
+    issue_b(kt, rb, dma_stage);
     if (DMA) dma_stage = dma_stage + 1 == STAGES ? 0 : dma_stage + 1;
   };
 
@@ -268,7 +297,14 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
   // measured 10-35 % SLOWER on every ResNet-50 layer as compiled by hipcc 7.2
   // and was removed; deeper pipelining is the job of the LDS-DMA flavour.)
   u32x4_t ra0[A_ITERS], rb0[B_ITERS];
-  if (DMA) {
+  if (DMA == 3) {
+    issue_a(0, ra0, 0);
+    issue_b(0, rb0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < A_ITERS; ++i) *(u32x4_t*)(sA + lds_off(srow + i * ROWS_PER_PASS, chunk_a)) = ra0[i];
+    issue_a(1, ra0, 0, KT > 1);
+  } else if (DMA) {
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
       if (t < KT) issue_loads(t, ra0, rb0);
@@ -324,71 +360,74 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv_igemm_kernel(ConvA
       for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     if (DMA == 3) {
-      const bool g1 = wave >= 4;  // the group that runs one barrier behind
-      auto wait_tile = [&](int kt) {  // this wave's pieces of tile kt+1 have landed
-        if (kt + 1 >= KT) return;
-        if (kt + STAGES - 1 < KT)
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_TILE) : "memory");
-        else
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      };
-      if (STAGES - 1 <= KT)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PER_TILE) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // tile 0 is complete
-      if (g1) __builtin_amdgcn_s_barrier();
-      int cs = 0;
-      for (int kt = 0; kt < KT; ++kt) {
-        // ---- load phase ----
+      // Hybrid flavour.  Tile kt is multiplied out of LDS stage cs while (a) the weight tile
+      // kt+1 streams into the other stage by LDS-DMA, (b) the activation tile kt+1, which
+      // landed in registers during the previous step, is stored there between the MFMA rows,
+      // and (c) the activation tile kt+2 is fetched into the second register set.
+      auto step = [&](int kt, const u32x4_t (&cur)[A_ITERS], u32x4_t (&nxt)[A_ITERS], int cs) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // every step issues the same instructions, so that the outstanding-load counts are the
+        // same on every path (the compiler's own s_waitcnt placement takes the worst path):
+        // past the last tile the loads are dead (range-checked away, zeros)
+        issue_b(kt + 1, rb0, cs ^ 1, kt + 1 < KT);
+        issue_a(kt + 2, nxt, 0, kt + 2 < KT);
         const unsigned char* pa = sA + cs * STAGE_BYTES;
         const unsigned char* pb = sB + cs * STAGE_BYTES;
         u32x4_t fa[2][MT], fb[2][NT], fl[2][SPLITW ? NT : 1];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int i = 0; i < MT; ++i) fa[0][i] = *(const u32x4_t*)(pa + lds_off(wm * WM + i * 16 + frow, fq));
 #pragma unroll
-          for (int i = 0; i < MT; ++i)
-            fa[ks][i] = *(const u32x4_t*)(pa + lds_off(wm * WM + i * 16 + frow, ks * 4 + fq));
+        for (int j = 0; j < NT; ++j) fb[0][j] = *(const u32x4_t*)(pb + lds_off(wn * WN + j * 16 + frow, fq));
+        if (SPLITW) {
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            fb[ks][j] = *(const u32x4_t*)(pb + lds_off(wn * WN + j * 16 + frow, ks * 4 + fq));
+          for (int j = 0; j < NT; ++j) fl[0][j] = *(const u32x4_t*)(pb + lds_off(BN + wn * WN + j * 16 + frow, fq));
+        }
+        // `cur` has landed once only the loads issued in this step are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS + B_ITERS) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int NG = 2 * MT;                        // MFMA rows of one K step
+        constexpr int NRD = MT + (SPLITW ? 2 : 1) * NT;   // ks = 1 fragment reads
+        int piece = 0, rd = 0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int ks = g / MT, i = g % MT;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT>(fa[ks][i], fb[ks][j], acc[i][j]);
           if (SPLITW) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-              fl[ks][j] = *(const u32x4_t*)(pb + lds_off(BN + wn * WN + j * 16 + frow, ks * 4 + fq));
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT>(fa[ks][i], fl[ks][j], acc[i][j]);
           }
-        }
-        // the stage of tile kt-1 was last read in the partner group's previous load phase
-        if (kt + STAGES - 1 < KT) issue_loads(kt + STAGES - 1, ra0, rb0);
-        if (g1) wait_tile(kt);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- MFMA phase ----
-        __builtin_amdgcn_s_setprio(1);
+          if (ks == 0) {  // this row's share of the ks = 1 fragment reads
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT>(fa[ks][i], fb[ks][j], acc[i][j]);
-          if (SPLITW) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT>(fa[ks][i], fl[ks][j], acc[i][j]);
+            for (int q = 0; q < (NRD + MT - 1) / MT; ++q, ++rd) {
+              if (rd < MT)
+                fa[1][rd] = *(const u32x4_t*)(pa + lds_off(wm * WM + rd * 16 + frow, 4 + fq));
+              else if (rd < MT + NT)
+                fb[1][rd - MT] = *(const u32x4_t*)(pb + lds_off(wn * WN + (rd - MT) * 16 + frow, 4 + fq));
+              else if (SPLITW && rd < NRD)
+                fl[1][rd - MT - NT] =
+                    *(const u32x4_t*)(pb + lds_off(BN + wn * WN + (rd - MT - NT) * 16 + frow, 4 + fq));
+            }
           }
+          // and of the stores of activation tile kt+1
+#pragma unroll
+          for (int q = 0; q < (A_ITERS + NG - 1) / NG; ++q, ++piece)
+            if (piece < A_ITERS)
+              *(u32x4_t*)(sA + (cs ^ 1) * STAGE_BYTES + lds_off(srow + piece * ROWS_PER_PASS, chunk_a)) = cur[piece];
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-        if (!g1) wait_tile(kt);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        cs = cs + 1 == STAGES ? 0 : cs + 1;
+        // weight tile kt+1 has landed once only the activation loads of tile kt+2 are outstanding
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_ITERS) : "memory");
+      };
+      u32x4_t ra1[A_ITERS];
+      // an odd K-step count runs one dead step (zeros times zeros): the loop body has no branch
+      for (int kt = 0; kt < KT; kt += 2) {
+        step(kt, ra0, ra1, 0);
+        step(kt + 1, ra1, ra0, 1);
       }
-      if (!g1) __builtin_amdgcn_s_barrier();  // every wave has executed 2*KT + 2 barriers
-      __builtin_amdgcn_s_barrier();           // tile buffers are reused by the epilogue
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // dead loads/stores of the last step
+      __builtin_amdgcn_s_barrier();  // tile buffers are reused by the epilogue
     } else if (DMA) {
     // One barrier per K step.  At the top of step kt the wave waits until its own
     // pieces of tile kt have landed (all but the STAGES-2 younger tiles' DMAs
@@ -549,10 +588,10 @@ thread_local char g_cfg_name[64] = "";
 template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST = 0>
 int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   const size_t stage = (size_t)(BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES;
-  const int stages = (!DMA || DMA == 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
+  const int stages = (!DMA || DMA >= 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
   const size_t lds_full = stages * stage;
   const int kt = a.K / BK;
-  const size_t lds = (kt < stages ? kt : stages) * stage;
+  const size_t lds = DMA == 3 ? lds_full : (kt < stages ? kt : stages) * stage;  // hybrid: both stages are written
   auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA, PERSIST>;
   static bool attr = false;
   if (!attr) {
@@ -570,10 +609,12 @@ int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// the staggered flavour exists for 8-wave tiles whose stage leaves room for three
+// the hybrid flavour (weights by LDS-DMA, activations through registers) has no stem form
 template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW>
-int launch_stagger(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
-  if constexpr (WARPS_M * WARPS_N == 8 && (BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES <= 49152)
+int launch_hybrid(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
+  // (256x256 and the 4x1-wave 256x64 tile would need more than 256 VGPRs)
+  if constexpr (MODE != CONV_MODE_STEM && BM * BN < 256 * 256 && !(BM == 256 && WARPS_N == 1) &&
+                (BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES * 2 <= 163840)
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, 3>(a, s, m_tiles, n_tiles);
   else
     return -3;
@@ -590,7 +631,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.dma >= 0 ? a.dma == 1 : use_dma()) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 1>(a, s, m_tiles, n_tiles); \
     if (a.dma == 2) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0, 1>(a, s, m_tiles, n_tiles); \
     if (a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 2>(a, s, m_tiles, n_tiles); \
-    if (a.dma == 4) return launch_stagger<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 4) return launch_hybrid<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0>(a, s, m_tiles, n_tiles);      \
   } while (0)
   if (mode == CONV_MODE_STEM) {
@@ -722,7 +763,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
-      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 LDS-DMA staggered
+      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid
       for (int dma = (cfg == 6 ? 3 : 0); dma < 5; ++dma) {
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
