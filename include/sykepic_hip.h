@@ -118,15 +118,23 @@ int spk_model_set_param_group(spk_model* m, const char* key, int group);
  * 1e-3 probability tolerance needs its 11-bit mantissa), 1 = bf16. fp32
  * accumulation either way. Training always runs bf16. */
 int spk_model_set_infer_dtype(spk_model* m, int bf16);
-/* Precision knobs of the fp16 eval path (defaults: split_weights = 1,
+/* Precision knobs of the fp16 eval path (defaults: split_weights = 3,
  * precise_residual = 0).  split_weights = 2 splits only the convs that write
- * the residual trunk (stem, block-closing convs, downsample branches).
+ * the residual trunk (stem, block-closing convs, downsample branches);
+ * split_weights = 3 splits every conv except the 3x3 convs inside a residual
+ * block (the lo-products that buy the least accuracy per MFMA cycle).
  * split_weights = 1: every conv weight is carried as
  * hi + lo fp16 halves and both products are accumulated (2x MFMA work, weight
  * rounding error ~2^-22) — weight rounding is the dominant logit error at
  * 16-bit storage.  precise_residual: shortcut tensors keep their fp16
  * rounding remainder for the residual add (+2 B/element of shortcut traffic). */
 int spk_model_set_precision(spk_model* m, int split_weights, int precise_residual);
+/* Per-op choice of split weights: flags[i] != 0 carries conv op i (index into the
+ * spk_layer_desc array of spk_model_create) as hi+lo halves; flags of non-conv ops
+ * are ignored.  Replaces the split_weights mode until spk_model_set_precision is
+ * called again.  `tools/split_search.py` derives the cheapest mask that keeps
+ * the reference's 1e-3 probability tolerance. */
+int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops);
 /* Dropout mask seed for training steps. */
 int spk_model_set_seed(spk_model* m, uint64_t seed);
 

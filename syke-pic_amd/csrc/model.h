@@ -55,7 +55,9 @@ struct spk_model {
   int infer_dt = DT_F16;       // 16-bit storage type of the eval path
   int packed_dt = -1;          // dtype the packed weights currently hold
   int packed_split = -1;
-  int splitw = 1;              // eval: hi+lo fp16 weights. 0 none, 1 every conv (default), 2 trunk writers only
+  int splitw = 3;              // eval: hi+lo fp16 weights. 0 none, 1 every conv, 2 trunk writers only, 3 all but inner 3x3 (default), 4 per-op mask
+  std::vector<unsigned char> split_mask;  // splitw == 4: one flag per graph op
+  int split_epoch = 0, packed_epoch = -1;  // bumps when the mask changes
   int act_dt = DT_F16;         // dtype of the activations now in the arena
 
   // activations of one (n,h,w) plan

@@ -310,11 +310,20 @@ extern "C" int spk_model_set_infer_dtype(spk_model* m, int bf16) {
 
 extern "C" int spk_model_set_precision(spk_model* m, int split_weights, int precise_residual) {
   if (!m) return fail(SPK_ERR_ARG, "null model");
-  m->splitw = split_weights < 0 ? 0 : (split_weights > 2 ? 2 : split_weights);
+  m->splitw = split_weights < 0 ? 0 : (split_weights > 3 ? 3 : split_weights);  // (4 = mask: spk_model_set_split_ops)
   if ((precise_residual != 0) != m->precise_res) {
     m->precise_res = precise_residual != 0;
     m->cap_n = 0;  // re-plan: remainder tensors appear / disappear
   }
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops) {
+  if (!m || !flags) return fail(SPK_ERR_ARG, "null argument");
+  if (n_ops != (int)m->layers.size()) return fail(SPK_ERR_ARG, "one flag per graph op expected");
+  m->split_mask.assign(flags, flags + n_ops);
+  m->splitw = 4;
+  ++m->split_epoch;
   return SPK_OK;
 }
 
@@ -330,11 +339,17 @@ extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
 // does this conv run with hi/lo split weights in the eval path?
 static int layer_split(const spk_model* m, const Layer& L) {
   if (m->infer_dt != DT_F16 || m->splitw == 0) return 0;
+  if (m->splitw == 4) return m->split_mask[&L - m->layers.data()] ? 1 : 0;
+  // 3: every conv except the 3x3 convs inside a residual block (tools/split_rules.py: their
+  // weight rounding adds the least logit error per MFMA cycle a lo-product costs)
+  if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 ? 1 : 0;
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;
 }
 
 int spk_commit(spk_model* m) {
-  if (!m->dirty && m->packed_dt == m->infer_dt && m->packed_split == (int)m->splitw) return SPK_OK;
+  if (!m->dirty && m->packed_dt == m->infer_dt && m->packed_split == (int)m->splitw &&
+      m->packed_epoch == m->split_epoch)
+    return SPK_OK;
   for (Layer& L : m->layers) {
     if (L.d.kind != SPK_OP_CONV) continue;
     float* sc = m->scale_bias + L.sb_off;
@@ -348,6 +363,7 @@ int spk_commit(spk_model* m) {
   }
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
+  m->packed_epoch = m->split_epoch;
   m->dirty = false;
   return SPK_OK;
 }

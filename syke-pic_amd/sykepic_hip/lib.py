@@ -60,6 +60,7 @@ SYMBOLS = {
     "spk_model_set_param_group": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "spk_model_set_infer_dtype": (C.c_int, [_P, C.c_int]),
     "spk_model_set_precision": (C.c_int, [_P, C.c_int, C.c_int]),
+    "spk_model_set_split_ops": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "spk_model_set_seed": (C.c_int, [_P, C.c_uint64]),
     "spk_forward_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     _P]),

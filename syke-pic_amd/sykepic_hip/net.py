@@ -156,10 +156,26 @@ class HipNet:
         self._build_views()
         self._stats = None
 
-    def set_precision(self, split_weights=1, precise_residual=False, bf16=False):
+    def set_precision(self, split_weights=3, precise_residual=False, bf16=False):
         """Eval-path precision knobs (see include/sykepic_hip.h)."""
         lib.check(self._lib.spk_model_set_infer_dtype(self._h, int(bool(bf16))))
         lib.check(self._lib.spk_model_set_precision(self._h, int(split_weights), int(bool(precise_residual))))
+        return self
+
+    def conv_ops(self):
+        """[(op index, conv name)] of the graph's convolutions, in execution order."""
+        return [(i, op.name) for i, op in enumerate(self.graph.ops) if op.kind == arch.OP_CONV]
+
+    def set_split_ops(self, names):
+        """Carry exactly the named convs as hi+lo fp16 halves in the eval path
+        (spk_model_set_split_ops); `set_precision` switches back to a mode."""
+        names = set(names)
+        known = {n for _, n in self.conv_ops()}
+        if names - known:
+            raise KeyError(f"not convolutions of this network: {sorted(names - known)}")
+        flags = bytes(1 if (op.kind == arch.OP_CONV and op.name in names) else 0 for op in self.graph.ops)
+        lib.check(self._lib.spk_model_set_infer_dtype(self._h, 0))
+        lib.check(self._lib.spk_model_set_split_ops(self._h, flags, len(flags)))
         return self
 
     # ---- lifetime ----

@@ -135,3 +135,37 @@ def test_resnet50_probability_tolerance_over_64_images():
         assert (p.argmax(1)[decided] == pr.argmax(1)[decided]).all()
     print(f"resnet50, 64 images: max |dp| = {worst:.2e}")
     assert worst <= PROB_TOL
+
+
+def test_split_weight_modes_and_per_op_mask():
+    """The precision modes of the eval path: the per-op mask API reproduces the
+    built-in modes bit for bit, and the default ("all but the 3x3 convs inside a
+    residual block") sits between plain fp16 and the every-conv split."""
+    from oracle import refnet
+    gold = np.load(GOLD)
+    g, sd = _state("resnet50", gold, "resnet50_224")
+    net = _hipnet("resnet50", sd)
+    ops = {op.name: op for op in g.ops if op.kind == arch.OP_CONV}
+    convs = [n for _, n in net.conv_ops()]
+    assert convs == list(ops) and len(convs) == 53
+    trunk = {n for n in convs if n == "base.0" or "downsample" in n or ops[n].res >= 0}
+    inner3 = {n for n in convs if ops[n].k == 3 and n not in trunk}
+    assert len(inner3) == 16
+    x = torch.from_numpy(synth.synth_images(16, 3, 224, 224, seed=41)).cuda()
+    by_mode = {}
+    for mode, keep in ((3, set(convs) - inner3), (1, set(convs)), (2, trunk), (0, set())):
+        net.set_precision(split_weights=mode)
+        a = net.forward(x)
+        net.set_split_ops(keep)
+        b = net.forward(x)
+        assert torch.equal(a, b), f"mode {mode} != its mask"
+        by_mode[mode] = a.cpu().numpy()
+    with pytest.raises(KeyError):
+        net.set_split_ops(["base.9.conv1"])
+    ref = refnet.load_numpy_state(refnet.RefNet("resnet50", 50), sd)
+    z = refnet.probabilities(ref, x.cpu(), base=0).numpy()
+    rms = {m: float(np.sqrt(np.mean((v - z) ** 2))) for m, v in by_mode.items()}
+    print("logit rms by split mode", rms)
+    assert rms[1] < rms[3] < rms[2] < rms[0]
+    net.set_precision()   # back to the default
+    assert torch.equal(net.forward(x), torch.from_numpy(by_mode[3]).cuda())
