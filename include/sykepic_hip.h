@@ -45,6 +45,17 @@ extern "C" {
 #define SPK_OP_GAVGPOOL 3  /* AdaptiveAvgPool2d(1) + flatten */
 #define SPK_OP_LINEAR 4    /* Linear with bias, no activation (head) */
 #define SPK_OP_DROPOUT 5   /* Dropout(p) in the head */
+/* EfficientNet (torchvision MBConv; eval path only):
+ *   DWCONV: depthwise Conv2d(C, C, k, stride, pad=(k-1)/2, groups=C, bias=False) + BatchNorm2d + activation
+ *   SE:     SqueezeExcitation(C, squeeze = `k`): avgpool -> fc1 (1x1 conv, bias) -> SiLU -> fc2 -> Sigmoid -> x * s;
+ *           `name` is the module prefix (name.fc1.weight ...), cin = cout = C. */
+#define SPK_OP_DWCONV 6
+#define SPK_OP_SE 7
+
+/* spk_layer_desc.relu: activation after BatchNorm (+ residual) */
+#define SPK_ACT_NONE 0
+#define SPK_ACT_RELU 1
+#define SPK_ACT_SILU 2
 
 /* input layouts / dtypes of the image batch */
 #define SPK_LAYOUT_NCHW 0
@@ -67,7 +78,7 @@ typedef struct spk_model spk_model;
 typedef struct {
   int32_t kind;
   int32_t cin, cout, k, stride, pad;
-  int32_t relu;
+  int32_t relu;  /* SPK_ACT_* */
   int32_t src, dst, res;
   int32_t child; /* index of the owning child of `base`; -1 for the head */
   float p;       /* dropout probability */

@@ -10,7 +10,19 @@ published architecture is restated: child order
 ``conv1,bn1,relu,maxpool,layer1,layer2,layer3,layer4,avgpool,fc`` and
 attribute names are what define the ``state_dict`` keys of ``best_state.pth``.
 ResNet v1.5 (stride on the 3x3 conv of a Bottleneck).  fp32, NCHW, CPU.
+
+EfficientNet (B0-B4 scaling of the 2019 paper as torchvision >= 0.13 builds it:
+``features[0]`` stem 3x3/2, ``features[1..7]`` MBConv stages with
+squeeze-excitation, ``features[8]`` 1x1 head conv, ``avgpool``,
+``classifier = [Dropout, Linear]``; ``Conv2dNormActivation`` =
+``Sequential(Conv2d(bias=False), BatchNorm2d, SiLU)``;
+``SqueezeExcitation`` = avgpool -> ``fc1`` (1x1 conv, bias) -> SiLU -> ``fc2``
+-> Sigmoid -> scale; stochastic depth is the identity in eval mode).  Checked
+against the published parameter counts (efficientnet_b4: 19,341,616 with the
+1000-class classifier, efficientnet_b0: 5,288,548).
 """
+
+import math
 
 import torch.nn as nn
 
@@ -93,6 +105,84 @@ class ResNet(nn.Module):
         return self.fc(self.avgpool(x).flatten(1))
 
 
+def _make_divisible(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
+
+
+def _cna(cin, cout, k, stride=1, groups=1, act=True):
+    """torchvision.ops.Conv2dNormActivation(norm=BatchNorm2d, activation=SiLU or None)."""
+    mods = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout)]
+    if act:
+        mods.append(nn.SiLU(inplace=True))
+    return nn.Sequential(*mods)
+
+
+class SqueezeExcitation(nn.Module):
+    def __init__(self, channels, squeeze):
+        super().__init__()
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.fc1 = nn.Conv2d(channels, squeeze, 1)
+        self.fc2 = nn.Conv2d(squeeze, channels, 1)
+        self.activation = nn.SiLU(inplace=True)
+        self.scale_activation = nn.Sigmoid()
+
+    def forward(self, x):
+        s = self.scale_activation(self.fc2(self.activation(self.fc1(self.avgpool(x)))))
+        return s * x
+
+
+class MBConv(nn.Module):
+    def __init__(self, cin, cout, k, stride, expand_ratio):
+        super().__init__()
+        self.use_res_connect = stride == 1 and cin == cout
+        exp = _make_divisible(cin * expand_ratio)
+        layers = []
+        if exp != cin:
+            layers.append(_cna(cin, exp, 1))
+        layers.append(_cna(exp, exp, k, stride, groups=exp))
+        layers.append(SqueezeExcitation(exp, max(1, cin // 4)))
+        layers.append(_cna(exp, cout, 1, act=False))
+        self.block = nn.Sequential(*layers)
+
+    def forward(self, x):
+        y = self.block(x)
+        return y + x if self.use_res_connect else y   # StochasticDepth: identity in eval
+
+
+class EfficientNet(nn.Module):
+    # expand ratio, kernel, stride, input channels, output channels, layers (B0 baseline)
+    _BASE = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3),
+             (6, 5, 1, 80, 112, 3), (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+
+    def __init__(self, width_mult, depth_mult, dropout, num_classes=1000):
+        super().__init__()
+        ch = lambda c: _make_divisible(c * width_mult)
+        feats = [_cna(3, ch(32), 3, 2)]
+        for t, k, s, cin, cout, n in self._BASE:
+            cin, cout, n = ch(cin), ch(cout), int(math.ceil(n * depth_mult))
+            feats.append(nn.Sequential(*[MBConv(cin if i == 0 else cout, cout, k, s if i == 0 else 1, t)
+                                         for i in range(n)]))
+        last_in = ch(320)
+        feats.append(_cna(last_in, 4 * last_in, 1))
+        self.features = nn.Sequential(*feats)
+        self.avgpool = nn.AdaptiveAvgPool2d(1)
+        self.classifier = nn.Sequential(nn.Dropout(dropout, inplace=True), nn.Linear(4 * last_in, num_classes))
+
+    def forward(self, x):
+        return self.classifier(self.avgpool(self.features(x)).flatten(1))
+
+
+_EFF = {  # width, depth, dropout (torchvision efficientnet_b0..b4; b5-b7 use a different BatchNorm eps)
+    "efficientnet_b0": (1.0, 1.0, 0.2),
+    "efficientnet_b1": (1.0, 1.1, 0.2),
+    "efficientnet_b2": (1.1, 1.2, 0.3),
+    "efficientnet_b3": (1.2, 1.4, 0.3),
+    "efficientnet_b4": (1.4, 1.8, 0.4),
+}
+
 _CFG = {
     "resnet18": (BasicBlock, (2, 2, 2, 2)),
     "resnet34": (BasicBlock, (3, 4, 6, 3)),
@@ -105,9 +195,11 @@ _CFG = {
 def make(name, weights=None):
     """Stand-in for ``torchvision.models.<name>(weights=...)``; pretrained
     weights cannot be fetched (no network), so ``weights`` is ignored."""
+    if name in _EFF:
+        return EfficientNet(*_EFF[name])
     block, depths = _CFG[name]
     return ResNet(block, depths)
 
 
 def names():
-    return sorted(_CFG)
+    return sorted(_CFG) + sorted(_EFF)

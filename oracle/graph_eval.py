@@ -20,8 +20,20 @@ def run(graph, state, x, train=False, eps=1e-5):
                              state[op.bn + ".weight"], state[op.bn + ".bias"], train, 0.1, eps)
             if op.res >= 0:
                 y = y + acts[op.res]
-            if op.relu:
+            if int(op.relu) == arch.ACT_SILU:
+                y = F.silu(y)
+            elif op.relu:
                 y = F.relu(y)
+        elif op.kind == arch.OP_DWCONV:   # EfficientNet: depthwise conv + BN + SiLU
+            y = F.conv2d(a, state[op.name + ".weight"], None, op.stride, op.pad, groups=op.cin)
+            y = F.batch_norm(y, state[op.bn + ".running_mean"].clone(), state[op.bn + ".running_var"].clone(),
+                             state[op.bn + ".weight"], state[op.bn + ".bias"], train, 0.1, eps)
+            y = F.silu(y) if int(op.relu) == arch.ACT_SILU else (F.relu(y) if op.relu else y)
+        elif op.kind == arch.OP_SE:       # squeeze-excitation gate
+            s = a.mean((2, 3), keepdim=True)
+            s = F.silu(F.conv2d(s, state[op.name + ".fc1.weight"], state[op.name + ".fc1.bias"]))
+            s = torch.sigmoid(F.conv2d(s, state[op.name + ".fc2.weight"], state[op.name + ".fc2.bias"]))
+            y = a * s
         elif op.kind == arch.OP_MAXPOOL:
             y = F.max_pool2d(a, op.k, op.stride, op.pad)
         elif op.kind == arch.OP_GAVGPOOL:

@@ -40,7 +40,10 @@ class RefNet(nn.Module):
     def __init__(self, name, num_classes, head=(256, 128), dropout=()):
         super().__init__()
         children = list(backbones.make(name).children())
-        feat = children[-1].in_features
+        last = children[-1]
+        if isinstance(last, nn.Sequential):   # EfficientNet classifier = [Dropout, Linear] (network.py:50-55)
+            last = next(m for m in last if isinstance(m, nn.Linear))
+        feat = last.in_features
         widths = [feat] + [int(h) for h in head] + [int(num_classes)]
         mods = [nn.Linear(a, b) for a, b in zip(widths[:-1], widths[1:])]
         for idx, p in dropout:
@@ -154,6 +157,24 @@ def eval_step(net, x, y):
         out = net(x)
         loss = F.cross_entropy(out, y)
     return float(loss), int((out.argmax(1) == y).sum()), out
+
+
+def calibrate_bn(net, x):
+    """Replace every BatchNorm's running statistics by the statistics of batch ``x`` (one
+    train-mode forward with momentum 1), as a trained network's would match its data.  Used
+    to give deep random-weight test networks (EfficientNet) O(1) activations at every depth;
+    returns the net in eval mode."""
+    bns = [m for m in net.modules() if isinstance(m, _BN)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    net.train()
+    with torch.no_grad():
+        net(x)
+    for m, mom in zip(bns, old):
+        m.momentum = mom
+        m.num_batches_tracked.zero_()
+    return net.eval()
 
 
 def load_numpy_state(net, state):

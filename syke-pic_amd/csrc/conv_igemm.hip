@@ -518,9 +518,12 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
             }
           }
         }
-        if (a.relu) {
+        if (a.relu == 1) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (a.relu == 2) {  // SiLU (EfficientNet)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
         }
         u32x4_t ov;
 #pragma unroll

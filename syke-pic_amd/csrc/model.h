@@ -7,7 +7,8 @@
 #include <unordered_map>
 #include <vector>
 
-enum ParamKind { PK_CONV_W = 1, PK_BN_W, PK_BN_B, PK_BN_MEAN, PK_BN_VAR, PK_BN_NBT, PK_FC_W, PK_FC_B };
+enum ParamKind { PK_CONV_W = 1, PK_BN_W, PK_BN_B, PK_BN_MEAN, PK_BN_VAR, PK_BN_NBT, PK_FC_W, PK_FC_B,
+                 PK_SE_W, PK_SE_B };
 
 struct Param {
   std::string key;
@@ -22,8 +23,9 @@ struct Param {
 };
 
 struct TDim {
-  int h = 0, w = 0, c = 0;
+  int h = 0, w = 0, c = 0;  // c: channels as laid out (padded to 64 for EfficientNet widths)
   bool bf16 = true;
+  int c_log = 0;            // logical channels (0: same as c)
 };
 
 struct Layer {
@@ -31,6 +33,8 @@ struct Layer {
   int mode = 0;     // CONV_MODE_*
   int kpad = 0;     // GEMM K of the packed weights
   int p_w = -1, p_g = -1, p_b = -1, p_mean = -1, p_var = -1, p_nbt = -1;
+  int p_w2 = -1, p_b2 = -1;       // SE: fc2 (p_w / p_b hold fc1)
+  int cin_p = 0, cout_p = 0;      // channels as laid out in HBM: padded to a multiple of 64 (zeros)
   size_t wpack_off = 0, sb_off = 0;
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
@@ -51,6 +55,9 @@ struct spk_model {
   size_t n_flat = 0, n_train = 0;
   bf16_t* wpack = nullptr;     // bf16 conv weights, [Cout][K] per layer
   float* scale_bias = nullptr; // eval-BN folded scale/bias per conv
+  float* dwpack = nullptr;     // fp32 tap-major weights of depthwise / 3x3-stem layers (EfficientNet)
+  bool eval_only = false;      // graph has ops without a training path (EfficientNet)
+  size_t se_off = 0;           // arena offset of the squeeze-excitation scratch (partials + scales)
   bool dirty = true;
   int infer_dt = DT_F16;       // 16-bit storage type of the eval path
   int packed_dt = -1;          // dtype the packed weights currently hold

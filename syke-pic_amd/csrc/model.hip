@@ -102,15 +102,30 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     L.d.name[sizeof L.d.name - 1] = 0;
     L.d.bn[sizeof L.d.bn - 1] = 0;
     m->n_tensors = std::max(m->n_tensors, std::max(L.d.dst, std::max(L.d.src, L.d.res)) + 1);
+    // channels are laid out padded to the 64-channel granularity of the implicit-GEMM kernel
+    L.cin_p = (L.d.cin + 63) / 64 * 64;
+    L.cout_p = (L.d.cout + 63) / 64 * 64;
     if (L.d.kind == SPK_OP_CONV) {
-      if (L.d.cout % 64) { delete m; return fail(SPK_ERR_UNSUPPORTED, "conv Cout must be a multiple of 64"); }
       const bool stem = (L.d.cin <= 4);
-      if (stem && !(L.d.k == 7 && L.d.stride == 2 && L.d.pad == 3)) {
-        delete m; return fail(SPK_ERR_UNSUPPORTED, "only the 7x7/2 pad 3 stem is supported for Cin<=4");
+      const bool stem7 = stem && L.d.k == 7 && L.d.stride == 2 && L.d.pad == 3 && L.d.cout == 64;
+      const bool stem3 = stem && L.d.k == 3 && L.d.stride == 2 && L.d.pad == 1;
+      if (stem && !stem7 && !stem3) {
+        delete m; return fail(SPK_ERR_UNSUPPORTED, "stems (Cin<=4): 7x7/2 pad 3 -> 64 or 3x3/2 pad 1");
       }
-      if (!stem && L.d.cin % 64) { delete m; return fail(SPK_ERR_UNSUPPORTED, "conv Cin must be a multiple of 64"); }
-      L.mode = stem ? CONV_MODE_STEM : CONV_MODE_GENERIC;
-      L.kpad = stem ? 256 : L.d.k * L.d.k * L.d.cin;
+      if (stem) L.cin_p = 4;
+      L.mode = stem7 ? CONV_MODE_STEM : (stem3 ? CONV_MODE_STEM3 : CONV_MODE_GENERIC);
+      L.kpad = stem7 ? 256 : L.d.k * L.d.k * L.cin_p;
+      if (stem3 || L.cin_p != L.d.cin || L.cout_p != L.d.cout || L.d.relu == SPK_ACT_SILU) m->eval_only = true;
+    } else if (L.d.kind == SPK_OP_DWCONV) {
+      if ((L.d.k != 3 && L.d.k != 5) || L.d.cin != L.d.cout || L.d.pad != (L.d.k - 1) / 2) {
+        delete m; return fail(SPK_ERR_UNSUPPORTED, "depthwise conv: k 3 or 5, pad (k-1)/2");
+      }
+      m->eval_only = true;
+    } else if (L.d.kind == SPK_OP_SE) {
+      if (L.d.cin != L.d.cout || L.d.k < 1 || L.d.k > 1024) {
+        delete m; return fail(SPK_ERR_UNSUPPORTED, "squeeze-excitation: cin == cout, 1 <= squeeze <= 1024");
+      }
+      m->eval_only = true;
     }
   }
   // Layers whose rounding errors enter the residual trunk undamped: the stem,
@@ -133,6 +148,18 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       L.p_mean = add_param(m, bn + ".running_mean", PK_BN_MEAN, oi, SPK_DTYPE_F32, {L.d.cout}, false);
       L.p_var = add_param(m, bn + ".running_var", PK_BN_VAR, oi, SPK_DTYPE_F32, {L.d.cout}, false);
       L.p_nbt = add_param(m, bn + ".num_batches_tracked", PK_BN_NBT, oi, SPK_DTYPE_I64, {}, false);
+    } else if (L.d.kind == SPK_OP_DWCONV) {
+      L.p_w = add_param(m, nm + ".weight", PK_CONV_W, oi, SPK_DTYPE_F32, {L.d.cout, 1, L.d.k, L.d.k}, true);
+      L.p_g = add_param(m, bn + ".weight", PK_BN_W, oi, SPK_DTYPE_F32, {L.d.cout}, true);
+      L.p_b = add_param(m, bn + ".bias", PK_BN_B, oi, SPK_DTYPE_F32, {L.d.cout}, true);
+      L.p_mean = add_param(m, bn + ".running_mean", PK_BN_MEAN, oi, SPK_DTYPE_F32, {L.d.cout}, false);
+      L.p_var = add_param(m, bn + ".running_var", PK_BN_VAR, oi, SPK_DTYPE_F32, {L.d.cout}, false);
+      L.p_nbt = add_param(m, bn + ".num_batches_tracked", PK_BN_NBT, oi, SPK_DTYPE_I64, {}, false);
+    } else if (L.d.kind == SPK_OP_SE) {
+      L.p_w = add_param(m, nm + ".fc1.weight", PK_SE_W, oi, SPK_DTYPE_F32, {L.d.k, L.d.cin, 1, 1}, true);
+      L.p_b = add_param(m, nm + ".fc1.bias", PK_SE_B, oi, SPK_DTYPE_F32, {L.d.k}, true);
+      L.p_w2 = add_param(m, nm + ".fc2.weight", PK_SE_W, oi, SPK_DTYPE_F32, {L.d.cout, L.d.k, 1, 1}, true);
+      L.p_b2 = add_param(m, nm + ".fc2.bias", PK_SE_B, oi, SPK_DTYPE_F32, {L.d.cout}, true);
     } else if (L.d.kind == SPK_OP_LINEAR) {
       L.p_w = add_param(m, nm + ".weight", PK_FC_W, oi, SPK_DTYPE_F32, {L.d.cout, L.d.cin}, true);
       L.p_b = add_param(m, nm + ".bias", PK_FC_B, oi, SPK_DTYPE_F32, {L.d.cout}, true);
@@ -163,15 +190,22 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     }
   }
   // packed bf16 weights + folded BN scale/bias
-  size_t wpack = 0, sb = 0;
+  size_t wpack = 0, sb = 0, dwp = 0;
   for (Layer& L : m->layers) {
-    if (L.d.kind != SPK_OP_CONV) continue;
-    L.wpack_off = wpack;
-    wpack += (size_t)2 * L.d.cout * L.kpad;  // room for the hi + lo halves
+    if (L.d.kind == SPK_OP_DWCONV || (L.d.kind == SPK_OP_CONV && L.mode == CONV_MODE_STEM3)) {
+      L.wpack_off = dwp;  // fp32, [taps (x4 input channels for the stem)][cout_p]
+      dwp += (size_t)L.d.k * L.d.k * (L.d.kind == SPK_OP_CONV ? 4 : 1) * L.cout_p;
+    } else if (L.d.kind == SPK_OP_CONV) {
+      L.wpack_off = wpack;
+      wpack += (size_t)2 * L.cout_p * L.kpad;  // room for the hi + lo halves
+    } else {
+      continue;
+    }
     L.sb_off = sb;
-    sb += (size_t)2 * L.d.cout;
+    sb += (size_t)2 * L.cout_p;
   }
   if (hipMalloc((void**)&m->wpack, std::max<size_t>(wpack, 8) * 2) != hipSuccess ||
+      hipMalloc((void**)&m->dwpack, std::max<size_t>(dwp, 8) * 4) != hipSuccess ||
       hipMalloc((void**)&m->scale_bias, std::max<size_t>(sb, 8) * 4) != hipSuccess) {
     spk_model_destroy(m);
     return fail(SPK_ERR_HIP, "hipMalloc(packed weights) failed");
@@ -196,6 +230,7 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->pbuf) hipFree(m->pbuf);
   if (m->wpack) hipFree(m->wpack);
   if (m->scale_bias) hipFree(m->scale_bias);
+  if (m->dwpack) hipFree(m->dwpack);
   spk_train_free(m);
   delete m;
 }
@@ -346,20 +381,44 @@ static int layer_split(const spk_model* m, const Layer& L) {
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;
 }
 
+// 3x3 RGB stem: master [cout][3][3][cin<=3] -> fp32 [9 taps][4][cout_p] (host repack: 1.3k floats, once per load)
+static int pack_stem3(spk_model* m, const Layer& L) {
+  const int cin = L.d.cin, cout = L.d.cout, cp = L.cout_p;
+  std::vector<float> w((size_t)cout * 9 * cin), out((size_t)36 * cp, 0.f);
+  if (hipStreamSynchronize(m->stream) != hipSuccess ||
+      hipMemcpy(w.data(), m->P(L.p_w), w.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  for (int co = 0; co < cout; ++co)
+    for (int t = 0; t < 9; ++t)
+      for (int c = 0; c < cin; ++c) out[(size_t)(t * 4 + c) * cp + co] = w[((size_t)co * 9 + t) * cin + c];
+  return hipMemcpy(m->dwpack + L.wpack_off, out.data(), out.size() * 4, hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+}
+
 int spk_commit(spk_model* m) {
   if (!m->dirty && m->packed_dt == m->infer_dt && m->packed_split == (int)m->splitw &&
       m->packed_epoch == m->split_epoch)
     return SPK_OK;
   for (Layer& L : m->layers) {
-    if (L.d.kind != SPK_OP_CONV) continue;
+    if (L.d.kind != SPK_OP_CONV && L.d.kind != SPK_OP_DWCONV) continue;
     float* sc = m->scale_bias + L.sb_off;
-    float* bi = sc + L.d.cout;
+    float* bi = sc + L.cout_p;
+    if (L.cout_p != L.d.cout)  // padded output channels: scale = shift = 0
+      HIP_TRY(hipMemsetAsync(sc, 0, (size_t)2 * L.cout_p * 4, m->stream));
     if (spk_launch_bn_fold(m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean), m->P(L.p_var), 1e-5f, sc, bi,
                            L.d.cout, m->stream))
       return fail(SPK_ERR_HIP, "bn_fold launch failed");
-    if (spk_launch_pack_weights(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
-                                L.mode, m->infer_dt, layer_split(m, L), m->stream))
-      return fail(SPK_ERR_HIP, "pack_weights launch failed");
+    int r;
+    if (L.d.kind == SPK_OP_DWCONV)
+      r = spk_launch_pack_tapmajor(m->P(L.p_w), m->dwpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.cout_p, m->stream);
+    else if (L.mode == CONV_MODE_STEM3)  // master layout [cout][kh][kw][cin]: rows = taps x 4 (cin padded to 4)
+      r = pack_stem3(m, L);
+    else if (L.cin_p != L.d.cin || L.cout_p != L.d.cout)
+      r = spk_launch_pack_padded(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.d.cin, L.cout_p,
+                                 L.cin_p, m->infer_dt, layer_split(m, L), m->stream);
+    else
+      r = spk_launch_pack_weights(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
+                                  L.mode, m->infer_dt, layer_split(m, L), m->stream);
+    if (r) return fail(SPK_ERR_HIP, "pack_weights launch failed");
   }
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
@@ -385,13 +444,17 @@ int spk_plan(spk_model* m, int n, int h, int w) {
     TDim o;
     switch (L.d.kind) {
       case SPK_OP_CONV:
+      case SPK_OP_DWCONV:
       case SPK_OP_MAXPOOL: {
         const int ih = in.h, iw = (L.d.src == 0) ? w : in.w;
         o.h = (ih + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
         o.w = (iw + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
-        o.c = L.d.cout;
+        o.c = L.cout_p;
+        o.c_log = L.d.kind == SPK_OP_MAXPOOL ? in.c_log : L.d.cout;
         o.bf16 = true;
         if (o.h < 1 || o.w < 1) return fail(SPK_ERR_ARG, "image too small for the network");
+        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && in.c != L.cin_p)
+          return fail(SPK_ERR_ARG, std::string("channel mismatch at ") + L.d.name);
         break;
       }
       case SPK_OP_GAVGPOOL: o = {1, 1, in.c, false}; break;
@@ -424,6 +487,15 @@ int spk_plan(spk_model* m, int n, int h, int w) {
       total += align256((size_t)d.h * d.w * d.c * 2 * n);
     }
   }
+  // squeeze-excitation scratch: pooled partial sums [n][chunks][c] + scales [n][c], largest layer
+  size_t se_floats = 0;
+  for (const Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_SE) continue;
+    const TDim& d = m->tdims[L.d.src];
+    se_floats = std::max(se_floats, (size_t)n * (spk_se_chunks(d.h * d.w) + 1) * d.c);
+  }
+  m->se_off = total;
+  total += align256(se_floats * 4);
   m->logits_off = total;
   total += align256((size_t)n * m->num_classes * 4);
   HIP_TRY(hipMalloc((void**)&m->arena, total));
@@ -454,6 +526,14 @@ static int micro_batch(spk_model* m, int n) {
 static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
+  if (L.mode == CONV_MODE_STEM3) {
+    const float* sc = m->scale_bias + L.sb_off;
+    if (spk_launch_stem3x3((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                           (bf16_t*)m->T(L.d.dst), nb, in.h, in.w, in.w, o.h, o.w, L.cout_p, L.d.relu, m->infer_dt,
+                           m->stream))
+      return fail(SPK_ERR_HIP, std::string("stem launch failed for ") + L.d.name);
+    return SPK_OK;
+  }
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.cfg = a.dma = -1;
@@ -465,9 +545,9 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   a.res_lo = L.d.res >= 0 ? (const bf16_t*)m->TLo(L.d.res) : nullptr;
   a.y_lo = (bf16_t*)m->TLo(L.d.dst);
   a.scale = m->scale_bias + L.sb_off;
-  a.bias = a.scale + L.d.cout;
+  a.bias = a.scale + L.cout_p;
   a.N = nb; a.H = in.h; a.W = in.w; a.Cin = in.c;
-  a.Ho = o.h; a.Wo = o.w; a.Cout = L.d.cout;
+  a.Ho = o.h; a.Wo = o.w; a.Cout = L.cout_p;
   a.kh = a.kw = L.d.k; a.stride = L.d.stride; a.pad = L.d.pad;
   a.M = nb * o.h * o.w;
   a.K = L.kpad;
@@ -475,7 +555,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   a.dt = m->infer_dt;
   a.splitw = layer_split(m, L);
   a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
-  a.w_bytes = (unsigned)((size_t)L.d.cout * L.kpad * 2 * (a.splitw ? 2 : 1));
+  a.w_bytes = (unsigned)((size_t)L.cout_p * L.kpad * 2 * (a.splitw ? 2 : 1));
   if (spk_conv_launch(a, L.mode, m->stream, nullptr))
     return fail(SPK_ERR_HIP, std::string("conv launch failed for ") + L.d.name);
   return SPK_OK;
@@ -486,6 +566,23 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
   const TDim& o = m->tdims[L.d.dst];
   switch (L.d.kind) {
     case SPK_OP_CONV: return run_conv_eval(m, L, nb);
+    case SPK_OP_DWCONV: {
+      const float* sc = m->scale_bias + L.sb_off;
+      if (spk_launch_dwconv((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                            (bf16_t*)m->T(L.d.dst), nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu,
+                            m->infer_dt, m->stream))
+        return fail(SPK_ERR_UNSUPPORTED, std::string("depthwise conv launch failed (fp16 eval only) for ") + L.d.name);
+      return SPK_OK;
+    }
+    case SPK_OP_SE: {
+      float* partial = (float*)((char*)m->arena + m->se_off);
+      float* scale = partial + (size_t)nb * spk_se_chunks(in.h * in.w) * in.c;
+      if (spk_launch_se((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), partial, scale, m->P(L.p_w),
+                        m->P(L.p_b), m->P(L.p_w2), m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,
+                        m->infer_dt, m->stream))
+        return fail(SPK_ERR_UNSUPPORTED, std::string("squeeze-excitation launch failed (fp16 eval only) for ") + L.d.name);
+      return SPK_OK;
+    }
     case SPK_OP_MAXPOOL:
       if (spk_launch_maxpool((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), nb, in.h, in.w,
                              in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, m->infer_dt, m->stream))
@@ -567,8 +664,9 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
   if (!m || !host || t <= 0 || t >= m->n_tensors || !m->arena || n > m->cap_n)
     return fail(SPK_ERR_ARG, "read_activation: bad arguments or no forward has run");
   const TDim& d = m->tdims[t];
+  const int cl = d.c_log > 0 ? d.c_log : d.c;  // the caller sees the logical channels only
   const size_t cnt = (size_t)n * d.h * d.w * d.c;
-  if ((int64_t)cnt != numel) return fail(SPK_ERR_ARG, "read_activation: size mismatch");
+  if ((int64_t)((size_t)n * d.h * d.w * cl) != numel) return fail(SPK_ERR_ARG, "read_activation: size mismatch");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (!d.bf16) {
@@ -580,7 +678,7 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
   for (int i = 0; i < n; ++i)
     for (int y = 0; y < d.h; ++y)
       for (int x = 0; x < d.w; ++x)
-        for (int c = 0; c < d.c; ++c) {
+        for (int c = 0; c < cl; ++c) {
           const bf16_t raw = tmp[(((size_t)i * d.h + y) * d.w + x) * d.c + c];
           float f;
           if (m->act_dt == DT_F16) {
@@ -591,7 +689,7 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
             const unsigned u = (unsigned)raw << 16;
             memcpy(&f, &u, 4);
           }
-          host[(((size_t)i * d.c + c) * d.h + y) * d.w + x] = f;
+          host[(((size_t)i * cl + c) * d.h + y) * d.w + x] = f;
         }
   return SPK_OK;
 }
@@ -660,6 +758,11 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
       snprintf(nm, sizeof nm, "%s", L.d.name);
     } else {
       by = in_b + out_b;
+      if (L.d.kind == SPK_OP_DWCONV || L.d.kind == SPK_OP_SE) {
+        if (L.d.kind == SPK_OP_DWCONV) fl = 2.0 * nb * o.h * o.w * (double)L.d.cout * L.d.k * L.d.k;
+        else by = 3 * in_b;  // pooled once, read and written once by the scale pass
+        snprintf(nm, sizeof nm, "%s", L.d.name);
+      } else
       snprintf(nm, sizeof nm, "%s@base.%d",
                L.d.kind == SPK_OP_MAXPOOL ? "maxpool" : (L.d.kind == SPK_OP_GAVGPOOL ? "avgpool" : "dropout"),
                L.d.child);

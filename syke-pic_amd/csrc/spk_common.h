@@ -58,7 +58,7 @@ template <int DT> __device__ __forceinline__ f32x4_t mfma16(const u32x4_t a, con
 //   minor), activations NHWC bf16, weights [Cout][K] bf16.
 // Epilogue: v = acc*scale[c] + bias[c] (+ residual) (ReLU) -> bf16.
 // ---------------------------------------------------------------------------
-enum { CONV_MODE_GENERIC = 0, CONV_MODE_STEM = 1, CONV_MODE_DGRAD = 2 };
+enum { CONV_MODE_GENERIC = 0, CONV_MODE_STEM = 1, CONV_MODE_DGRAD = 2, CONV_MODE_STEM3 = 3 /* 3x3/2 direct stem */ };
 
 struct ConvArgs {
   const bf16_t* x;      // [N,H,W,Cin]   (stem mode: Cin stored = 4)
@@ -104,6 +104,17 @@ int spk_launch_bn_fold(const float* g, const float* b, const float* mean, const 
                        float eps, float* scale, float* bias, int c, hipStream_t s);
 // master fp32 KRSC weights -> bf16 [Cout][K] (generic) or the stem image
 // splitw: out = [2][Cout][K], second half = remainder w - float(first half)
+// EfficientNet pieces (effnet.hip)
+int spk_launch_pack_padded(const float* w, bf16_t* out, int cout, int taps, int cin, int cout_p, int cin_p, int dt,
+                           int splitw, hipStream_t s);
+int spk_launch_pack_tapmajor(const float* w, float* out, int c, int rows, int c_p, hipStream_t s);
+int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
+                       int wid, int wstride, int ho, int wo, int c_p, int act, int dt, hipStream_t s);
+int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
+                      int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s);
+int spk_se_chunks(int hw);
+int spk_launch_se(const bf16_t* x, bf16_t* y, float* partial, float* scale, const float* w1, const float* b1,
+                  const float* w2, const float* b2, int n, int hw, int c, int c_p, int sq, int dt, hipStream_t s);
 int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
                             int mode, int dt, int splitw, hipStream_t s);
 

@@ -106,6 +106,9 @@ static void mark(spk_model* m, int phase) {
 }
 
 static int ensure_state(spk_model* m) {
+  if (m->eval_only)
+    return tfail(SPK_ERR_UNSUPPORTED,
+                 "this network (EfficientNet: depthwise / squeeze-excitation / SiLU layers) has an inference path only");
   if (m->train) return SPK_OK;
   TrainState* t = new TrainState();
   m->train = t;
@@ -231,6 +234,9 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
     return tfail(SPK_ERR_ARG, "train step: bad arguments (batch must be >= 2 for train-mode BatchNorm)");
   if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return tfail(SPK_ERR_ARG, "train step: dtype must be f32 or u8");
   HIP_TRY(hipSetDevice(m->device));
+  if (m->eval_only)
+    return tfail(SPK_ERR_UNSUPPORTED,
+                 "this network (EfficientNet: depthwise / squeeze-excitation / SiLU layers) has an inference path only");
   for (const Layer& L : m->layers)
     if (L.d.kind == SPK_OP_DROPOUT && L.d.p > 0.f)
       return tfail(SPK_ERR_UNSUPPORTED, "Dropout(p>0) in the head is not implemented on the MI355X training path yet");

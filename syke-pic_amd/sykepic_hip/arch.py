@@ -14,7 +14,8 @@ avgpool,fc``).  The graph is consumed by the C-ABI library
 
 from dataclasses import dataclass, field
 
-OP_CONV, OP_MAXPOOL, OP_GAVGPOOL, OP_LINEAR, OP_DROPOUT = 1, 2, 3, 4, 5
+OP_CONV, OP_MAXPOOL, OP_GAVGPOOL, OP_LINEAR, OP_DROPOUT, OP_DWCONV, OP_SE = 1, 2, 3, 4, 5, 6, 7
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2   # Op.relu (bool for the ResNets: True == ACT_RELU)
 
 _RESNETS = {
     "resnet18": ("basic", (2, 2, 2, 2)),
@@ -25,8 +26,29 @@ _RESNETS = {
 }
 
 
+# torchvision efficientnet_b0..b4: (width multiplier, depth multiplier); inference only on the MI355X path.
+# (b5-b7 use BatchNorm eps 1e-3 and are not built.)
+_EFFNETS = {
+    "efficientnet_b0": (1.0, 1.0),
+    "efficientnet_b1": (1.0, 1.1),
+    "efficientnet_b2": (1.1, 1.2),
+    "efficientnet_b3": (1.2, 1.4),
+    "efficientnet_b4": (1.4, 1.8),
+}
+# expand ratio, kernel, stride, input channels, output channels, layers (B0 baseline; Tan & Le 2019, table 1)
+_MBCONV = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3),
+           (6, 5, 1, 80, 112, 3), (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+
+
 def supported_networks():
-    return sorted(_RESNETS)
+    return sorted(_RESNETS) + sorted(_EFFNETS)
+
+
+def _make_divisible(v, divisor=8):
+    new_v = max(divisor, int(v + divisor / 2) // divisor * divisor)
+    if new_v < 0.9 * v:
+        new_v += divisor
+    return new_v
 
 
 @dataclass
@@ -59,8 +81,81 @@ class Graph:
     head_modules: list = field(default_factory=list)  # [("linear", i, in, out) | ("dropout", i, p)]
 
 
+def _add_head(g, ops, new_t, cur, feat, num_classes, head, dropout):
+    """Linear(feat->h0) ... Linear(h[-1]->num_classes), no activations; Dropout
+    inserted by *list index* exactly as list.insert does (reference network.py:56-61)."""
+    widths = [feat] + [int(h) for h in head] + [num_classes]
+    mods = [("linear", widths[i], widths[i + 1]) for i in range(len(widths) - 1)]
+    for idx, p in dropout:
+        mods.insert(int(idx), ("dropout", float(p)))
+    n_lin = sum(1 for m in mods if m[0] == "linear")
+    seen = 0
+    for i, m in enumerate(mods):
+        d = new_t()
+        if m[0] == "linear":
+            seen += 1
+            ops.append(Op(OP_LINEAR, f"head.{i}", "", m[1], m[2], 1, 1, 0, False, cur, d, -1, -1, seen == n_lin))
+            g.head_modules.append(("linear", i, m[1], m[2]))
+        else:
+            ops.append(Op(OP_DROPOUT, f"head.{i}", "", 0, 0, 1, 1, 0, False, cur, d, -1, -1, False, m[1]))
+            g.head_modules.append(("dropout", i, m[1]))
+        cur = d
+    return cur
+
+
+def _build_efficientnet(network, num_classes, head, dropout, in_chans):
+    """torchvision EfficientNet: children [features, avgpool, classifier]; the reference keeps
+    [features, avgpool] as ``base`` and reads ``in_features`` off the classifier's Linear
+    (network.py:50-55).  state_dict keys: base.0.<i>... for features[i]."""
+    wm, dm = _EFFNETS[network]
+    ch = lambda c: _make_divisible(c * wm)
+    import math
+    g = Graph(network, in_chans, num_classes, 4 * ch(320), n_base_children=2)
+    ops = g.ops
+    t = [0]
+
+    def new_t():
+        t[0] += 1
+        return t[0]
+
+    cur = new_t()
+    ops.append(Op(OP_CONV, "base.0.0.0", "base.0.0.1", in_chans, ch(32), 3, 2, 1, ACT_SILU, 0, cur, -1, 0))
+    for si, (ratio, k, stride, cin, cout, n) in enumerate(_MBCONV):
+        cin, cout, n = ch(cin), ch(cout), int(math.ceil(n * dm))
+        for b in range(n):
+            bi, bs = (cin, stride) if b == 0 else (cout, 1)
+            pre = f"base.0.{si + 1}.{b}.block"
+            exp = _make_divisible(bi * ratio)
+            x_in, j = cur, 0
+            if exp != bi:
+                d = new_t()
+                ops.append(Op(OP_CONV, f"{pre}.{j}.0", f"{pre}.{j}.1", bi, exp, 1, 1, 0, ACT_SILU, cur, d, -1, 0))
+                cur, j = d, j + 1
+            d = new_t()
+            ops.append(Op(OP_DWCONV, f"{pre}.{j}.0", f"{pre}.{j}.1", exp, exp, k, bs, (k - 1) // 2, ACT_SILU, cur, d,
+                          -1, 0))
+            cur, j = d, j + 1
+            d = new_t()
+            ops.append(Op(OP_SE, f"{pre}.{j}", "", exp, exp, max(1, bi // 4), 1, 0, ACT_NONE, cur, d, -1, 0))
+            cur, j = d, j + 1
+            d = new_t()
+            res = x_in if (bs == 1 and bi == cout) else -1
+            ops.append(Op(OP_CONV, f"{pre}.{j}.0", f"{pre}.{j}.1", exp, cout, 1, 1, 0, ACT_NONE, cur, d, res, 0,
+                          res >= 0))
+            cur = d
+    d = new_t()
+    ops.append(Op(OP_CONV, "base.0.8.0", "base.0.8.1", ch(320), 4 * ch(320), 1, 1, 0, ACT_SILU, cur, d, -1, 0))
+    cur = d
+    d = new_t()
+    ops.append(Op(OP_GAVGPOOL, "", "", g.feat, g.feat, 0, 1, 0, False, cur, d, -1, 1))
+    _add_head(g, ops, new_t, d, g.feat, num_classes, head, dropout)
+    return g
+
+
 def build_graph(network, num_classes, head=(256, 128), dropout=(), in_chans=3):
-    """Mirror of ``TorchVisionNet.__init__`` for the ResNet family."""
+    """Mirror of ``TorchVisionNet.__init__`` (ResNet and EfficientNet-B0..B4 families)."""
+    if network in _EFFNETS:
+        return _build_efficientnet(network, num_classes, list(head), list(dropout), in_chans)
     if network not in _RESNETS:
         raise ValueError(
             f"network {network!r} has no MI355X path yet; supported: {supported_networks()}"
@@ -167,6 +262,21 @@ def param_specs(g):
             return 0
         return 1 if ".downsample." in op.name else 0
 
+    if g.network in _EFFNETS:   # graph order == module order == state_dict order
+        for op in g.ops:
+            if op.kind in (OP_CONV, OP_DWCONV):
+                cin1 = 1 if op.kind == OP_DWCONV else op.cin
+                specs.append((f"{op.name}.weight", (op.cout, cin1, op.k, op.k), "conv_w"))
+                bn(op.bn, op.cout, op.last_bn)
+            elif op.kind == OP_SE:
+                specs.append((f"{op.name}.fc1.weight", (op.k, op.cin, 1, 1), "se_w"))
+                specs.append((f"{op.name}.fc1.bias", (op.k,), "se_b"))
+                specs.append((f"{op.name}.fc2.weight", (op.cout, op.k, 1, 1), "se_w"))
+                specs.append((f"{op.name}.fc2.bias", (op.cout,), "se_b"))
+            elif op.kind == OP_LINEAR:
+                specs.append((f"{op.name}.weight", (op.cout, op.cin), "fc_w_last" if op.last_bn else "fc_w"))
+                specs.append((f"{op.name}.bias", (op.cout,), "fc_b"))
+        return specs
     convs = [op for op in g.ops if op.kind == OP_CONV]
     blocks = {}
     ordered = []
@@ -198,12 +308,14 @@ def conv_flops_per_image(g, h, w):
     total = 0
     for op in g.ops:
         ih, iw = dims.get(op.src, (1, 1))
-        if op.kind in (OP_CONV, OP_MAXPOOL):
+        if op.kind in (OP_CONV, OP_MAXPOOL, OP_DWCONV):
             oh = (ih + 2 * op.pad - op.k) // op.stride + 1
             ow = (iw + 2 * op.pad - op.k) // op.stride + 1
             dims[op.dst] = (oh, ow)
             if op.kind == OP_CONV:
                 total += 2 * oh * ow * op.cout * op.cin * op.k * op.k
+            elif op.kind == OP_DWCONV:
+                total += 2 * oh * ow * op.cout * op.k * op.k
         elif op.kind == OP_GAVGPOOL:
             dims[op.dst] = (1, 1)
         elif op.kind == OP_LINEAR:

@@ -206,6 +206,24 @@ class HipNet:
             return HipLeaf(op.bn, "bn", [P(op.bn + ".weight", True), P(op.bn + ".bias", True)],
                            f"BatchNorm2d({op.cout}, eps=1e-05, momentum=0.1)")
 
+        if g.n_base_children == 2:   # EfficientNet: base = [features, avgpool]; flat leaf list under features
+            leaves = []
+            for op in g.ops:
+                if op.kind in (arch.OP_CONV, arch.OP_DWCONV):
+                    grp = f", groups={op.cin}" if op.kind == arch.OP_DWCONV else ""
+                    leaves.append(HipLeaf(op.name, "conv", [P(op.name + ".weight", False)],
+                                          f"Conv2d({op.cin}, {op.cout}, kernel_size=({op.k}, {op.k}), "
+                                          f"stride=({op.stride}, {op.stride}), padding=({op.pad}, {op.pad}){grp}, bias=False)"))
+                    leaves.append(bn_leaf(op))
+                elif op.kind == arch.OP_SE:
+                    for fc, (a, b) in (("fc1", (op.cin, op.k)), ("fc2", (op.k, op.cout))):
+                        leaves.append(HipLeaf(f"{op.name}.{fc}", "conv",
+                                              [P(f"{op.name}.{fc}.weight", False), P(f"{op.name}.{fc}.bias", False)],
+                                              f"Conv2d({a}, {b}, kernel_size=(1, 1), stride=(1, 1))"))
+            self.base = HipSequential([HipSequential(leaves),
+                                       HipLeaf("base.1", "avgpool", [], "AdaptiveAvgPool2d(output_size=1)")])
+            self._finish_views(g, P)
+            return
         children = [None] * g.n_base_children
         convs = [op for op in g.ops if op.kind == arch.OP_CONV]
         stem = convs[0]
@@ -233,6 +251,9 @@ class HipNet:
             children[child] = HipSequential(items)
         children[8] = HipLeaf("base.8", "avgpool", [], "AdaptiveAvgPool2d(output_size=1)")
         self.base = HipSequential(children)
+        self._finish_views(g, P)
+
+    def _finish_views(self, g, P):
         head_items = []
         for mod in g.head_modules:
             if mod[0] == "linear":

@@ -84,7 +84,7 @@ def synth_state_dict(param_specs, seed=2, logit_gain=60.0):
 
     kinds: conv_w, bn_w, bn_w_last (last BN of a residual block: small gamma
     so the residual stream keeps O(1) variance through 16 blocks), bn_b,
-    bn_mean, bn_var, bn_nbt, fc_w, fc_w_last, fc_b.
+    bn_mean, bn_var, bn_nbt, fc_w, fc_w_last, fc_b, se_w, se_b.
     """
     out = {}
     for key, shape, kind in param_specs:
@@ -110,6 +110,11 @@ def synth_state_dict(param_specs, seed=2, logit_gain=60.0):
             v = uniform(shape, s, -b, b)
         elif kind == "fc_b":
             v = uniform(shape, s, -0.05, 0.05)
+        elif kind == "se_w":   # squeeze-excitation 1x1 convs [out, in, 1, 1]
+            b = float(np.sqrt(6.0 / shape[1]))
+            v = uniform(shape, s, -b, b)
+        elif kind == "se_b":
+            v = uniform(shape, s, -0.5, 0.5)
         else:
             raise ValueError(f"unknown param kind {kind!r}")
         out[key] = v

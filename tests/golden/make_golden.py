@@ -78,21 +78,31 @@ def ref_config(network, shape):
     return cfg
 
 
-def build_ref_net(network, num_classes, seed):
+def build_ref_net(network, num_classes, seed, logit_gain=60.0):
     from sykepic.train.config import get_network
     net = get_network(ref_config(network, (3, 224, 224)), num_classes)
     g = arch.build_graph(network, num_classes)
-    sd = synth.synth_state_dict(arch.param_specs(g), seed=seed)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=seed, logit_gain=logit_gain)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     return net
 
 
-def golden_net_pass():
+def golden_net_pass(effnet=False):
+    """effnet=True: the EfficientNet cases (SURVEY.md section 4 golden (1)), written to their own file so
+    that the ResNet fixture stays byte-identical."""
     from sykepic.compute.probability import net_pass
     out = {}
     cases = [("resnet18", 180, 8), ("resnet18", 224, 8), ("resnet50", 224, 8)]
+    if effnet:
+        cases = [("efficientnet_b0", 224, 8), ("efficientnet_b4", 224, 8)]
     for network, hw, n in cases:
         net = build_ref_net(network, 50, seed=2)
+        if effnet:
+            # BatchNorm running statistics := statistics of the calibration batch (as a trained net's match
+            # its data): keeps the activations of the 32-block random-weight net O(1) at every depth.  The
+            # tests repeat this with oracle.refnet.calibrate_bn on the same generator-seeded batch.
+            from oracle import refnet
+            refnet.calibrate_bn(net, torch.from_numpy(synth.synth_images(16, 3, hw, hw, seed=99)))
         # centre the logits on a calibration batch so that the arg-max varies
         # from image to image (a random-weight net otherwise always favours
         # one class); the shift is stored and re-applied by the tests.
@@ -117,7 +127,7 @@ def golden_net_pass():
             net.eval()
             out[f"{tag}_logits"] = net(x).numpy()
         print(tag, "top1", out[f"{tag}_probs"].argmax(1), "pmax", out[f"{tag}_probs"].max(1))
-    np.savez_compressed(HERE / "net_pass.npz", **out)
+    np.savez_compressed(HERE / ("net_pass_effnet.npz" if effnet else "net_pass.npz"), **out)
 
 
 class SnapshotLoader:
@@ -262,6 +272,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["net_pass", "train", "sched", "pred"]
     if "net_pass" in which:
         golden_net_pass()
+    if "effnet" in which:
+        golden_net_pass(effnet=True)
     if "train" in which:
         for name in ("SGD", "Adam"):
             with tempfile.TemporaryDirectory() as tmp:

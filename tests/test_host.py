@@ -25,7 +25,25 @@ def test_state_dict_layout_matches_torch_module():
             assert sum(int(np.prod(s)) for k, s, kind in specs if not kind.startswith(("bn_mean", "bn_var", "bn_nbt"))) == nparams
     assert abs(arch.conv_flops_per_image(arch.build_graph("resnet50", 50), 224, 224) - 8.175e9) < 5e6
     with pytest.raises(ValueError):
-        arch.build_graph("efficientnet_b4", 50)
+        arch.build_graph("efficientnet_b7", 50)   # BatchNorm eps 1e-3 variants are not built
+
+
+def test_efficientnet_graph_matches_torch_module():
+    """state_dict layout, MAC count (1.396 G dense + 0.1024 G depthwise for B4) and the
+    block structure of the EfficientNet graphs."""
+    for network in ("efficientnet_b0", "efficientnet_b4"):
+        g = arch.build_graph(network, 50)
+        specs = arch.param_specs(g)
+        ref = refnet.RefNet(network, 50).state_dict()
+        assert [k for k, _, _ in specs] == list(ref.keys())
+        assert all(tuple(ref[k].shape) == tuple(s) for k, s, _ in specs)
+    g = arch.build_graph("efficientnet_b4", 50)
+    assert g.feat == 1792 and g.n_base_children == 2
+    assert sum(1 for op in g.ops if op.kind == arch.OP_SE) == 32
+    assert sum(1 for op in g.ops if op.kind == arch.OP_DWCONV) == 32
+    assert sorted({op.cin for op in g.ops if op.kind == arch.OP_DWCONV}) == [24, 48, 144, 192, 336, 672, 960, 1632, 2688]
+    macs = arch.conv_flops_per_image(g, 224, 224) / 2
+    assert abs(macs - 1.4993e9) < 1e6
 
 
 def test_dropout_index_semantics():

@@ -39,6 +39,30 @@ def test_net_pass_matches_reference(golden_dir, network, hw):
     assert np.abs(z.numpy() - gold[f"{tag}_logits"]).max() < 2e-3 * np.abs(gold[f"{tag}_logits"]).max()
 
 
+@pytest.mark.parametrize("network", ["efficientnet_b0", "efficientnet_b4"])
+def test_efficientnet_net_pass_matches_reference(golden_dir, network):
+    """EfficientNet (torchvision MBConv topology restated in oracle/backbones.py; parameter
+    counts below are the published ones) through the reference's TorchVisionNet + net_pass."""
+    from effnet_util import calibrated_state
+    from oracle import backbones
+    published = {"efficientnet_b0": 5288548, "efficientnet_b4": 19341616}
+    assert sum(p.numel() for p in backbones.make(network).parameters()) == published[network]
+    gold = np.load(golden_dir / "net_pass_effnet.npz")
+    tag = f"{network}_224"
+    g, sd, net = calibrated_state(network, 224, gold)
+    assert [k for k, _, _ in arch.param_specs(g)] == list(net.state_dict().keys())
+    rois = gold[f"{tag}_rois_in"].tolist()
+    n = len(rois)
+    x = torch.from_numpy(synth.synth_images(n, 3, 224, 224, seed=0))
+    paths = [f"/x/D20180712T065600_IFCB114_{r:05d}.png" for r in rois]
+    res = refnet.net_pass(net, [(x[: n // 2], paths[: n // 2]), (x[n // 2:], paths[n // 2:])])
+    assert [r for r, _ in res] == gold[f"{tag}_rois_out"].tolist()
+    p = np.array([q for _, q in res])
+    # the BatchNorm calibration is recomputed here: allow for its float round-off
+    assert np.abs(p - gold[f"{tag}_probs"]).max() < 2e-5
+    assert (p.argmax(1) == gold[f"{tag}_probs"].argmax(1)).all()
+
+
 @pytest.mark.parametrize("optim_name", ["SGD", "Adam"])
 def test_train_steps_match_reference(golden_dir, optim_name):
     """3 epochs x 1 batch with LRWarmup steps at epochs 1,2,3 (one step per

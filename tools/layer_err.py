@@ -11,9 +11,18 @@ from oracle import graph_eval
 network, hw, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 g = arch.build_graph(network, 50)
 sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+if network.startswith("efficientnet"):   # calibrated BatchNorm statistics (tests/effnet_util.py)
+    from oracle import refnet
+    ref = refnet.load_numpy_state(refnet.RefNet(network, 50), sd)
+    refnet.calibrate_bn(ref, torch.from_numpy(synth.synth_images(16, 3, hw, hw, seed=99)))
+    sd = {k: v.numpy().copy() for k, v in ref.state_dict().items()}
+if len(sys.argv) > 4:
+    pass
 net = HipNet(network, 50, weights=None)
 net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
 net.eval()
+if len(sys.argv) > 4:
+    net.set_precision(split_weights=int(sys.argv[4]))
 x = synth.synth_images(n, 3, hw, hw, seed=0)
 tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
 acts = graph_eval.run(g, tsd, torch.from_numpy(x))
