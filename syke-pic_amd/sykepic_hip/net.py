@@ -222,7 +222,7 @@ class HipNet:
                                               f"Conv2d({a}, {b}, kernel_size=(1, 1), stride=(1, 1))"))
             self.base = HipSequential([HipSequential(leaves),
                                        HipLeaf("base.1", "avgpool", [], "AdaptiveAvgPool2d(output_size=1)")])
-            self._finish_views(g, P)
+            HipNet._finish_views(self, g, P)
             return
         children = [None] * g.n_base_children
         convs = [op for op in g.ops if op.kind == arch.OP_CONV]
@@ -251,7 +251,7 @@ class HipNet:
             children[child] = HipSequential(items)
         children[8] = HipLeaf("base.8", "avgpool", [], "AdaptiveAvgPool2d(output_size=1)")
         self.base = HipSequential(children)
-        self._finish_views(g, P)
+        HipNet._finish_views(self, g, P)
 
     def _finish_views(self, g, P):
         head_items = []
