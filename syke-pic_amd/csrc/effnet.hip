@@ -11,6 +11,8 @@
 // All of these are HBM-bound passes: 16-B per-lane accesses, channels innermost.
 #include "spk_common.h"
 
+#include <algorithm>
+
 namespace {
 
 template <int DT>
@@ -59,171 +61,202 @@ __global__ void pack_tapmajor_kernel(const float* __restrict__ w, float* __restr
   out[i] = ch < c ? w[(size_t)ch * rows + r] : 0.f;
 }
 
-// 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 8 output channels of
-// one output pixel; weights [9 taps][4 ch][c_p] fp32 (exact fp32 products of the 16-bit image).
-template <int DT>
-__global__ void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                               const float* __restrict__ scale, const float* __restrict__ bias,
-                               bf16_t* __restrict__ y, int n, int h, int wid, int wstride, int ho, int wo, int c_p,
-                               int act) {
-  const int c8 = c_p >> 3;
-  const size_t total = (size_t)n * ho * wo * c8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % c8);
-    size_t p = i / c8;
-    const int ox = (int)(p % wo);
-    p /= wo;
-    const int oy = (int)(p % ho), img = (int)(p / ho);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 16 output channels of
+// one output pixel (27 image values in registers, the weights from LDS, two 16-B stores); exact fp32
+// products of the 16-bit image.
+template <int DT, int CP>
+__global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ bias, bf16_t* __restrict__ y, int n,
+                                                      int h, int wid, int wstride, int ho, int wo, int act) {
+  constexpr int G = CP / 16;  // threads per pixel
+  __shared__ __attribute__((aligned(16))) float sw[29 * CP];  // [27 (tap, channel)][CP], scale[CP], bias[CP]
+  for (int i = threadIdx.x; i < 27 * CP; i += 256) {
+    const int k = i / CP, c = i - k * CP;          // k = tap*3 + channel
+    sw[i] = w[(size_t)((k / 3) * 4 + k % 3) * CP + c];  // source rows are [tap][4 channels]
+  }
+  for (int i = threadIdx.x; i < CP; i += 256) {
+    sw[27 * CP + i] = scale[i];
+    sw[28 * CP + i] = bias[i];
+  }
+  __syncthreads();
+  const unsigned total = (unsigned)n * ho * wo * G;  // < 2^31 (checked by the launcher): 32-bit index math
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % G) * 16;
+    unsigned p = i / G;
+    const size_t pix = p;
+    const int ox = (int)(p % (unsigned)wo);
+    p /= (unsigned)wo;
+    const int oy = (int)(p % (unsigned)ho), img = (int)(p / (unsigned)ho);
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int iy = 2 * oy - 1 + r;
-      if ((unsigned)iy >= (unsigned)h) continue;
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int ix = 2 * ox - 1 + s;
-        if ((unsigned)ix >= (unsigned)wid) continue;
-        const uint2 px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
-        const float ch[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
+      for (int q = 0; q < 3; ++q) {
+        const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
+        uint2 px = {0u, 0u};
+        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wid)
+          px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
+        const float xin[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float* wp = w + (size_t)((r * 3 + s) * 4 + c) * c_p + cg * 8;
-          const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
+          const float* wp = sw + ((r * 3 + q) * 3 + c) * CP + c0;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[j] += ch[c] * w0[j];
-            acc[4 + j] += ch[c] * w1[j];
+          for (int v = 0; v < 4; ++v) {
+            const f32x4_t wv = *(const f32x4_t*)(wp + 4 * v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[4 * v + j] += xin[c] * wv[j];
           }
         }
       }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = act_f(acc[j] * scale[cg * 8 + j] + bias[cg * 8 + j], act);
-    *(u32x4_t*)(y + i * 8) = pack8f<DT>(acc);
+    for (int j = 0; j < 16; ++j) acc[j] = act_f(acc[j] * sw[27 * CP + c0 + j] + sw[28 * CP + c0 + j], act);
+    *(u32x4_t*)(y + pix * CP + c0) = pack8f<DT>(acc);
+    *(u32x4_t*)(y + pix * CP + c0 + 8) = pack8f<DT>(acc + 8);
   }
 }
 
-// depthwise KxK conv + folded BN + activation; one thread = 8 channels of one output pixel
+// depthwise KxK conv + folded BN + activation.  One block = one pixel chunk of ONE image x one tile of up
+// to 256 channels: the tile's K*K x 256 weights, scales and shifts sit in LDS; a thread owns 8 channels and
+// walks the chunk's pixels; lanes of a wave cover consecutive channel groups (contiguous 16-B accesses).
+// The per-channel sums of the block's outputs (fp32, before the 16-bit rounding) are reduced over the block
+// in fixed order and written as the squeeze-excitation pool partial [img][chunk][c_p].
 template <int DT, int K>
-__global__ void dwconv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                              const float* __restrict__ scale, const float* __restrict__ bias,
-                              bf16_t* __restrict__ y, int n, int h, int wid, int c_p, int ho, int wo, int stride,
-                              int act) {
+__global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                     float* __restrict__ partial, int h, int wid, int c_p, int ho,
+                                                     int wo, int stride, int act, int chunks) {
   constexpr int PAD = (K - 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [K*K + 2][tc]; reused for the pool reduce
+  const int img = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
   const int c8 = c_p >> 3;
-  const size_t total = (size_t)n * ho * wo * c8;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % c8);
-    size_t p = i / c8;
-    const int ox = (int)(p % wo);
-    p /= wo;
-    const int oy = (int)(p % ho), img = (int)(p / ho);
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int cg0 = blockIdx.x * 32;
+  const int ncg = min(32, c8 - cg0), tc = ncg * 8;
+  for (int i = threadIdx.x; i < (K * K + 2) * tc; i += 256) {
+    const int r = i / tc, c = i - r * tc;
+    sm[i] = r < K * K ? w[(size_t)r * c_p + cg0 * 8 + c]
+                      : (r == K * K ? scale[cg0 * 8 + c] : bias[cg0 * 8 + c]);
+  }
+  __syncthreads();
+  const int rows = 256 / ncg;  // pixel lanes
+  const int cg = threadIdx.x % ncg, prow = threadIdx.x / ncg;
+  const int hw = ho * wo, per = (hw + chunks - 1) / chunks;
+  const int p0 = chunk * per, p1 = min(hw, p0 + per);
+  float pool[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (prow < rows) {
+    const float* wl = sm + cg * 8;
+    for (int p = p0 + prow; p < p1; p += rows) {
+      const int oy = p / wo, ox = p - oy * wo;
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int r = 0; r < K; ++r) {
-      const int iy = oy * stride - PAD + r;
-      if ((unsigned)iy >= (unsigned)h) continue;
+      for (int r = 0; r < K; ++r) {
+        const int iy = oy * stride - PAD + r;
+        if ((unsigned)iy >= (unsigned)h) continue;
 #pragma unroll
-      for (int s = 0; s < K; ++s) {
-        const int ix = ox * stride - PAD + s;
-        if ((unsigned)ix >= (unsigned)wid) continue;
-        float xv[8];
-        unpack8f<DT>(*(const u32x4_t*)(x + (((size_t)img * h + iy) * wid + ix) * c_p + cg * 8), xv);
-        const float* wp = w + (size_t)(r * K + s) * c_p + cg * 8;
-        const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
+        for (int q = 0; q < K; ++q) {
+          const int ix = ox * stride - PAD + q;
+          if ((unsigned)ix >= (unsigned)wid) continue;
+          float xv[8];
+          unpack8f<DT>(*(const u32x4_t*)(x + (((size_t)img * h + iy) * wid + ix) * c_p + (cg0 + cg) * 8), xv);
+          const f32x4_t w0 = *(const f32x4_t*)(wl + (r * K + q) * tc), w1 = *(const f32x4_t*)(wl + (r * K + q) * tc + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[j] += xv[j] * w0[j];
-          acc[4 + j] += xv[4 + j] * w1[j];
+          for (int j = 0; j < 4; ++j) {
+            acc[j] += xv[j] * w0[j];
+            acc[4 + j] += xv[4 + j] * w1[j];
+          }
         }
       }
-    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = act_f(acc[j] * scale[cg * 8 + j] + bias[cg * 8 + j], act);
-    *(u32x4_t*)(y + i * 8) = pack8f<DT>(acc);
-  }
-}
-
-// squeeze: per-image, per-channel sums of a pixel chunk -> partial[img][chunk][c_p] (ordered two-stage sum)
-template <int DT>
-__global__ __launch_bounds__(256) void se_pool_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial,
-                                                      int hw, int c_p, int chunks) {
-  extern __shared__ float sm[];  // [rows in flight][c_p]
-  const int img = blockIdx.y, chunk = blockIdx.x;
-  const int c8 = c_p >> 3;
-  const int tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
-  const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
-  const int per = (hw + chunks - 1) / chunks;
-  const int p0 = chunk * per, p1 = min(hw, p0 + per);
-  if (lane_r < rif) {
-    for (int cg = lane_c; cg < c8; cg += tpr) {
-      float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      for (int p = p0 + lane_r; p < p1; p += rif) {
-        float v[8];
-        unpack8f<DT>(*(const u32x4_t*)(x + ((size_t)img * hw + p) * c_p + cg * 8), v);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += v[j];
+      for (int j = 0; j < 8; ++j) {
+        acc[j] = act_f(acc[j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j], act);
+        pool[j] += acc[j];
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) sm[lane_r * c_p + cg * 8 + j] = s[j];
+      *(u32x4_t*)(y + ((size_t)img * hw + p) * c_p + (cg0 + cg) * 8) = pack8f<DT>(acc);
     }
   }
+  if (!partial) return;
+  __syncthreads();  // weights are dead: the buffer becomes [rows][tc] pool partials
+  if (prow < rows) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm[prow * tc + cg * 8 + j] = pool[j];
+  }
   __syncthreads();
-  for (int c = threadIdx.x; c < c_p; c += 256) {
+  for (int c = threadIdx.x; c < tc; c += 256) {
     float t = 0.f;
-    for (int r = 0; r < rif; ++r) t += sm[r * c_p + c];
-    partial[((size_t)img * chunks + chunk) * c_p + c] = t;
+    for (int r = 0; r < rows; ++r) t += sm[r * tc + c];
+    partial[((size_t)img * chunks + chunk) * c_p + cg0 * 8 + c] = t;
   }
 }
 
-// excitation: s = sigmoid(W2 silu(W1 avg + b1) + b2); one block per image; scale[img][c_p] (0 on padding)
-__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
-                                                    const float* __restrict__ w1, const float* __restrict__ b1,
-                                                    const float* __restrict__ w2, const float* __restrict__ b2,
-                                                    float* __restrict__ scale, int c, int c_p, int sq) {
-  extern __shared__ float sm[];  // avg[c_p], hid[sq]
-  float* avg = sm;
-  float* hid = sm + c_p;
-  const int img = blockIdx.x;
-  for (int i = threadIdx.x; i < c_p; i += 256) {
-    float t = 0.f;
-    for (int k = 0; k < chunks; ++k) t += partial[((size_t)img * chunks + k) * c_p + i];
-    avg[i] = t * inv_hw;
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = wave; j < sq; j += 4) {  // one wave per hidden unit: lanes stride the channels
-    float t = 0.f;
-    for (int i = lane; i < c; i += 64) t += w1[(size_t)j * c + i] * avg[i];
+// excitation, part 1: hid = silu(W1 avg + b1).  Block (img, 4 hidden units): all 256 threads stride the channels
+// (the pooled mean is summed from the depthwise kernel's chunk partials on the fly), so every thread has
+// 4 x c/256 independent weight loads in flight; fixed-order shuffle + LDS reduction.  hid[img][sq].
+__global__ __launch_bounds__(256) void se_fc1_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
+                                                     const float* __restrict__ w1, const float* __restrict__ b1,
+                                                     float* __restrict__ hid, int c, int c_p, int sq) {
+  __shared__ float red[4][4];
+  const int img = blockIdx.x, j0 = blockIdx.y * 4;
+  float t[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < c; i += 256) {
+    float a = 0.f;
+    for (int k = 0; k < chunks; ++k) a += partial[((size_t)img * chunks + k) * c_p + i];
+    a *= inv_hw;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    if (lane == 0) {
-      t += b1[j];
-      hid[j] = t / (1.f + __expf(-t));
-    }
+    for (int q = 0; q < 4; ++q)
+      if (j0 + q < sq) t[q] += w1[(size_t)(j0 + q) * c + i] * a;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t[q] += __shfl_xor(t[q], o, 64);
+    if (lane == 0) red[wave][q] = t[q];
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < c_p; i += 256) {
-    float s = 0.f;
-    if (i < c) {
-      float t = b2[i];
-      for (int j = 0; j < sq; ++j) t += w2[(size_t)i * sq + j] * hid[j];
-      s = 1.f / (1.f + __expf(-t));
-    }
-    scale[(size_t)img * c_p + i] = s;
+  if (threadIdx.x < 4 && j0 + threadIdx.x < sq) {
+    const int q = threadIdx.x;
+    const float v = red[0][q] + red[1][q] + red[2][q] + red[3][q] + b1[j0 + q];
+    hid[(size_t)img * sq + j0 + q] = v / (1.f + __expf(-v));
   }
+}
+
+// excitation, part 2: s = sigmoid(W2 hid + b2); thread = channel, fc2 weights transposed ([sq][c_p]: coalesced);
+// scale[img][c_p] (0 on padding)
+__global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hid, const float* __restrict__ w2t,
+                                                     const float* __restrict__ b2, float* __restrict__ scale, int c,
+                                                     int c_p, int sq) {
+  extern __shared__ float sh[];  // hid[sq]
+  const int img = blockIdx.x;
+  for (int j = threadIdx.x; j < sq; j += 256) sh[j] = hid[(size_t)img * sq + j];
+  __syncthreads();
+  const int i = blockIdx.y * 256 + threadIdx.x;
+  if (i >= c_p) return;
+  float s = 0.f;
+  if (i < c) {
+    float t = b2[i];
+#pragma unroll 8
+    for (int j = 0; j < sq; ++j) t += w2t[(size_t)j * c_p + i] * sh[j];
+    s = 1.f / (1.f + __expf(-t));
+  }
+  scale[(size_t)img * c_p + i] = s;
 }
 
 template <int DT>
 __global__ void se_scale_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale,
-                                bf16_t* __restrict__ y, size_t total8, int hw, int c_p) {
-  const int c8 = c_p >> 3;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total8; i += (size_t)gridDim.x * blockDim.x) {
-    const int cg = (int)(i % c8);
-    const size_t img = i / c8 / hw;
+                                bf16_t* __restrict__ y, int hw, int c_p) {
+  // one block row (blockIdx.y) per image: no 64-bit divisions in the loop
+  const unsigned c8 = c_p >> 3, per_img = (unsigned)hw * c8;
+  const size_t base = (size_t)blockIdx.y * per_img;
+  for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < per_img; k += gridDim.x * blockDim.x) {
+    const unsigned cg = k % c8;
+    const size_t i = base + k;
     float v[8];
     unpack8f<DT>(*(const u32x4_t*)(x + i * 8), v);
-    const float* s = scale + img * c_p + cg * 8;
+    const float* s = scale + (size_t)blockIdx.y * c_p + cg * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= s[j];
     *(u32x4_t*)(y + i * 8) = pack8f<DT>(v);
@@ -257,36 +290,51 @@ int spk_launch_pack_tapmajor(const float* w, float* out, int c, int rows, int c_
 
 int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
                        int wid, int wstride, int ho, int wo, int c_p, int act, int dt, hipStream_t s) {
-  const int g = grid_for((size_t)n * ho * wo * (c_p / 8), 256);
-  DT_DISPATCH(dt,
-              hipLaunchKernelGGL(stem3x3_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, wstride, ho, wo, c_p, act),
-              hipLaunchKernelGGL(stem3x3_kernel<DT_F16>, dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, wstride, ho, wo, c_p, act));
+  if (c_p != 64 || dt != DT_F16 || (size_t)n * ho * wo * 4 >= ((size_t)1 << 31)) return -2;  // B0..B4 stems pad to 64
+  const int g = grid_for((size_t)n * ho * wo * 4, 256);
+  hipLaunchKernelGGL((stem3x3_kernel<DT_F16, 64>), dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, wstride, ho,
+                     wo, act);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
-                      int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s) {
+// chunks of one image's output pixels (same value at planning and at launch): enough blocks to fill the chip
+int spk_dw_chunks(int n, int hw, int c_p) {
+  const int ctiles = (c_p / 8 + 31) / 32;
+  int chunks = 1;
+  while (chunks < 64 && (long)n * ctiles * chunks < 2048 && hw / (chunks * 2) >= 16) chunks *= 2;
+  return chunks;
+}
+
+int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, float* partial,
+                      int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s) {
   if ((k != 3 && k != 5) || dt != DT_F16) return -2;
-  const int g = grid_for((size_t)n * ho * wo * (c_p / 8), 256);
+  const int chunks = spk_dw_chunks(n, ho * wo, c_p);
+  const int c8 = c_p / 8, ctiles = (c8 + 31) / 32;
+  const int tc = (c8 < 32 ? c8 : 32) * 8;
+  const size_t lds = (size_t)std::max((k * k + 2) * tc, 256 / (tc / 8) * tc) * 4;
+  const dim3 grid(ctiles, n * chunks);
   if (k == 3)
-    hipLaunchKernelGGL((dwconv_kernel<DT_F16, 3>), dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, c_p, ho, wo, stride, act);
+    hipLaunchKernelGGL((dwconv_kernel<DT_F16, 3>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, c_p, ho, wo, stride, act, chunks);
   else
-    hipLaunchKernelGGL((dwconv_kernel<DT_F16, 5>), dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, c_p, ho, wo, stride, act);
+    hipLaunchKernelGGL((dwconv_kernel<DT_F16, 5>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, c_p, ho, wo, stride, act, chunks);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// chunks of the squeeze pass for a given image size (same value at planning and at launch)
-int spk_se_chunks(int hw) { return hw >= 4096 ? 16 : (hw >= 512 ? 4 : 1); }
-
-int spk_launch_se(const bf16_t* x, bf16_t* y, float* partial, float* scale, const float* w1, const float* b1,
-                  const float* w2, const float* b2, int n, int hw, int c, int c_p, int sq, int dt, hipStream_t s) {
+// squeeze-excitation gate on a depthwise output whose pool partials [n][chunks][c_p] the depthwise kernel wrote
+int spk_launch_se(const bf16_t* x, bf16_t* y, const float* partial, int chunks, float* scale, const float* w1,
+                  const float* b1, const float* w2t, const float* b2, int n, int hw, int c, int c_p, int sq, int dt,
+                  hipStream_t s) {
   if (dt != DT_F16) return -2;
-  const int chunks = spk_se_chunks(hw);
-  const int c8 = c_p / 8, tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
-  hipLaunchKernelGGL(se_pool_kernel<DT_F16>, dim3(chunks, n), dim3(256), (size_t)rif * c_p * 4, s, x, partial, hw, c_p, chunks);
-  hipLaunchKernelGGL(se_fc_kernel, dim3(n), dim3(256), (size_t)(c_p + sq) * 4, s, partial, chunks, 1.0f / (float)hw, w1, b1,
-                     w2, b2, scale, c, c_p, sq);
-  const size_t total8 = (size_t)n * hw * c8;
-  hipLaunchKernelGGL(se_scale_kernel<DT_F16>, dim3(grid_for(total8, 256)), dim3(256), 0, s, x, scale, y, total8, hw, c_p);
+  float* hid = scale + (size_t)n * c_p;  // scratch behind the scales: [n][sq]
+  hipLaunchKernelGGL(se_fc1_kernel, dim3(n, (sq + 3) / 4), dim3(256), 0, s, partial, chunks, 1.0f / (float)hw, w1, b1, hid,
+                     c, c_p, sq);
+  hipLaunchKernelGGL(se_fc2_kernel, dim3(n, (c_p + 255) / 256), dim3(256), (size_t)sq * 4, s, hid, w2t, b2, scale, c, c_p,
+                     sq);
+  const size_t per_img = (size_t)hw * (c_p / 8);
+  if (per_img >= ((size_t)1 << 31)) return -2;
+  int gx = (int)((per_img + 255) / 256);
+  const int want = std::max(1, 4096 / n);  // about 16 blocks per CU over the whole batch
+  if (gx > want) gx = want;
+  hipLaunchKernelGGL(se_scale_kernel<DT_F16>, dim3(gx, n), dim3(256), 0, s, x, scale, y, hw, c_p);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

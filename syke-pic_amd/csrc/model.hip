@@ -195,6 +195,10 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     if (L.d.kind == SPK_OP_DWCONV || (L.d.kind == SPK_OP_CONV && L.mode == CONV_MODE_STEM3)) {
       L.wpack_off = dwp;  // fp32, [taps (x4 input channels for the stem)][cout_p]
       dwp += (size_t)L.d.k * L.d.k * (L.d.kind == SPK_OP_CONV ? 4 : 1) * L.cout_p;
+    } else if (L.d.kind == SPK_OP_SE) {
+      L.wpack_off = dwp;  // fp32 fc2 weights transposed: [squeeze][cout_p]
+      dwp += (size_t)L.d.k * L.cout_p;
+      continue;
     } else if (L.d.kind == SPK_OP_CONV) {
       L.wpack_off = wpack;
       wpack += (size_t)2 * L.cout_p * L.kpad;  // room for the hi + lo halves
@@ -399,6 +403,9 @@ int spk_commit(spk_model* m) {
       m->packed_epoch == m->split_epoch)
     return SPK_OK;
   for (Layer& L : m->layers) {
+    if (L.d.kind == SPK_OP_SE &&
+        spk_launch_pack_tapmajor(m->P(L.p_w2), m->dwpack + L.wpack_off, L.d.cout, L.d.k, L.cout_p, m->stream))
+      return fail(SPK_ERR_HIP, "pack (squeeze-excitation) launch failed");
     if (L.d.kind != SPK_OP_CONV && L.d.kind != SPK_OP_DWCONV) continue;
     float* sc = m->scale_bias + L.sb_off;
     float* bi = sc + L.cout_p;
@@ -492,7 +499,8 @@ int spk_plan(spk_model* m, int n, int h, int w) {
   for (const Layer& L : m->layers) {
     if (L.d.kind != SPK_OP_SE) continue;
     const TDim& d = m->tdims[L.d.src];
-    se_floats = std::max(se_floats, (size_t)n * (spk_se_chunks(d.h * d.w) + 1) * d.c);
+    // partials [n][chunks][c] (chunks(1) >= chunks(nb)), scales [n][c], hidden units [n][squeeze]
+    se_floats = std::max(se_floats, (size_t)n * ((spk_dw_chunks(1, d.h * d.w, d.c) + 1) * d.c + L.d.k));
   }
   m->se_off = total;
   total += align256(se_floats * 4);
@@ -568,17 +576,23 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
     case SPK_OP_CONV: return run_conv_eval(m, L, nb);
     case SPK_OP_DWCONV: {
       const float* sc = m->scale_bias + L.sb_off;
+      // the pool partial sums of the squeeze-excitation gate that follows are a by-product
       if (spk_launch_dwconv((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                            (bf16_t*)m->T(L.d.dst), nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu,
-                            m->infer_dt, m->stream))
+                            (bf16_t*)m->T(L.d.dst), (float*)((char*)m->arena + m->se_off), nb, in.h, in.w, in.c, o.h,
+                            o.w, L.d.k, L.d.stride, L.d.relu, m->infer_dt, m->stream))
         return fail(SPK_ERR_UNSUPPORTED, std::string("depthwise conv launch failed (fp16 eval only) for ") + L.d.name);
       return SPK_OK;
     }
     case SPK_OP_SE: {
+      // src is the output of a depthwise conv, which left its pool partials in the scratch
+      bool from_dw = false;
+      for (const Layer& Q : m->layers) from_dw |= (Q.d.kind == SPK_OP_DWCONV && Q.d.dst == L.d.src);
+      if (!from_dw) return fail(SPK_ERR_UNSUPPORTED, "squeeze-excitation must follow a depthwise conv");
       float* partial = (float*)((char*)m->arena + m->se_off);
-      float* scale = partial + (size_t)nb * spk_se_chunks(in.h * in.w) * in.c;
-      if (spk_launch_se((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), partial, scale, m->P(L.p_w),
-                        m->P(L.p_b), m->P(L.p_w2), m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,
+      const int chunks = spk_dw_chunks(nb, in.h * in.w, in.c);
+      float* scale = partial + (size_t)nb * chunks * in.c;
+      if (spk_launch_se((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), partial, chunks, scale, m->P(L.p_w),
+                        m->P(L.p_b), m->dwpack + L.wpack_off, m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,
                         m->infer_dt, m->stream))
         return fail(SPK_ERR_UNSUPPORTED, std::string("squeeze-excitation launch failed (fp16 eval only) for ") + L.d.name);
       return SPK_OK;

@@ -110,11 +110,12 @@ int spk_launch_pack_padded(const float* w, bf16_t* out, int cout, int taps, int 
 int spk_launch_pack_tapmajor(const float* w, float* out, int c, int rows, int c_p, hipStream_t s);
 int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
                        int wid, int wstride, int ho, int wo, int c_p, int act, int dt, hipStream_t s);
-int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
-                      int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s);
-int spk_se_chunks(int hw);
-int spk_launch_se(const bf16_t* x, bf16_t* y, float* partial, float* scale, const float* w1, const float* b1,
-                  const float* w2, const float* b2, int n, int hw, int c, int c_p, int sq, int dt, hipStream_t s);
+int spk_dw_chunks(int n, int hw, int c_p);
+int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, float* partial,
+                      int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s);
+int spk_launch_se(const bf16_t* x, bf16_t* y, const float* partial, int chunks, float* scale, const float* w1,
+                  const float* b1, const float* w2t, const float* b2, int n, int hw, int c, int c_p, int sq, int dt,
+                  hipStream_t s);
 int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
                             int mode, int dt, int splitw, hipStream_t s);
 

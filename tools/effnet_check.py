@@ -37,3 +37,14 @@ rows.sort(key=lambda r: -r[1])
 for nme, ms, fl, by in rows[:12]:
     print(f"  {nme:34s} {ms*1e3:8.1f} us  {fl/ms/1e9 if ms else 0:8.1f} GF/s  {by/ms/1e6 if ms else 0:8.1f} GB/s")
 print("total ms", sum(r[1] for r in rows))
+g2 = {op.name: op for op in g.ops}
+agg = {}
+for nme, ms, fl, by in rows:
+    op = g2.get(nme)
+    kind = "other"
+    if op is not None:
+        kind = {arch.OP_CONV: "conv1x1" if op.k == 1 else "stem", arch.OP_DWCONV: f"dw{op.k}", arch.OP_SE: "se",
+                arch.OP_LINEAR: "head"}.get(op.kind, "other")
+    a = agg.setdefault(kind, [0, 0.0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += fl; a[3] += by
+for k, (c, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {k:10s} x{c:3d} {ms:7.3f} ms  {fl/ms/1e9 if ms else 0:9.1f} GF/s  {by/ms/1e6 if ms else 0:8.1f} GB/s")
