@@ -62,17 +62,19 @@ __global__ void pack_tapmajor_kernel(const float* __restrict__ w, float* __restr
 }
 
 // 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 16 output channels of
-// one output pixel (27 image values in registers, the weights from LDS, two 16-B stores); exact fp32
-// products of the 16-bit image.
+// one output pixel; the 27 x C weights, scales and shifts sit in LDS (4 distinct addresses per wave read:
+// broadcast, conflict-free); 9 8-byte image loads, 432 FMAs and two 16-B stores per thread.  The register
+// cap keeps 4 waves per SIMD (uncapped, the scheduler front-loads all 108 LDS reads into 460 VGPRs).
+// Exact fp32 products of the 16-bit image.
 template <int DT, int CP>
-__global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                                                      const float* __restrict__ scale,
-                                                      const float* __restrict__ bias, bf16_t* __restrict__ y, int n,
-                                                      int h, int wid, int wstride, int ho, int wo, int act) {
+__global__ __launch_bounds__(256, 4) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ y, int n,
+                                                         int h, int wid, int wstride, int ho, int wo, int act) {
   constexpr int G = CP / 16;  // threads per pixel
   __shared__ __attribute__((aligned(16))) float sw[29 * CP];  // [27 (tap, channel)][CP], scale[CP], bias[CP]
   for (int i = threadIdx.x; i < 27 * CP; i += 256) {
-    const int k = i / CP, c = i - k * CP;          // k = tap*3 + channel
+    const int k = i / CP, c = i - k * CP;               // k = tap*3 + channel
     sw[i] = w[(size_t)((k / 3) * 4 + k % 3) * CP + c];  // source rows are [tap][4 channels]
   }
   for (int i = threadIdx.x; i < CP; i += 256) {
@@ -81,7 +83,10 @@ __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__
   }
   __syncthreads();
   const unsigned total = (unsigned)n * ho * wo * G;  // < 2^31 (checked by the launcher): 32-bit index math
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  // one work item per thread, no grid-stride loop: with one, the compiler keeps all 27 x 16 weights of the
+  // thread's channel group in registers across iterations (460 VGPRs, one wave per SIMD)
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) {
     const int c0 = (int)(i % G) * 16;
     unsigned p = i / G;
     const size_t pix = p;
@@ -91,24 +96,24 @@ __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    // a real loop over the taps (not unrolled): unrolled, hipcc 7.2 reads all 108 weight quads up front and
+    // spills them (372 spilled VGPRs)
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+      const int r = t / 3, q = t - 3 * r;
+      const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
+      uint2 px = {0u, 0u};
+      if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wid)
+        px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
+      const float xin[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) {
+        const float* wp = sw + (t * 3 + c) * CP + c0;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
-        uint2 px = {0u, 0u};
-        if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wid)
-          px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
-        const float xin[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
+        for (int v = 0; v < 4; ++v) {
+          const f32x4_t wv = *(const f32x4_t*)(wp + 4 * v);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float* wp = sw + ((r * 3 + q) * 3 + c) * CP + c0;
-#pragma unroll
-          for (int v = 0; v < 4; ++v) {
-            const f32x4_t wv = *(const f32x4_t*)(wp + 4 * v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[4 * v + j] += xin[c] * wv[j];
-          }
+          for (int j = 0; j < 4; ++j) acc[4 * v + j] += xin[c] * wv[j];
         }
       }
     }
@@ -119,18 +124,21 @@ __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__
   }
 }
 
-// depthwise KxK conv + folded BN + activation.  One block = one pixel chunk of ONE image x one tile of up
-// to 256 channels: the tile's K*K x 256 weights, scales and shifts sit in LDS; a thread owns 8 channels and
-// walks the chunk's pixels; lanes of a wave cover consecutive channel groups (contiguous 16-B accesses).
-// The per-channel sums of the block's outputs (fp32, before the 16-bit rounding) are reduced over the block
-// in fixed order and written as the squeeze-excitation pool partial [img][chunk][c_p].
-template <int DT, int K>
+// depthwise KxK conv + folded BN + activation.  One block = one chunk of output pixels of ONE image x one tile
+// of up to 256 channels: the tile's K*K x 256 weights, scales and shifts sit in LDS.  A thread owns 8 channels
+// and PX horizontally adjacent output pixels: each input value is loaded once for all the outputs whose window
+// covers it ((PX-1)*S+K columns per row instead of PX*K: the pass is bound by L1 requests, not HBM).  Lanes of
+// a wave cover consecutive channel groups (contiguous 16-B accesses).  The per-channel sums of the block's
+// outputs (fp32, before the 16-bit rounding) are reduced over the block in fixed order and written as the
+// squeeze-excitation pool partial [img][chunk][c_p].
+template <int DT, int K, int S, int PX>
 __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                      float* __restrict__ partial, int h, int wid, int c_p, int ho,
-                                                     int wo, int stride, int act, int chunks) {
+                                                     int wo, int act, int chunks) {
   constexpr int PAD = (K - 1) / 2;
+  constexpr int COLS = (PX - 1) * S + K;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [K*K + 2][tc]; reused for the pool reduce
   const int img = blockIdx.y / chunks, chunk = blockIdx.y % chunks;
   const int c8 = c_p >> 3;
@@ -142,40 +150,60 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
                       : (r == K * K ? scale[cg0 * 8 + c] : bias[cg0 * 8 + c]);
   }
   __syncthreads();
-  const int rows = 256 / ncg;  // pixel lanes
+  const int rows = 256 / ncg;  // pixel-group lanes
   const int cg = threadIdx.x % ncg, prow = threadIdx.x / ncg;
-  const int hw = ho * wo, per = (hw + chunks - 1) / chunks;
-  const int p0 = chunk * per, p1 = min(hw, p0 + per);
+  const int gpr = (wo + PX - 1) / PX, ngroups = ho * gpr;  // groups of PX outputs along W
+  const int per = (ngroups + chunks - 1) / chunks;
+  const int g0 = chunk * per, g1 = min(ngroups, g0 + per);
   float pool[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (prow < rows) {
     const float* wl = sm + cg * 8;
-    for (int p = p0 + prow; p < p1; p += rows) {
-      const int oy = p / wo, ox = p - oy * wo;
-      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16_t* xi = x + (size_t)img * h * wid * c_p + (cg0 + cg) * 8;
+    bf16_t* yi = y + (size_t)img * ho * wo * c_p + (cg0 + cg) * 8;
+    for (int g = g0 + prow; g < g1; g += rows) {
+      const int oy = g / gpr, ox0 = (g - oy * gpr) * PX;
+      float acc[PX][8];
+#pragma unroll
+      for (int u = 0; u < PX; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
 #pragma unroll
       for (int r = 0; r < K; ++r) {
-        const int iy = oy * stride - PAD + r;
+        const int iy = oy * S - PAD + r;
         if ((unsigned)iy >= (unsigned)h) continue;
+        float wrow[K][8];
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-          const int ix = ox * stride - PAD + q;
-          if ((unsigned)ix >= (unsigned)wid) continue;
-          float xv[8];
-          unpack8f<DT>(*(const u32x4_t*)(x + (((size_t)img * h + iy) * wid + ix) * c_p + (cg0 + cg) * 8), xv);
           const f32x4_t w0 = *(const f32x4_t*)(wl + (r * K + q) * tc), w1 = *(const f32x4_t*)(wl + (r * K + q) * tc + 4);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[j] += xv[j] * w0[j];
-            acc[4 + j] += xv[4 + j] * w1[j];
+          for (int j = 0; j < 4; ++j) { wrow[q][j] = w0[j]; wrow[q][4 + j] = w1[j]; }
+        }
+#pragma unroll
+        for (int col = 0; col < COLS; ++col) {
+          const int ix = ox0 * S - PAD + col;
+          if ((unsigned)ix >= (unsigned)wid) continue;
+          float xv[8];
+          unpack8f<DT>(*(const u32x4_t*)(xi + ((size_t)iy * wid + ix) * c_p), xv);
+#pragma unroll
+          for (int u = 0; u < PX; ++u) {
+            const int q = col - u * S;  // tap of output u that this column feeds
+            if (q >= 0 && q < K) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[u][j] += xv[j] * wrow[q][j];
+            }
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        acc[j] = act_f(acc[j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j], act);
-        pool[j] += acc[j];
+      for (int u = 0; u < PX; ++u) {
+        if (ox0 + u >= wo) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          acc[u][j] = act_f(acc[u][j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j], act);
+          pool[j] += acc[u][j];
+        }
+        *(u32x4_t*)(yi + ((size_t)oy * wo + ox0 + u) * c_p) = pack8f<DT>(acc[u]);
       }
-      *(u32x4_t*)(y + ((size_t)img * hw + p) * c_p + (cg0 + cg) * 8) = pack8f<DT>(acc);
     }
   }
   if (!partial) return;
@@ -291,13 +319,13 @@ int spk_launch_pack_tapmajor(const float* w, float* out, int c, int rows, int c_
 int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
                        int wid, int wstride, int ho, int wo, int c_p, int act, int dt, hipStream_t s) {
   if (c_p != 64 || dt != DT_F16 || (size_t)n * ho * wo * 4 >= ((size_t)1 << 31)) return -2;  // B0..B4 stems pad to 64
-  const int g = grid_for((size_t)n * ho * wo * 4, 256);
+  const int g = (int)(((size_t)n * ho * wo * 4 + 255) / 256);
   hipLaunchKernelGGL((stem3x3_kernel<DT_F16, 64>), dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, wstride, ho,
                      wo, act);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// chunks of one image's output pixels (same value at planning and at launch): enough blocks to fill the chip
+// chunks of one image's work items (same value at planning and at launch): enough blocks to fill the chip
 int spk_dw_chunks(int n, int hw, int c_p) {
   const int ctiles = (c_p / 8 + 31) / 32;
   int chunks = 1;
@@ -307,16 +335,22 @@ int spk_dw_chunks(int n, int hw, int c_p) {
 
 int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, float* partial,
                       int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s) {
-  if ((k != 3 && k != 5) || dt != DT_F16) return -2;
-  const int chunks = spk_dw_chunks(n, ho * wo, c_p);
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || dt != DT_F16) return -2;
+  constexpr int PX = 4;
+  const int groups = ho * ((wo + PX - 1) / PX);
+  const int chunks = spk_dw_chunks(n, groups, c_p);
   const int c8 = c_p / 8, ctiles = (c8 + 31) / 32;
   const int tc = (c8 < 32 ? c8 : 32) * 8;
   const size_t lds = (size_t)std::max((k * k + 2) * tc, 256 / (tc / 8) * tc) * 4;
   const dim3 grid(ctiles, n * chunks);
-  if (k == 3)
-    hipLaunchKernelGGL((dwconv_kernel<DT_F16, 3>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, c_p, ho, wo, stride, act, chunks);
-  else
-    hipLaunchKernelGGL((dwconv_kernel<DT_F16, 5>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, c_p, ho, wo, stride, act, chunks);
+#define SPK_DW(K, S)                                                                                              \
+  hipLaunchKernelGGL((dwconv_kernel<DT_F16, K, S, PX>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, \
+                     c_p, ho, wo, act, chunks)
+  if (k == 3 && stride == 1) SPK_DW(3, 1);
+  else if (k == 3) SPK_DW(3, 2);
+  else if (stride == 1) SPK_DW(5, 1);
+  else SPK_DW(5, 2);
+#undef SPK_DW
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

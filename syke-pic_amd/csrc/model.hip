@@ -500,7 +500,7 @@ int spk_plan(spk_model* m, int n, int h, int w) {
     if (L.d.kind != SPK_OP_SE) continue;
     const TDim& d = m->tdims[L.d.src];
     // partials [n][chunks][c] (chunks(1) >= chunks(nb)), scales [n][c], hidden units [n][squeeze]
-    se_floats = std::max(se_floats, (size_t)n * ((spk_dw_chunks(1, d.h * d.w, d.c) + 1) * d.c + L.d.k));
+    se_floats = std::max(se_floats, (size_t)n * ((spk_dw_chunks(1, d.h * ((d.w + 3) / 4), d.c) + 1) * d.c + L.d.k));
   }
   m->se_off = total;
   total += align256(se_floats * 4);
@@ -589,7 +589,7 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       for (const Layer& Q : m->layers) from_dw |= (Q.d.kind == SPK_OP_DWCONV && Q.d.dst == L.d.src);
       if (!from_dw) return fail(SPK_ERR_UNSUPPORTED, "squeeze-excitation must follow a depthwise conv");
       float* partial = (float*)((char*)m->arena + m->se_off);
-      const int chunks = spk_dw_chunks(nb, in.h * in.w, in.c);
+      const int chunks = spk_dw_chunks(nb, in.h * ((in.w + 3) / 4), in.c);  // as the depthwise launch: groups of 4 outputs
       float* scale = partial + (size_t)nb * chunks * in.c;
       if (spk_launch_se((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), partial, chunks, scale, m->P(L.p_w),
                         m->P(L.p_b), m->dwpack + L.wpack_off, m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,
