@@ -195,6 +195,18 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
                 "algorithmic_bytes_per_launch": round(sum(by for _, _, _, by in conv) / len(conv)),
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
                 "hbm_GBs_algorithmic": round(sum(by for _, _, _, by in layers) / (all_ms * 1e-3) / 1e9, 1)}
+        if args.network.startswith("efficientnet"):
+            # EfficientNet: 2/3 of the time is depthwise / squeeze-excitation / padded 1x1 passes that move bytes:
+            # the bound is HBM, over all kernels of the forward
+            all_by = sum(by for _, _, _, by in layers)
+            gbs = all_by / (all_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "all forward kernels (conv_igemm 1x1, dwconv, se_*, stem3x3)",
+                    "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                    "traffic": None, "launches": len(layers), "avg_launch_us": round(all_ms * 1e3 / len(layers), 2),
+                    "algorithmic_bytes_per_launch": round(all_by / len(layers)),
+                    "all_kernels_ms_per_step": round(all_ms, 3),
+                    "conv1x1_tflops": round(sum(fl for n, _, fl, _ in conv if ".block." in n or n.endswith("8.0")) / 1e12 /
+                                            max(sum(ms for n, ms, _, _ in conv) * 1e-3, 1e-9), 1)}
         pmc = ROOT / "profiles" / f"r01_pmc_traffic_infer_{args.precision}.json"
         if pmc.is_file() and args.batch == 256 and args.network == "resnet50":
             # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
@@ -267,6 +279,8 @@ def main():
     # headline = the inference step (net_pass body); the training step of the
     # same model/config rides along under "train" (BASELINE metric names both)
     modes = ["infer", "train"] if args.mode == "both" else [args.mode]
+    if args.network.startswith("efficientnet"):
+        modes = ["infer"]   # BASELINE config 5 is an inference config; the MI355X path has no EfficientNet training
     results = []
     for m in modes:
         if rank == 0:
