@@ -115,7 +115,7 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       if (stem) L.cin_p = 4;
       L.mode = stem7 ? CONV_MODE_STEM : (stem3 ? CONV_MODE_STEM3 : CONV_MODE_GENERIC);
       L.kpad = stem7 ? 256 : L.d.k * L.d.k * L.cin_p;
-      if (stem3 || L.cin_p != L.d.cin || L.cout_p != L.d.cout || L.d.relu == SPK_ACT_SILU) m->eval_only = true;
+      if (stem3 || (!stem && L.cin_p != L.d.cin) || L.cout_p != L.d.cout || L.d.relu == SPK_ACT_SILU) m->eval_only = true;
     } else if (L.d.kind == SPK_OP_DWCONV) {
       if ((L.d.k != 3 && L.d.k != 5) || L.d.cin != L.d.cout || L.d.pad != (L.d.k - 1) / 2) {
         delete m; return fail(SPK_ERR_UNSUPPORTED, "depthwise conv: k 3 or 5, pad (k-1)/2");
@@ -419,7 +419,7 @@ int spk_commit(spk_model* m) {
       r = spk_launch_pack_tapmajor(m->P(L.p_w), m->dwpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.cout_p, m->stream);
     else if (L.mode == CONV_MODE_STEM3)  // master layout [cout][kh][kw][cin]: rows = taps x 4 (cin padded to 4)
       r = pack_stem3(m, L);
-    else if (L.cin_p != L.d.cin || L.cout_p != L.d.cout)
+    else if (L.mode == CONV_MODE_GENERIC && (L.cin_p != L.d.cin || L.cout_p != L.d.cout))
       r = spk_launch_pack_padded(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.d.cin, L.cout_p,
                                  L.cin_p, m->infer_dt, layer_split(m, L), m->stream);
     else
