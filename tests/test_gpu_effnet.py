@@ -90,3 +90,56 @@ def test_efficientnet_odd_size_u8_and_no_training():
     net.train()
     with pytest.raises(RuntimeError, match="inference path only"):
         net.forward_backward(xf.cuda(), torch.zeros(5, dtype=torch.int64).cuda())
+
+
+def test_efficientnet_through_prob_workflow(tmp_path, golden_dir):
+    """`sykepic prob` end to end with an EfficientNet model directory (config.ini network = efficientnet_b0):
+    the reference's own raw fixture -> .prob.csv, numbers against the oracle, state_dict round trip."""
+    import shutil
+    from configparser import ConfigParser
+    from oracle import refnet
+    from sykepic_hip import arch, ifcb, prob
+    from sykepic_hip.net import HipNet
+    classes = [f"class_{i:02d}" for i in range(6)]
+    g = arch.build_graph("efficientnet_b0", len(classes), head=(32,))
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=6, logit_gain=3.0)
+    ref = refnet.load_numpy_state(refnet.RefNet("efficientnet_b0", len(classes), head=(32,)), sd)
+    refnet.calibrate_bn(ref, torch.from_numpy(synth.synth_images(8, 3, 96, 96, seed=3)))
+    model = tmp_path / "model"
+    model.mkdir()
+    (model / "class_names.txt").write_text("\n".join(classes) + "\n")
+    cfg = ConfigParser()
+    cfg.read(golden_dir / "ref_data" / "config.ini")   # the reference's own model config, network swapped
+    cfg["model"]["network"] = "efficientnet_b0"
+    cfg["model"]["head"] = "32"
+    cfg["image"]["shape"] = "3, 96, 96"
+    with open(model / "config.ini", "w") as fh:
+        cfg.write(fh)
+    torch.save(ref.state_dict(), model / "best_state.pth")
+    raw = tmp_path / "raw"
+    raw.mkdir()
+    for suf in (".adc", ".roi", ".hdr"):
+        src = golden_dir / "ref_data" / f"D20180712T065600_IFCB114{suf}"
+        if src.exists():
+            shutil.copy(src, raw / src.name)
+
+    class A:
+        raw = None; samples = None; image_dir = None; images = None; model = None; out = None
+        batch_size = 64; num_workers = 0; force = True
+    a = A()
+    a.samples, a.model, a.out = [str(raw / "D20180712T065600_IFCB114")], str(model), str(tmp_path / "out")
+    prob.call(a)
+    csv = tmp_path / "out" / "2018" / "07" / "12" / "D20180712T065600_IFCB114.prob.csv"
+    lines = csv.read_text().splitlines()
+    assert lines[0] == "roi," + ",".join(classes) and [ln.split(",")[0] for ln in lines[1:]] == ["2", "3"]
+    got = np.array([[float(v) for v in ln.split(",")[1:]] for ln in lines[1:]])
+    # the same ROIs through the host pipeline and the oracle
+    net, cls, shape, tr, dev = prob.prepare_model(model)
+    rois = ifcb.read_rois(raw / "D20180712T065600_IFCB114.adc", raw / "D20180712T065600_IFCB114.roi")
+    x = torch.stack([tr(np.repeat(img[:, :, None], 3, axis=2)) for _, img in rois])
+    want = refnet.probabilities(ref, x).numpy()
+    # a workflow check: random EfficientNet weights on real ROIs (statistics far from the calibration batch)
+    # are worse conditioned than the golden cases above, which carry the 1e-3 tolerance
+    assert np.abs(got - want).max() < 5e-3 and (got.argmax(1) == want.argmax(1)).all()
+    back = net.state_dict()
+    assert all(torch.equal(back[k].cpu(), v) for k, v in ref.state_dict().items())
