@@ -103,6 +103,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   int kr = r_first, ks_ = s_first, kc0 = 0;
   int wr = r_first, ws = s_first, wc0 = 0;  // tap walk of the weight tiles (dgrad)
 
+  const int cin_s = a.cin_s > 0 ? a.cin_s : a.Cin;     // channels per stored input pixel
+  const int cout_s = a.cout_s > 0 ? a.cout_s : a.Cout;  // channels per stored output pixel
   auto set_tile = [&](int w) {
     const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = w & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (w >> 3);
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
         a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
         a_w0[i] = w0;
-        a_base[i] = ((img * a.H + h0) * a.W + w0) * a.Cin + chunk * 8;
+        a_base[i] = ((img * a.H + h0) * a.W + w0) * cin_s + chunk * 8;
       }
     }
 #pragma unroll
@@ -205,10 +207,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         if (ks_ >= a.kw) { ks_ = s_first; kr += tap_step; }
       }
     } else {
-      const int tap_off = (kr * a.W + ks_) * a.Cin + kc0;
+      const int tap_off = (kr * a.W + ks_) * cin_s + kc0;
+      const bool chan_ok = kc0 + chunk * 8 < cin_s;  // K is padded to 64 per tap, the tensor is not
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
-        const bool ok = ((unsigned)(a_h0[i] + kr) < (unsigned)a.H) &&
+        const bool ok = chan_ok && ((unsigned)(a_h0[i] + kr) < (unsigned)a.H) &&
                         ((unsigned)(a_w0[i] + ks_) < (unsigned)a.W);
         const unsigned off = ok ? (unsigned)((a_base[i] + tap_off) * 2) : 0x80000000u;
         put_a(rs, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
           const int m = em0 + wm * WM + i * 16 + erow + p * RPP;
-          rres[i][p] = m < a.M ? *(const u32x4_t*)(a.res + out_pixel(m) * a.Cout + gcol) : u32x4_t{0, 0, 0, 0};
+          rres[i][p] = (m < a.M && gcol < cout_s) ? *(const u32x4_t*)(a.res + out_pixel(m) * cout_s + gcol)
+                                                  : u32x4_t{0, 0, 0, 0};
         }
     }
 #pragma unroll
@@ -493,8 +497,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       const f32x4_t v0 = *(const f32x4_t*)(epi + row * EPI_LD + ecol);
       const f32x4_t v1 = *(const f32x4_t*)(epi + row * EPI_LD + ecol + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (m < a.M) {
-        const size_t o = out_pixel(m) * a.Cout + gcol;
+      if (m < a.M && gcol < cout_s) {
+        const size_t o = out_pixel(m) * cout_s + gcol;
         if (a.stats) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }

@@ -61,67 +61,60 @@ __global__ void pack_tapmajor_kernel(const float* __restrict__ w, float* __restr
   out[i] = ch < c ? w[(size_t)ch * rows + r] : 0.f;
 }
 
-// 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 16 output channels of
-// one output pixel; the 27 x C weights, scales and shifts sit in LDS (4 distinct addresses per wave read:
-// broadcast, conflict-free); 9 8-byte image loads, 432 FMAs and two 16-B stores per thread.  The register
-// cap keeps 4 waves per SIMD (uncapped, the scheduler front-loads all 108 LDS reads into 460 VGPRs).
+// 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 8 output channels of
+// one output pixel; the 27 x C weights, scales and shifts sit in LDS; 9 8-byte image loads, 216 FMAs and one
+// 16-B store per thread.  C (32..48 for B0-B4, a multiple of 8) is the stored channel count.  A real (not
+// unrolled) tap loop: unrolled, hipcc 7.2 front-loads every LDS read and spills hundreds of VGPRs.
 // Exact fp32 products of the 16-bit image.
-template <int DT, int CP>
-__global__ __launch_bounds__(256, 4) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ bias, bf16_t* __restrict__ y, int n,
-                                                         int h, int wid, int wstride, int ho, int wo, int act) {
-  constexpr int G = CP / 16;  // threads per pixel
-  __shared__ __attribute__((aligned(16))) float sw[29 * CP];  // [27 (tap, channel)][CP], scale[CP], bias[CP]
-  for (int i = threadIdx.x; i < 27 * CP; i += 256) {
-    const int k = i / CP, c = i - k * CP;               // k = tap*3 + channel
-    sw[i] = w[(size_t)((k / 3) * 4 + k % 3) * CP + c];  // source rows are [tap][4 channels]
+template <int DT>
+__global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ bias, bf16_t* __restrict__ y, int n,
+                                                      int h, int wid, int wstride, int ho, int wo, int c, int c_p,
+                                                      int act) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [27 (tap, channel)][c], scale[c], bias[c]
+  for (int i = threadIdx.x; i < 27 * c; i += 256) {
+    const int k = i / c, col = i - k * c;                    // k = tap*3 + channel
+    sw[i] = w[(size_t)((k / 3) * 4 + k % 3) * c_p + col];    // source rows are [tap][4 channels] x c_p
   }
-  for (int i = threadIdx.x; i < CP; i += 256) {
-    sw[27 * CP + i] = scale[i];
-    sw[28 * CP + i] = bias[i];
+  for (int i = threadIdx.x; i < c; i += 256) {
+    sw[27 * c + i] = scale[i];
+    sw[28 * c + i] = bias[i];
   }
   __syncthreads();
-  const unsigned total = (unsigned)n * ho * wo * G;  // < 2^31 (checked by the launcher): 32-bit index math
-  // one work item per thread, no grid-stride loop: with one, the compiler keeps all 27 x 16 weights of the
-  // thread's channel group in registers across iterations (460 VGPRs, one wave per SIMD)
+  const unsigned G = (unsigned)c >> 3;                 // threads per pixel
+  const unsigned total = (unsigned)n * ho * wo * G;    // < 2^31 (checked by the launcher): 32-bit index math
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) {
-    const int c0 = (int)(i % G) * 16;
-    unsigned p = i / G;
-    const size_t pix = p;
-    const int ox = (int)(p % (unsigned)wo);
-    p /= (unsigned)wo;
-    const int oy = (int)(p % (unsigned)ho), img = (int)(p / (unsigned)ho);
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    // a real loop over the taps (not unrolled): unrolled, hipcc 7.2 reads all 108 weight quads up front and
-    // spills them (372 spilled VGPRs)
+  if (i >= total) return;
+  const int c0 = (int)(i % G) * 8;
+  unsigned p = i / G;
+  const size_t pix = p;
+  const int ox = (int)(p % (unsigned)wo);
+  p /= (unsigned)wo;
+  const int oy = (int)(p % (unsigned)ho), img = (int)(p / (unsigned)ho);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
-      const int r = t / 3, q = t - 3 * r;
-      const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
-      uint2 px = {0u, 0u};
-      if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wid)
-        px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
-      const float xin[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
+  for (int t = 0; t < 9; ++t) {
+    const int r = t / 3, q = t - 3 * r;
+    const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
+    uint2 px = {0u, 0u};
+    if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wid)
+      px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
+    const float xin[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float* wp = sw + (t * 3 + c) * CP + c0;
+    for (int ch = 0; ch < 3; ++ch) {
+      const float* wp = sw + (t * 3 + ch) * c + c0;
+      const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const f32x4_t wv = *(const f32x4_t*)(wp + 4 * v);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[4 * v + j] += xin[c] * wv[j];
-        }
+      for (int j = 0; j < 4; ++j) {
+        acc[j] += xin[ch] * w0[j];
+        acc[4 + j] += xin[ch] * w1[j];
       }
     }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = act_f(acc[j] * sw[27 * CP + c0 + j] + sw[28 * CP + c0 + j], act);
-    *(u32x4_t*)(y + pix * CP + c0) = pack8f<DT>(acc);
-    *(u32x4_t*)(y + pix * CP + c0 + 8) = pack8f<DT>(acc + 8);
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = act_f(acc[j] * sw[27 * c + c0 + j] + sw[28 * c + c0 + j], act);
+  *(u32x4_t*)(y + pix * c + c0) = pack8f<DT>(acc);
 }
 
 // depthwise KxK conv + folded BN + activation.  One block = one chunk of output pixels of ONE image x one tile
@@ -317,11 +310,11 @@ int spk_launch_pack_tapmajor(const float* w, float* out, int c, int rows, int c_
 }
 
 int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
-                       int wid, int wstride, int ho, int wo, int c_p, int act, int dt, hipStream_t s) {
-  if (c_p != 64 || dt != DT_F16 || (size_t)n * ho * wo * 4 >= ((size_t)1 << 31)) return -2;  // B0..B4 stems pad to 64
-  const int g = (int)(((size_t)n * ho * wo * 4 + 255) / 256);
-  hipLaunchKernelGGL((stem3x3_kernel<DT_F16, 64>), dim3(g), dim3(256), 0, s, x, w, scale, bias, y, n, h, wid, wstride, ho,
-                     wo, act);
+                       int wid, int wstride, int ho, int wo, int c, int c_p, int act, int dt, hipStream_t s) {
+  const size_t total = (size_t)n * ho * wo * (c / 8);
+  if (c % 8 || c > 256 || dt != DT_F16 || total >= ((size_t)1 << 31)) return -2;
+  hipLaunchKernelGGL(stem3x3_kernel<DT_F16>, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)29 * c * 4, s, x, w,
+                     scale, bias, y, n, h, wid, wstride, ho, wo, c, c_p, act);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -329,7 +322,7 @@ int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, cons
 int spk_dw_chunks(int n, int hw, int c_p) {
   const int ctiles = (c_p / 8 + 31) / 32;
   int chunks = 1;
-  while (chunks < 64 && (long)n * ctiles * chunks < 2048 && hw / (chunks * 2) >= 16) chunks *= 2;
+  while (chunks < 64 && (long)n * ctiles * chunks < 1024 && hw / (chunks * 2) >= 16) chunks *= 2;
   return chunks;
 }
 

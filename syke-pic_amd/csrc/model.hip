@@ -102,9 +102,14 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     L.d.name[sizeof L.d.name - 1] = 0;
     L.d.bn[sizeof L.d.bn - 1] = 0;
     m->n_tensors = std::max(m->n_tensors, std::max(L.d.dst, std::max(L.d.src, L.d.res)) + 1);
-    // channels are laid out padded to the 64-channel granularity of the implicit-GEMM kernel
+    // GEMM dims of the packed weights: padded to the 64-channel granularity of the implicit-GEMM kernel; the
+    // activation tensors keep their own channel count (a multiple of 8: 16-B accesses)
     L.cin_p = (L.d.cin + 63) / 64 * 64;
     L.cout_p = (L.d.cout + 63) / 64 * 64;
+    if ((L.d.kind == SPK_OP_CONV || L.d.kind == SPK_OP_DWCONV || L.d.kind == SPK_OP_SE) &&
+        (L.d.cout % 8 || (L.d.cin > 4 && L.d.cin % 8))) {
+      delete m; return fail(SPK_ERR_UNSUPPORTED, "channel counts must be multiples of 8");
+    }
     if (L.d.kind == SPK_OP_CONV) {
       const bool stem = (L.d.cin <= 4);
       const bool stem7 = stem && L.d.k == 7 && L.d.stride == 2 && L.d.pad == 3 && L.d.cout == 64;
@@ -404,7 +409,7 @@ int spk_commit(spk_model* m) {
     return SPK_OK;
   for (Layer& L : m->layers) {
     if (L.d.kind == SPK_OP_SE &&
-        spk_launch_pack_tapmajor(m->P(L.p_w2), m->dwpack + L.wpack_off, L.d.cout, L.d.k, L.cout_p, m->stream))
+        spk_launch_pack_tapmajor(m->P(L.p_w2), m->dwpack + L.wpack_off, L.d.cout, L.d.k, L.d.cout, m->stream))
       return fail(SPK_ERR_HIP, "pack (squeeze-excitation) launch failed");
     if (L.d.kind != SPK_OP_CONV && L.d.kind != SPK_OP_DWCONV) continue;
     float* sc = m->scale_bias + L.sb_off;
@@ -416,7 +421,7 @@ int spk_commit(spk_model* m) {
       return fail(SPK_ERR_HIP, "bn_fold launch failed");
     int r;
     if (L.d.kind == SPK_OP_DWCONV)
-      r = spk_launch_pack_tapmajor(m->P(L.p_w), m->dwpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.cout_p, m->stream);
+      r = spk_launch_pack_tapmajor(m->P(L.p_w), m->dwpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.d.cout, m->stream);
     else if (L.mode == CONV_MODE_STEM3)  // master layout [cout][kh][kw][cin]: rows = taps x 4 (cin padded to 4)
       r = pack_stem3(m, L);
     else if (L.mode == CONV_MODE_GENERIC && (L.cin_p != L.d.cin || L.cout_p != L.d.cout))
@@ -456,11 +461,11 @@ int spk_plan(spk_model* m, int n, int h, int w) {
         const int ih = in.h, iw = (L.d.src == 0) ? w : in.w;
         o.h = (ih + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
         o.w = (iw + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
-        o.c = L.cout_p;
-        o.c_log = L.d.kind == SPK_OP_MAXPOOL ? in.c_log : L.d.cout;
+        o.c = L.d.cout;
+        o.c_log = L.d.cout;
         o.bf16 = true;
         if (o.h < 1 || o.w < 1) return fail(SPK_ERR_ARG, "image too small for the network");
-        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && in.c != L.cin_p)
+        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && in.c != L.d.cin)
           return fail(SPK_ERR_ARG, std::string("channel mismatch at ") + L.d.name);
         break;
       }
@@ -537,8 +542,8 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   if (L.mode == CONV_MODE_STEM3) {
     const float* sc = m->scale_bias + L.sb_off;
     if (spk_launch_stem3x3((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                           (bf16_t*)m->T(L.d.dst), nb, in.h, in.w, in.w, o.h, o.w, L.cout_p, L.d.relu, m->infer_dt,
-                           m->stream))
+                           (bf16_t*)m->T(L.d.dst), nb, in.h, in.w, in.w, o.h, o.w, L.d.cout, L.cout_p, L.d.relu,
+                           m->infer_dt, m->stream))
       return fail(SPK_ERR_HIP, std::string("stem launch failed for ") + L.d.name);
     return SPK_OK;
   }
@@ -554,8 +559,10 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   a.y_lo = (bf16_t*)m->TLo(L.d.dst);
   a.scale = m->scale_bias + L.sb_off;
   a.bias = a.scale + L.cout_p;
-  a.N = nb; a.H = in.h; a.W = in.w; a.Cin = in.c;
+  a.N = nb; a.H = in.h; a.W = in.w; a.Cin = L.mode == CONV_MODE_GENERIC ? L.cin_p : in.c;
   a.Ho = o.h; a.Wo = o.w; a.Cout = L.cout_p;
+  a.cin_s = in.c != a.Cin ? in.c : 0;       // EfficientNet: tensors are not padded, the GEMM is
+  a.cout_s = o.c != a.Cout ? o.c : 0;
   a.kh = a.kw = L.d.k; a.stride = L.d.stride; a.pad = L.d.pad;
   a.M = nb * o.h * o.w;
   a.K = L.kpad;

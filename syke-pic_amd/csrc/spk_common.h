@@ -81,6 +81,9 @@ struct ConvArgs {
   int oH, oW;           // ... and the full output height/width (Ho/Wo are then the class grid)
   int kt_count;         // K steps of this launch when not K/64 (parity classes use a tap subset)
   unsigned int x_bytes, w_bytes;
+  // channels per pixel as stored in HBM when they differ from the GEMM's 64-padded Cin / Cout (EfficientNet widths
+  // are multiples of 8 only): 0 = same.  K chunks past cin_s read as zeros, output columns past cout_s are not stored.
+  int cin_s, cout_s;
 };
 
 // returns 0 on success; fills *m_tiles with the number of row tiles used
@@ -109,7 +112,7 @@ int spk_launch_pack_padded(const float* w, bf16_t* out, int cout, int taps, int 
                            int splitw, hipStream_t s);
 int spk_launch_pack_tapmajor(const float* w, float* out, int c, int rows, int c_p, hipStream_t s);
 int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, int n, int h,
-                       int wid, int wstride, int ho, int wo, int c_p, int act, int dt, hipStream_t s);
+                       int wid, int wstride, int ho, int wo, int c, int c_p, int act, int dt, hipStream_t s);
 int spk_dw_chunks(int n, int hw, int c_p);
 int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, float* partial,
                       int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s);

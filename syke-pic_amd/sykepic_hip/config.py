@@ -51,4 +51,5 @@ def get_network(config, num_classes, device=None, pretrained_ok=True):
         for drop in config.get("model", "dropout").split(";"):
             idx, p = drop.split(",")
             dropout.append((int(idx), float(p)))
-    return HipNet(network, num_classes, weights, head, dropout, device=device)
+    # pretrained_ok=False: the caller loads a checkpoint next (prob.prepare_model) - skip the random initialisation
+    return HipNet(network, num_classes, weights, head, dropout, device=device, init=pretrained_ok)

@@ -128,7 +128,7 @@ class HipSequential:
 
 class HipNet:
     def __init__(self, name, num_classes, weights="DEFAULT", head=(256, 128), dropout=(),
-                 last_activation=None, device=None):
+                 last_activation=None, device=None, init=True):
         # `weights` names pretrained torchvision weights; there is nothing to
         # download from here and a best_state.pth / training run overwrites
         # every tensor anyway (quirk Q7) — only None/"" vs. other is recorded.
@@ -155,6 +155,38 @@ class HipNet:
         self._params = OrderedDict()
         self._build_views()
         self._stats = None
+        if init:
+            self.reset_parameters()
+
+    def reset_parameters(self):
+        """Random initialisation with the distributions torchvision / torch.nn give a freshly constructed
+        ``TorchVisionNet`` (reference network.py:48 with ``weights=None``): convolutions
+        ``kaiming_normal_(mode="fan_out", nonlinearity="relu")``, BatchNorm weight 1 / bias 0 / mean 0 / var 1,
+        squeeze-excitation biases 0, head ``Linear`` layers torch's default (``kaiming_uniform_(a=sqrt(5))``
+        = U(+-1/sqrt(fan_in)) for weight and bias).  Drawn from torch's global CPU generator, so
+        ``torch.manual_seed`` makes it reproducible as it does for the reference.  Pretrained ImageNet
+        weights (``weights="DEFAULT"``) cannot be downloaded here: the same random start is used and a
+        checkpoint (`load_state_dict`) overwrites it (quirk Q7)."""
+        sd = {}
+        for key, shape, kind in self._specs:
+            if kind in ("conv_w", "se_w"):
+                fan_out = shape[0] * shape[2] * shape[3]
+                sd[key] = torch.randn(shape) * (2.0 / fan_out) ** 0.5
+            elif kind in ("bn_w", "bn_w_last", "bn_var"):
+                sd[key] = torch.ones(shape)
+            elif kind in ("bn_b", "bn_mean", "se_b"):
+                sd[key] = torch.zeros(shape)
+            elif kind == "bn_nbt":
+                sd[key] = torch.zeros(shape, dtype=torch.int64)
+            elif kind in ("fc_w", "fc_w_last"):
+                bound = 1.0 / shape[1] ** 0.5
+                sd[key] = (torch.rand(shape) * 2 - 1) * bound
+                fan_in = shape[1]
+            elif kind == "fc_b":
+                sd[key] = (torch.rand(shape) * 2 - 1) * (1.0 / fan_in ** 0.5)
+            else:
+                raise ValueError(f"no initialiser for parameter kind {kind!r}")
+        self.load_state_dict(sd)
 
     def set_precision(self, split_weights=3, precise_residual=False, bf16=False):
         """Eval-path precision knobs (see include/sykepic_hip.h)."""

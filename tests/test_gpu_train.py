@@ -184,3 +184,35 @@ def test_training_is_bitwise_reproducible():
         grads.append({p.key: net._read_grad(p.key, p.shape) for p in net.parameters()})
     for k in grads[0]:
         assert torch.equal(grads[0][k], grads[1][k]), k
+
+
+def test_fresh_network_is_randomly_initialised_and_learns():
+    """A HipNet built with weights=None starts from torch/torchvision's initial distributions (the
+    reference's TorchVisionNet(weights=None)), reproducibly under torch.manual_seed, and a few Adam steps on one
+    batch reduce the loss (an all-zero start would leave every conv dead)."""
+    from sykepic_hip.net import HipNet
+    from sykepic_hip.optim import HipOptimizer
+    torch.manual_seed(7)
+    net = HipNet("resnet18", 5, weights=None, head=(32,))
+    sd = net.state_dict()
+    w = sd["base.4.0.conv1.weight"]                     # [64, 64, 3, 3]: std = sqrt(2 / (64*9))
+    assert abs(float(w.std()) - (2.0 / (64 * 9)) ** 0.5) < 0.1 * (2.0 / (64 * 9)) ** 0.5 and abs(float(w.mean())) < 2e-3
+    assert torch.all(sd["base.1.weight"] == 1) and torch.all(sd["base.1.bias"] == 0)
+    assert torch.all(sd["base.1.running_var"] == 1) and int(sd["base.1.num_batches_tracked"]) == 0
+    hw_ = sd["head.0.weight"]                           # U(+-1/sqrt(512))
+    assert float(hw_.abs().max()) <= 512 ** -0.5 + 1e-7 and float(hw_.std()) > 0.5 * 512 ** -0.5 / 3 ** 0.5
+    torch.manual_seed(7)
+    again = HipNet("resnet18", 5, weights=None, head=(32,)).state_dict()
+    assert all(torch.equal(again[k], v) for k, v in sd.items())
+    x = torch.from_numpy(synth.synth_images(16, 3, 64, 64, seed=3)).cuda()
+    y = torch.from_numpy(synth.synth_labels(16, 5, seed=4)).cuda()
+    opt = HipOptimizer(net, "Adam", [{"params": list(net.parameters()), "lr": 1e-3}])
+    net.train()
+    losses = []
+    for _ in range(12):
+        net.reset_stats()
+        net.forward_backward(x, y)
+        opt.step()
+        losses.append(net.read_stats()[0] / 16)
+    print("losses", [round(l, 3) for l in losses])
+    assert losses[-1] < 0.7 * losses[0]

@@ -116,7 +116,7 @@ batch_size = 16
 num_workers = 0
 [train]
 gpu = yes
-max_epochs = 4
+max_epochs = 8
 early_stop_patience = 12
 learning_rate = 0.01
 optimizer = Adam
@@ -124,9 +124,9 @@ optimizer = Adam
 use = yes
 factor_1 = 0.1
 factor_2 = 0.5
-step_1 = 2
-step_2 = 3
-step_3 = 4
+step_1 = 3
+step_2 = 5
+step_3 = 7
 verbose = no
 [lr_reduction]
 use = yes
@@ -137,10 +137,14 @@ verbose = yes
 
 
 def test_train_main_end_to_end(tmp_path, capsys):
-    """4 epochs on 3 synthetic classes: artefacts, checkpoint interchangeable
-    with the torch module of the reference, loss goes down."""
+    """8 epochs on 3 synthetic classes (every phase of the unfreeze schedule): artefacts, checkpoint
+    interchangeable with the torch module of the reference, loss goes down."""
+    import random
     from oracle import refnet
     from sykepic_hip import train
+    random.seed(1234)          # the split / oversampling / augmentations draw from the global generators
+    np.random.seed(1234)
+    torch.manual_seed(1234)
     rng = np.random.RandomState(0)
     ds = tmp_path / "ds"
     for ci, name in enumerate(("blob", "bars", "flat")):
@@ -164,9 +168,9 @@ def test_train_main_end_to_end(tmp_path, capsys):
         assert (mdir / f).is_file(), f
     assert (mdir / "class_names.txt").read_text().split("\n") == ["bars", "blob", "flat"]
     stats = [ln for ln in out.splitlines() if ln.startswith("[STAT] Train")]
-    assert len(stats) == 4
+    assert len(stats) == 8
     losses = [float(s.split("Train Loss: ")[1]) for s in stats]
-    assert losses[-1] < losses[0]
+    assert min(losses[1:]) < losses[0] - 0.005, losses
     # the checkpoint is a plain state_dict the reference's torch module accepts
     sd = torch.load(mdir / "best_state.pth")
     ref = refnet.RefNet("resnet18", 3, head=(32, 16))
