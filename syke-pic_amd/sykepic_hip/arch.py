@@ -324,3 +324,19 @@ def conv_flops_per_image(g, h, w):
         else:
             dims[op.dst] = dims.get(op.src, (1, 1))
     return total
+
+
+_RESNET_CHILDREN = {"conv1": 0, "bn1": 1, "layer1": 4, "layer2": 5, "layer3": 6, "layer4": 7}
+
+
+def backbone_key(network, key):
+    """state_dict key of a torchvision backbone checkpoint (``resnet50-*.pth``: ``conv1.weight``,
+    ``layer1.0.conv1.weight``, ``fc.weight`` ...; EfficientNet: ``features.1.0.block...``,
+    ``classifier.1.weight``) -> key of the same tensor under ``TorchVisionNet.base`` (``base.<child>...``),
+    or None for the classifier the reference drops (network.py:49-55)."""
+    first, _, rest = key.partition(".")
+    if network in _EFFNETS:
+        return f"base.0.{rest}" if first == "features" else None
+    if first in _RESNET_CHILDREN:
+        return f"base.{_RESNET_CHILDREN[first]}.{rest}"
+    return None

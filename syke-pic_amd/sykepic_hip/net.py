@@ -157,6 +157,31 @@ class HipNet:
         self._stats = None
         if init:
             self.reset_parameters()
+            self._load_pretrained(weights)
+
+    def _load_pretrained(self, weights):
+        """``weights`` names torchvision's pretrained ImageNet weights in the reference (network.py:48).
+        Nothing can be downloaded here; a path to a local torchvision checkpoint (e.g. ``resnet50-11ad3fa6.pth``)
+        is loaded into ``base``, anything else keeps the random start (with a warning)."""
+        import logging
+        import os
+        if not weights:
+            return
+        if isinstance(weights, (str, os.PathLike)) and os.path.isfile(weights):
+            ckpt = torch.load(weights, map_location="cpu")
+            mapped = {}
+            for k, v in ckpt.items():
+                nk = arch.backbone_key(self.name, k)
+                if nk is not None:
+                    mapped[nk] = v
+            missing = [k for k, _, _ in self._specs if k.startswith("base.") and k not in mapped]
+            if missing:
+                raise RuntimeError(f"{weights}: not a {self.name} backbone checkpoint (missing {missing[:3]} ...)")
+            self.load_state_dict(mapped, strict=False)
+            return
+        logging.getLogger("sykepic_hip").warning(
+            "pretrained weights %r cannot be downloaded here: %s starts from a random initialisation "
+            "(give the path of a local torchvision checkpoint as `weights` to load one)", weights, self.name)
 
     def reset_parameters(self):
         """Random initialisation with the distributions torchvision / torch.nn give a freshly constructed

@@ -216,3 +216,23 @@ def test_fresh_network_is_randomly_initialised_and_learns():
         losses.append(net.read_stats()[0] / 16)
     print("losses", [round(l, 3) for l in losses])
     assert losses[-1] < 0.7 * losses[0]
+
+
+def test_weights_argument_loads_a_local_backbone_checkpoint(tmp_path):
+    """`weights=<path to a torchvision checkpoint>` fills `base` (what `weights="DEFAULT"` downloads in the
+    reference), the head keeps its fresh initialisation."""
+    from oracle import backbones
+    from sykepic_hip.net import HipNet
+    tv = backbones.make("resnet18")
+    torch.manual_seed(3)
+    for p in tv.parameters():
+        p.data.normal_(0, 0.05)
+    path = tmp_path / "resnet18-local.pth"
+    torch.save(tv.state_dict(), path)
+    net = HipNet("resnet18", 4, weights=str(path), head=(16,))
+    sd = net.state_dict()
+    assert torch.equal(sd["base.0.weight"], tv.state_dict()["conv1.weight"])
+    assert torch.equal(sd["base.7.1.bn2.running_var"], tv.state_dict()["layer4.1.bn2.running_var"])
+    assert float(sd["head.0.weight"].abs().max()) <= 512 ** -0.5 + 1e-7
+    with pytest.raises(RuntimeError, match="not a resnet50 backbone"):
+        HipNet("resnet50", 4, weights=str(path))

@@ -123,3 +123,15 @@ def test_product_never_imports_oracle():
     pkg = pathlib.Path(prob.__file__).parent
     for f in pkg.glob("*.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle\b", f.read_text(), flags=re.M), f
+
+
+def test_backbone_checkpoint_key_mapping():
+    """torchvision backbone checkpoints (the reference's `weights=` source) map onto `base.<child>` keys."""
+    from oracle import backbones
+    for network in ("resnet18", "resnet50", "efficientnet_b0"):
+        tv = backbones.make(network).state_dict()
+        want = [k for k, _, _ in arch.param_specs(arch.build_graph(network, 50)) if k.startswith("base.")]
+        mapped = [arch.backbone_key(network, k) for k in tv]
+        assert [m for m in mapped if m is not None] == want
+        dropped = [k for k, m in zip(tv, mapped) if m is None]
+        assert dropped and all(k.startswith(("fc.", "classifier.")) for k in dropped)
