@@ -206,6 +206,32 @@ typedef struct {
 int spk_preprocess_rois(const unsigned char* blob_dev, int64_t blob_bytes, const spk_roi* rois_dev,
                         int n, int out_h, int out_w, int border, unsigned char* out_dev, void* hip_stream);
 
+/* Training augmentations on a batch of resized+bordered uint8 NHWC images:
+ * replaces the cv2 calls of sykepic/train/image.py:80-180 that Compose.__call__ (image.py:25-56) makes per
+ * image in the DataLoader workers.  The random draws stay on the host (Python `random`, reference call order);
+ * ops_dev is [n_ops][n]: op j of every sample, applied in order, each rounding to uint8 as the host does.
+ *   FLIP_H / FLIP_V: i0 = apply flag            TRANSLATE: i0 = x shift, i1 = y shift (constant border)
+ *   ZOOM: i0 = side of the resized square (round(w * f)); centred pad (i0 < w) or crop
+ *   ROTATE: d[0..5] = inverse affine map (row major 2x3), bilinear, constant border
+ *   BRIGHT: d[0] = factor, truncating
+ * border_dev: [n][4] bytes (one value per channel).  tmp_dev: scratch of the batch size (needed when n_ops > 1).
+ * The result is written to out_dev. */
+#define SPK_AUG_FLIP_H 1
+#define SPK_AUG_FLIP_V 2
+#define SPK_AUG_TRANSLATE 3
+#define SPK_AUG_ZOOM 4
+#define SPK_AUG_ROTATE 5
+#define SPK_AUG_BRIGHT 6
+typedef struct {
+  int32_t kind;
+  int32_t i0, i1;
+  int32_t pad_;
+  double d[6];
+} spk_aug_op;
+int spk_augment_batch(const unsigned char* in_dev, unsigned char* out_dev, unsigned char* tmp_dev, int n, int h,
+                      int w, int c, const spk_aug_op* ops_dev, int n_ops, const unsigned char* border_dev,
+                      void* stream);
+
 /* --- prediction from probabilities and thresholds ---
  * row_prediction of sykepic/compute/prediction.py:49-71 for n rows at once:
  * thresholds_dev = float[num_classes] (+inf for a class without a threshold):

@@ -3,12 +3,12 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../sykepic_hip/libsykepic_hip.so
-SRCS="model.hip train.hip conv_igemm.hip conv_stem.hip conv_wgrad.hip pointwise.hip effnet.hip preprocess.hip head.hip train_kernels.hip"
+SRCS="model.hip train.hip conv_igemm.hip conv_stem.hip conv_wgrad.hip pointwise.hip effnet.hip preprocess.hip augment.hip head.hip train_kernels.hip"
 mkdir -p build
 pids=()
 for f in $SRCS; do
   o=build/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ spk_common.h -nt "$o" ] || [ model.h -nt "$o" ] || [ ../../include/sykepic_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ spk_common.h -nt "$o" ] || [ model.h -nt "$o" ] || [ ../../include/sykepic_hip.h -nt "$o" ] || [ resize_u8.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -14,28 +14,9 @@
 // (12 B = three dword stores) per thread per step.
 #include "../../include/sykepic_hip.h"
 #include "spk_common.h"
+#include "resize_u8.h"
 
 namespace {
-
-struct Axis {
-  int i0, i1, a0, a1;
-};
-
-__device__ __forceinline__ Axis coeff(int d, int src, int dst) {
-#pragma clang fp contract(off)  // no FMA fusion: the host computes mul, then sub
-  const double scale = (double)src / (double)dst;
-  double f = ((double)d + 0.5) * scale - 0.5;
-  int s = (int)floor(f);
-  f -= (double)s;
-  if (s < 0) { f = 0.0; s = 0; }
-  if (s >= src - 1) { f = 0.0; s = src - 1; }
-  Axis r;
-  r.i0 = s;
-  r.i1 = min(s + 1, src - 1);
-  r.a1 = (int)rint(f * 2048.0);
-  r.a0 = (int)rint((1.0 - f) * 2048.0);
-  return r;
-}
 
 __global__ __launch_bounds__(256) void roi_preprocess_kernel(const unsigned char* __restrict__ blob,
                                                              long long blob_bytes,

@@ -183,7 +183,10 @@ class ModelData:
         self.oversampled = True
 
     def set_data_loaders(self, batch_size, num_workers, train_transform, eval_transform, num_chans=3,
-                         rank=0, world=1):
+                         rank=0, world=1, device=None):
+        """device: run the transforms (resize, border, augmentations) on that GPU for whole batches
+        (`gpu_augment.GpuLoader`) where the pipeline allows it; None: per-image host transforms in DataLoader
+        workers, as the reference (data.py:165-183)."""
         self.batch_size, self.num_workers = batch_size, num_workers
         self.train_transform, self.eval_transform, self.num_chans = train_transform, eval_transform, num_chans
         if self.oversampled:
@@ -196,6 +199,16 @@ class ModelData:
         train_data = ImageDataset(train_x, train_y, train_transform, num_chans, n_cls)
         val_data = ImageDataset(self.val_x, self.val_y, eval_transform, num_chans, n_cls)
         sampler = ShardedShuffle(len(train_data), rank, world, self.random_seed) if world > 1 else None
+        if device is not None:
+            from . import gpu_augment
+            if gpu_augment.supported(train_transform, num_chans) and gpu_augment.supported(eval_transform, num_chans):
+                G = gpu_augment.GpuLoader
+                self.train_loader = G(train_x, train_y, train_transform, batch_size, device, shuffle=sampler is None,
+                                      sampler=sampler)
+                self.val_loader = G(self.val_x, self.val_y, eval_transform, batch_size, device)
+                if self.test_x:
+                    self.test_loader = G(self.test_x, self.test_y, eval_transform, batch_size, device)
+                return
         self.train_loader = DataLoader(train_data, batch_size, shuffle=sampler is None, sampler=sampler,
                                        num_workers=num_workers)
         self.val_loader = DataLoader(val_data, batch_size, num_workers=num_workers)

@@ -33,6 +33,13 @@ class Roi(C.Structure):
     _fields_ = [("offset", C.c_int64), ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class AugOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("i0", C.c_int32), ("i1", C.c_int32), ("pad_", C.c_int32), ("d", C.c_double * 6)]
+
+
+AUG_FLIP_H, AUG_FLIP_V, AUG_TRANSLATE, AUG_ZOOM, AUG_ROTATE, AUG_BRIGHT = 1, 2, 3, 4, 5, 6
+
+
 class LayerTime(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("ms", C.c_float), ("flops", C.c_double),
                 ("bytes", C.c_double)]
@@ -74,6 +81,7 @@ SYMBOLS = {
     "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_preprocess_rois": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "spk_predict_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P]),
+    "spk_augment_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),
     "spk_model_profile_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.POINTER(LayerTime), C.c_int]),
     "spk_model_profile_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,

@@ -98,8 +98,10 @@ def main(args):
         plots.view_batch(model_data.train_loader, height, width, out_file)
         print(f"[INFO] Image collage saved to {out_file}")
         return
+    # transforms run batched on the GPU where the pipeline allows it (SYKEPIC_HOST_TRANSFORMS=1: host workers)
+    gpu_tf = None if os.environ.get("SYKEPIC_HOST_TRANSFORMS") else torch.device("cuda", local)
     model_data.set_data_loaders(batch_size, num_workers, train_transform, eval_transform, img_shape[0],
-                                rank=rank, world=world)
+                                rank=rank, world=world, device=gpu_tf)
     num_classes = len(model_data.le.classes_)
     external_test = config.get("dataset", "external_test", fallback="")
     if external_test:

@@ -1,0 +1,84 @@
+"""GPU training transforms (`spk_preprocess_rois` + `spk_augment_batch`) against the host
+pipeline (sykepic_hip/preprocess.py, the restated Compose of the reference): with the same `random` seed the
+batched GPU result is byte-identical to transforming the images one by one on the host."""
+
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from sykepic_hip import gpu_augment, preprocess as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _images(rng, n):
+    out = []
+    for _ in range(n):
+        h, w = rng.randint(20, 260), rng.randint(20, 330)
+        g = rng.randint(0, 256, (h, w)).astype(np.uint8)
+        g[rng.rand(h, w) < 0.45] = rng.randint(120, 210)      # a clear modal grey level
+        out.append(np.repeat(g[:, :, None], 3, axis=2))
+    return out
+
+
+PIPELINES = {
+    "reference default (flip, translate, zoom, brightness)":
+        lambda: [P.Resize(), P.FlipHorizontal(), P.FlipVertical(), P.Translate(), P.Zoom((0.6, 1.4)),
+                 P.ChangeBrightness((0.95, 1.1)), P.ToTensor()],
+    "all six": lambda: [P.Resize(), P.FlipHorizontal(), P.FlipVertical(), P.Translate(), P.Rotate(10),
+                        P.Zoom((0.6, 1.4)), P.ChangeBrightness((0.8, 1.3)), P.ToTensor()],
+    "rotate only": lambda: [P.Resize(), P.Rotate(45), P.ToTensor()],
+    "zoom only": lambda: [P.Resize(), P.Zoom((0.5, 2.0)), P.ToTensor()],
+    "eval": lambda: [P.Resize(), P.ToTensor()],
+}
+
+
+@pytest.mark.parametrize("name", list(PIPELINES))
+@pytest.mark.parametrize("border", ["mode", "white"])
+def test_gpu_transform_is_byte_identical_to_the_host_pipeline(name, border):
+    rng = np.random.RandomState(5)
+    imgs = _images(rng, 24)
+    t = P.Compose(PIPELINES[name](), (180, 180), border)
+    assert gpu_augment.supported(t, 3)
+    random.seed(99)
+    want = torch.stack([t(im) for im in imgs])                      # [n, 3, H, W] float32 in [0, 1]
+    random.seed(99)
+    got = gpu_augment.GpuTransform(t, "cuda:0")(imgs)               # [n, H, W, 3] uint8
+    want_u8 = (want * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1)
+    diff = (got.cpu().int() - want_u8.int()).abs()
+    assert int(diff.max()) == 0, f"{name}/{border}: {int((diff > 0).sum())} bytes differ, max {int(diff.max())}"
+    assert random.random() == (random.seed(99), [t(im) for im in imgs], random.random())[2]   # same number of draws
+
+
+def test_unsupported_pipelines_fall_back():
+    t = P.Compose([P.Resize(), P.ToTensor(), P.Normalize(P.IMAGENET_MEAN, P.IMAGENET_STD)], (180, 180), "mode")
+    assert not gpu_augment.supported(t, 3)
+    assert not gpu_augment.supported(P.Compose([P.Resize(), P.Zoom((0.8, 1.2)), P.ToTensor()], (120, 180), "mode"), 3)
+    assert not gpu_augment.supported(P.Compose([P.Resize(), P.ToTensor()], (180, 180), "mode"), 1)
+
+
+def test_loader_feeds_the_training_step(tmp_path):
+    """GpuLoader over PNG files: batches of uint8 NHWC on the GPU drive forward_backward directly."""
+    from PIL import Image
+    from sykepic_hip.net import HipNet
+    rng = np.random.RandomState(1)
+    paths, labels = [], []
+    for i, im in enumerate(_images(rng, 10)):
+        p = tmp_path / f"img_{i:02d}.png"
+        Image.fromarray(im[..., 0]).save(p)
+        paths.append(p)
+        labels.append(i % 3)
+    t = P.Compose(PIPELINES["reference default (flip, translate, zoom, brightness)"](), (64, 64), "mode")
+    loader = gpu_augment.GpuLoader(paths, labels, t, 4, "cuda:0", shuffle=True)
+    assert len(loader) == 3 and len(loader.dataset) == 10
+    net = HipNet("resnet18", 3, weights=None, head=(8,))
+    net.train()
+    seen = 0
+    for x, y in loader:
+        assert x.dtype == torch.uint8 and x.is_cuda and x.shape[1:] == (64, 64, 3)
+        net.reset_stats()
+        net.forward_backward(x, y)
+        seen += len(y)
+    assert seen == 10
