@@ -155,9 +155,17 @@ class HipNet:
         self._params = OrderedDict()
         self._build_views()
         self._stats = None
+        # Random start: the seed is drawn from torch's global generator NOW (so `torch.manual_seed` before the
+        # constructor reproduces the network, as for the reference), the tensors themselves are generated at
+        # first use — a `load_state_dict` of a full checkpoint in between makes them unnecessary.
+        self._init_seed = int(torch.empty((), dtype=torch.int64).random_().item()) if init else None
         if init:
-            self.reset_parameters()
             self._load_pretrained(weights)
+
+    def _ensure_init(self):
+        if getattr(self, "_init_seed", None) is not None:
+            seed, self._init_seed = self._init_seed, None
+            self.reset_parameters(seed)
 
     def _load_pretrained(self, weights):
         """``weights`` names torchvision's pretrained ImageNet weights in the reference (network.py:48).
@@ -183,7 +191,7 @@ class HipNet:
             "pretrained weights %r cannot be downloaded here: %s starts from a random initialisation "
             "(give the path of a local torchvision checkpoint as `weights` to load one)", weights, self.name)
 
-    def reset_parameters(self):
+    def reset_parameters(self, seed=None):
         """Random initialisation with the distributions torchvision / torch.nn give a freshly constructed
         ``TorchVisionNet`` (reference network.py:48 with ``weights=None``): convolutions
         ``kaiming_normal_(mode="fan_out", nonlinearity="relu")``, BatchNorm weight 1 / bias 0 / mean 0 / var 1,
@@ -192,11 +200,16 @@ class HipNet:
         ``torch.manual_seed`` makes it reproducible as it does for the reference.  Pretrained ImageNet
         weights (``weights="DEFAULT"``) cannot be downloaded here: the same random start is used and a
         checkpoint (`load_state_dict`) overwrites it (quirk Q7)."""
+        self._init_seed = None
+        gen = None
+        if seed is not None:
+            gen = torch.Generator()
+            gen.manual_seed(seed)
         sd = {}
         for key, shape, kind in self._specs:
             if kind in ("conv_w", "se_w"):
                 fan_out = shape[0] * shape[2] * shape[3]
-                sd[key] = torch.randn(shape) * (2.0 / fan_out) ** 0.5
+                sd[key] = torch.randn(shape, generator=gen) * (2.0 / fan_out) ** 0.5
             elif kind in ("bn_w", "bn_w_last", "bn_var"):
                 sd[key] = torch.ones(shape)
             elif kind in ("bn_b", "bn_mean", "se_b"):
@@ -205,10 +218,10 @@ class HipNet:
                 sd[key] = torch.zeros(shape, dtype=torch.int64)
             elif kind in ("fc_w", "fc_w_last"):
                 bound = 1.0 / shape[1] ** 0.5
-                sd[key] = (torch.rand(shape) * 2 - 1) * bound
+                sd[key] = (torch.rand(shape, generator=gen) * 2 - 1) * bound
                 fan_in = shape[1]
             elif kind == "fc_b":
-                sd[key] = (torch.rand(shape) * 2 - 1) * (1.0 / fan_in ** 0.5)
+                sd[key] = (torch.rand(shape, generator=gen) * 2 - 1) * (1.0 / fan_in ** 0.5)
             else:
                 raise ValueError(f"no initialiser for parameter kind {kind!r}")
         self.load_state_dict(sd)
@@ -377,6 +390,7 @@ class HipNet:
 
     def forward(self, x, softmax_base=0.0):
         """Eval-mode forward.  softmax_base <= 0: raw logits."""
+        self._ensure_init()
         x, n, h, w, layout, dtype = self._prep(x)
         out = torch.empty((n, self.num_classes), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
@@ -414,6 +428,7 @@ class HipNet:
         return float(s[0]), float(s[1])
 
     def eval_step(self, x, y, want_logits=False):
+        self._ensure_init()
         x, n, h, w, layout, dtype = self._prep(x)
         y = y.to(self.device, dtype=torch.int64).contiguous()
         logits = torch.empty((n, self.num_classes), dtype=torch.float32, device=self.device) if want_logits else None
@@ -428,6 +443,7 @@ class HipNet:
     def forward_backward(self, x, y, want_logits=False):
         """zero_grad + train-mode forward + CrossEntropyLoss + backward
         (reference sykepic/train/train.py:239-242) in one library call."""
+        self._ensure_init()
         x, n, h, w, layout, dtype = self._prep(x)
         if n < 2:
             raise ValueError("Expected more than 1 value per channel when training (batch of 1)")
@@ -442,6 +458,7 @@ class HipNet:
         return logits
 
     def optim_step(self, desc):
+        self._ensure_init()
         with torch.cuda.device(self.device):
             lib.check(self._lib.spk_model_set_stream(self._h, self._stream()))
             lib.check(self._lib.spk_optim_step(self._h, C.byref(desc)))
@@ -460,6 +477,7 @@ class HipNet:
         lib.check(self._lib.spk_model_set_param_group(self._h, key.encode(), int(group)))
 
     def _read_tensor(self, key, shape, dtype):
+        self._ensure_init()
         if dtype == torch.int64:
             buf = np.zeros((), dtype=np.int64)
         else:
@@ -477,6 +495,7 @@ class HipNet:
     def state_dict(self):
         """CPU tensors, NCHW fp32 (+ int64 counters): the on-disk contract of
         best_state.pth (reference train.py:300)."""
+        self._ensure_init()
         sd = OrderedDict()
         for key, shape, kind in self._specs:
             sd[key] = self._read_tensor(key, shape, torch.int64 if kind == "bn_nbt" else torch.float32)
@@ -489,6 +508,10 @@ class HipNet:
         if strict and (missing or unexpected):
             raise RuntimeError(f"Error(s) in loading state_dict for HipNet: missing keys {missing}, "
                                f"unexpected keys {unexpected}")
+        if missing:
+            self._ensure_init()     # a partial load keeps the random start of the other tensors
+        else:
+            self._init_seed = None  # a full checkpoint replaces the pending random start
         for k, v in state.items():
             if k not in want:
                 continue
@@ -518,6 +541,7 @@ class HipNet:
 
     def profile_train(self, x, y, iters=3):
         """[(phase, ms per step, algorithmic FLOPs, launches per step)]."""
+        self._ensure_init()
         x, n, h, w, layout, dtype = self._prep(x)
         y = y.to(self.device, dtype=torch.int64).contiguous()
         recs = (lib.LayerTime * 32)()
@@ -531,6 +555,7 @@ class HipNet:
         return [(r.name.decode(), r.ms, r.flops, r.bytes) for r in recs[:cnt]]
 
     def profile_layers(self, x, iters=5):
+        self._ensure_init()
         x, n, h, w, layout, dtype = self._prep(x)
         cap = len(self.graph.ops) + 4
         recs = (lib.LayerTime * cap)()
