@@ -103,8 +103,11 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   int kr = r_first, ks_ = s_first, kc0 = 0;
   int wr = r_first, ws = s_first, wc0 = 0;  // tap walk of the weight tiles (dgrad)
 
-  const int cin_s = a.cin_s > 0 ? a.cin_s : a.Cin;     // channels per stored input pixel
-  const int cout_s = a.cout_s > 0 ? a.cout_s : a.Cout;  // channels per stored output pixel
+  // PERSIST == 2 marks the instantiations for tensors whose stored channel count is not the GEMM's padded one
+  // (EfficientNet widths); everywhere else the strides are compile-time equal to Cin / Cout and the checks vanish
+  constexpr bool PADC = PERSIST == 2;
+  const int cin_s = (PADC && a.cin_s > 0) ? a.cin_s : a.Cin;     // channels per stored input pixel
+  const int cout_s = (PADC && a.cout_s > 0) ? a.cout_s : a.Cout;  // channels per stored output pixel
   auto set_tile = [&](int w) {
     const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = w & 7;
     const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (w >> 3);
@@ -208,7 +211,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       }
     } else {
       const int tap_off = (kr * a.W + ks_) * cin_s + kc0;
-      const bool chan_ok = kc0 + chunk * 8 < cin_s;  // K is padded to 64 per tap, the tensor is not
+      const bool chan_ok = !PADC || kc0 + chunk * 8 < cin_s;  // K is padded to 64 per tap, the tensor is not
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
         const bool ok = chan_ok && ((unsigned)(a_h0[i] + kr) < (unsigned)a.H) &&
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
     const int em0 = m0, emt = mt_idx, en0 = n0;
     const int gcol = en0 + wn * WN + ecol;
     const int next = work + (int)gridDim.x;
-    const bool has_next = PERSIST && !DMA && next < ntiles;
+    const bool has_next = PERSIST == 1 && !DMA && next < ntiles;
 
     // epilogue operand prefetch: the shortcut tensor is independent of the K
     // loop, so its loads are issued now and land under the MFMAs
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
           const int m = em0 + wm * WM + i * 16 + erow + p * RPP;
-          rres[i][p] = (m < a.M && gcol < cout_s) ? *(const u32x4_t*)(a.res + out_pixel(m) * cout_s + gcol)
+          rres[i][p] = (m < a.M && (!PADC || gcol < cout_s)) ? *(const u32x4_t*)(a.res + out_pixel(m) * cout_s + gcol)
                                                   : u32x4_t{0, 0, 0, 0};
         }
     }
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       const f32x4_t v0 = *(const f32x4_t*)(epi + row * EPI_LD + ecol);
       const f32x4_t v1 = *(const f32x4_t*)(epi + row * EPI_LD + ecol + 4);
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-      if (m < a.M && gcol < cout_s) {
+      if (m < a.M && (!PADC || gcol < cout_s)) {
         const size_t o = out_pixel(m) * cout_s + gcol;
         if (a.stats) {
 #pragma unroll
@@ -606,7 +609,7 @@ int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
     attr = true;
   }
   int grid = m_tiles * n_tiles;
-  if (PERSIST) {
+  if (PERSIST == 1) {
     // persistent: as many blocks as stay resident (LDS-limited, at most 4 per CU)
     int bpc = (int)(163840 / (lds ? lds : 1));
     bpc = bpc < 1 ? 1 : (bpc > 4 ? 4 : bpc);
@@ -646,6 +649,19 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     SPK_GO(CONV_MODE_STEM, DT_BF16, 0);
   }
   if (mode == CONV_MODE_DGRAD) SPK_GO(CONV_MODE_DGRAD, DT_BF16, 0);
+  if (a.dt == DT_F16 && (a.cin_s > 0 || a.cout_s > 0)) {
+    // stored channels != padded GEMM channels: the two flavours instantiated with the channel checks
+#define SPK_GO_PAD(SW)                                                                                        \
+  do {                                                                                                        \
+    if (a.dma == 0) return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, SW, 0, 2>(a, s, m_tiles, n_tiles); \
+    if (a.dma < 0 || a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, SW, 2, 2>(a, s, m_tiles, n_tiles); \
+    return -3;                                                                                                \
+  } while (0)
+    if (a.splitw) SPK_GO_PAD(1);
+    SPK_GO_PAD(0);
+#undef SPK_GO_PAD
+  }
+  if (a.cin_s > 0 || a.cout_s > 0) return -2;  // only the fp16 eval path has padded GEMMs
   if (a.dt == DT_F16) { if (a.splitw) SPK_GO(CONV_MODE_GENERIC, DT_F16, 1); SPK_GO(CONV_MODE_GENERIC, DT_F16, 0); }
   SPK_GO(CONV_MODE_GENERIC, DT_BF16, 0);
 #undef SPK_GO
@@ -744,7 +760,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
   }
   const int pad_cls = a.pad * 16 + (a.cls_ph >= 0 ? 1 + a.cls_ph * 2 + a.cls_pw : 0);
   const TuneKey key(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
-                    a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y));
+                    a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y) + 2 * (a.cin_s > 0) + 4 * (a.cout_s > 0));
   auto it = g_tuned.find(key);
   if (it == g_tuned.end()) {
     if ((const void*)a.res == (const void*)a.y && a.res) {
