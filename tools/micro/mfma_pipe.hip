@@ -424,7 +424,20 @@ int main(int argc, char** argv) {
   for (int pass = 0; pass < 1; ++pass) {
     const unsigned win = argc > 1 ? (unsigned)atoi(argv[1]) << 20 : small;
     printf("---- DMA window %u MiB, KT %d ----\n", win >> 20, KT);
-    if (argc > 2) {  // split-weight (hi+lo) shapes
+    if (argc > 2 && argv[2][0] == '3') {  // 3x3 halo slab: one activation tile feeds 3 taps (B tile and MFMAs x3)
+      run<128, 128, 2, 2, 2, 2, 1>("now: dma 2 stages", src, win, out, 8192, KT);
+      run<128, 128, 2, 2, 2, 2, 3>("slab: dma 2 stages", src, win, out, 2048, KT);
+      run<128, 128, 2, 2, 4, 2, 3>("slab: dma spread", src, win, out, 2048, KT);
+      run<128, 64, 2, 2, 2, 2, 1>("now: dma 2 stages", src, win, out, 8192, KT);
+      run<128, 64, 2, 2, 2, 2, 3>("slab: dma 2 stages", src, win, out, 4096, KT);
+      run<128, 64, 2, 2, 4, 2, 3>("slab: dma spread", src, win, out, 4096, KT);
+      run<256, 64, 4, 2, 2, 2, 1>("now: dma 2 stages", src, win, out, 4096, KT);
+      run<256, 64, 4, 2, 2, 2, 3>("slab: dma 2 stages", src, win, out, 2048, KT);
+      run<256, 64, 4, 2, 4, 2, 3>("slab: dma spread", src, win, out, 2048, KT);
+      run<256, 128, 4, 2, 2, 2, 1>("now: dma 2 stages", src, win, out, 2048, KT);
+      run<64, 64, 2, 2, 2, 2, 1>("now: dma 2 stages", src, win, out, 16384, KT);
+      run<64, 64, 2, 2, 2, 2, 3>("slab: dma 2 stages", src, win, out, 8192, KT);
+    } else if (argc > 2) {  // split-weight (hi+lo) shapes
       run<128, 64, 2, 2, 1, 2, 2>("+ds_read", src, win, out, 8192, KT);
       run<128, 64, 2, 2, 2, 2, 2>("dma 2 stages", src, win, out, 8192, KT);
       run<128, 64, 2, 2, 4, 2, 2>("dma spread", src, win, out, 8192, KT);
