@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--mode", default="both", choices=["both", "infer", "train"])
     ap.add_argument("--precision", default="mixed", choices=["mixed", "precise", "balanced", "fast", "bf16"],
                     help="mixed (library default): fp16 + hi/lo split weights on every conv except the 3x3 convs "
-                         "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tools/split_rules.py: "
+                         "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tests/diagnostics/split_rules.py: "
                          "passes the 1e-3 parity tolerance); precise: split on every conv (5.9e-4); balanced: split "
                          "only the layers that write the residual trunk (1.3e-3 worst case); fast: plain fp16 "
                          "(1.5e-3); bf16 (5e-3)")

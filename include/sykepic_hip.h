@@ -143,7 +143,7 @@ int spk_model_set_precision(spk_model* m, int split_weights, int precise_residua
 /* Per-op choice of split weights: flags[i] != 0 carries conv op i (index into the
  * spk_layer_desc array of spk_model_create) as hi+lo halves; flags of non-conv ops
  * are ignored.  Replaces the split_weights mode until spk_model_set_precision is
- * called again.  `tools/split_search.py` derives the cheapest mask that keeps
+ * called again.  `tests/diagnostics/split_search.py` derives the cheapest mask that keeps
  * the reference's 1e-3 probability tolerance. */
 int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops);
 /* Dropout mask seed for training steps. */

@@ -384,7 +384,7 @@ extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
 static int layer_split(const spk_model* m, const Layer& L) {
   if (m->infer_dt != DT_F16 || m->splitw == 0) return 0;
   if (m->splitw == 4) return m->split_mask[&L - m->layers.data()] ? 1 : 0;
-  // 3: every conv except the 3x3 convs inside a residual block (tools/split_rules.py: their
+  // 3: every conv except the 3x3 convs inside a residual block (tests/diagnostics/split_rules.py: their
   // weight rounding adds the least logit error per MFMA cycle a lo-product costs)
   if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 ? 1 : 0;
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;

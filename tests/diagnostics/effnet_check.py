@@ -1,7 +1,7 @@
 """EfficientNet eval path vs the fp32 oracle (GPU diagnostic)."""
 import sys, time
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
 import numpy as np, torch
 from oracle import refnet

@@ -1,7 +1,7 @@
 """EfficientNet: logit error vs precision knobs (GPU diagnostic)."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd"), str(ROOT / "tests")]
 import numpy as np, torch
 from oracle import refnet

@@ -1,7 +1,7 @@
 """Diagnostic: max |dp| of the eval precision modes over many synthetic images (ResNet-50)."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
 import numpy as np, torch
 from sykepic_hip import arch, synth

@@ -1,5 +1,7 @@
 import sys, os, numpy as np, torch
-sys.path[:0] = ["/root/repo", "/root/repo/syke-pic_amd"]
+import pathlib
+ROOT = pathlib.Path(__file__).resolve().parent.parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
 from sykepic_hip import arch, synth
 from sykepic_hip.net import HipNet
 g = arch.build_graph('resnet18', 50)

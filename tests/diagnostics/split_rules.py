@@ -1,7 +1,7 @@
 """max |dp| of structural split-weight rules over many images and two synthetic nets (GPU diagnostic)."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
 import numpy as np, torch
 from oracle import refnet
