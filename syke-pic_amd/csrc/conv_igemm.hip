@@ -22,20 +22,35 @@
 
 namespace {
 
-constexpr int BK = 64;            // K elements per LDS stage
+constexpr int BK = 64;            // K elements per LDS stage (the default; BKT = 32 instantiations halve it)
 constexpr int ROW_BYTES = BK * 2; // 128-B LDS rows
 
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  // 16-B chunk swizzle: rows r and r^1 share a 256-B bank row; (row>>1)&7
-  // spreads 16 consecutive rows of one chunk column over all 16 slots.
-  return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+// 16-B chunk swizzle.  128-B rows (BK 64): rows r and r^1 share a 256-B bank row; (row>>1)&7 spreads 16
+// consecutive rows of one chunk column over all 16 slots.  64-B rows (BK 32): four rows share a bank row; with
+// chunk ^ ((row>>2)&2) every 16-lane group of a ds_read_b128 fragment read (which mixes two chunk columns, see
+// MI355X_MICROARCH.md LDS) touches 16 distinct slots.
+template <int BKT>
+__device__ __forceinline__ int lds_off_t(int row, int chunk) {
+  if (BKT == 64) return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+  return row * 64 + ((chunk ^ ((row >> 2) & 2)) << 4);
+}
+template <int BKT>
+__device__ __forceinline__ int src_swizzle(int row) {  // DMA lands lane l in slot l % chunks: fetch chunk slot ^ this
+  return BKT == 64 ? ((row >> 1) & 7) : ((row >> 2) & 2);
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST, int BKT = 64>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_igemm_kernel(ConvArgs a, int m_tiles,
                                                                             int n_tiles) {
+  // BKT: K elements per LDS stage.  32 halves the stage: twice the resident blocks per CU, whose load, operand-read
+  // and MFMA phases (which add up within one block) then overlap across blocks.
+  constexpr int BK = BKT;
+  constexpr int ROW_BYTES = BK * 2;
+  constexpr int CPR = BK / 8;  // 16-B chunks per LDS row
+  static_assert(BKT == 64 || (BKT == 32 && MODE != CONV_MODE_STEM && DMA != 3), "K step");
+  auto lds_off = [](int row, int chunk) { return lds_off_t<BKT>(row, chunk); };
   constexpr int NTHREADS = WARPS_M * WARPS_N * 64;
-  constexpr int ROWS_PER_PASS = NTHREADS / 8;  // 8 chunks per 128-B row
+  constexpr int ROWS_PER_PASS = NTHREADS / CPR;
   constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
   constexpr int MT = WM / 16, NT = WN / 16;
   // SPLITW: weights carried as hi + lo (w = w_hi + w_lo, both 16-bit) and both
@@ -58,6 +73,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   static_assert(DMA != 3 || MODE != CONV_MODE_STEM, "no hybrid stem");
   constexpr int PER_TILE = A_ITERS + B_ITERS;  // DMA instructions per wave per tile
   static_assert(!DMA || ROWS_PER_PASS % 16 == 0, "swizzle must not depend on the pass");
+  constexpr int PIECE_ROWS = 1024 / ROW_BYTES;  // rows one wave-wide 16-B-per-lane DMA instruction covers
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // one LDS stage when the whole K fits in it (1x1 convs with Cin = 64):
@@ -86,16 +102,16 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
 
   // ---- per-thread staging coordinates (fixed over the K loop) ----
-  const int srow = tid >> 3;
+  const int srow = tid / CPR;
   // register staging writes chunk c to its swizzled slot; DMA lands lane l of a
   // row in slot l&7, so that lane must FETCH the chunk whose slot that is
-  const int chunk_a = tid & 7;                               // register path: plain chunk, swizzled store
-  const int chunk_b = (tid & 7) ^ ((srow >> 1) & 7);         // DMA path: swizzled source chunk
+  const int chunk_a = tid % CPR;                             // register path: plain chunk, swizzled store
+  const int chunk_b = (tid % CPR) ^ src_swizzle<BKT>(srow);  // DMA path: swizzled source chunk
   const int chunk = (DMA && DMA != 3) ? chunk_b : chunk_a;  // chunk of the ACTIVATION loads
   int a_base[A_ITERS], a_h0[A_ITERS], a_w0[A_ITERS];
   int b_off[B_ITERS];
   const int HoWo = a.Ho * a.Wo;
-  const int KT = a.kt_count > 0 ? a.kt_count : a.K / BK;
+  const int KT = a.kt_count > 0 ? a.kt_count * (64 / BK) : a.K / BK;  // kt_count is in 64-deep steps
   // scalar walk over (tap row r, tap col s, channel block c0) for generic mode
   const int r_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_ph + a.pad) & 1) : 0;
   const int s_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_pw + a.pad) & 1) : 0;
@@ -181,7 +197,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
     const __amdgpu_buffer_rsrc_t rs =
         DMA == 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, live ? a.x_bytes : 0, 0x00020000) : rx;
     // wave-uniform LDS row of this wave's 8-row piece in pass i: wave*8 + i*ROWS_PER_PASS
-    unsigned char* const dA = sA + stage * STAGE_BYTES + wave * (8 * ROW_BYTES);
+    unsigned char* const dA = sA + stage * STAGE_BYTES + wave * (PIECE_ROWS * ROW_BYTES);
     if (MODE == CONV_MODE_STEM) {
       const int krow = kt * 2 + (chunk >> 2);
       const int qq = chunk & 3;
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   auto issue_b = [&](int kt, u32x4_t (&rb)[B_ITERS], int stage, bool live = true) {
     const __amdgpu_buffer_rsrc_t rs =
         DMA == 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, live ? a.w_bytes : 0, 0x00020000) : rw;
-    unsigned char* const dB = sB + stage * STAGE_BYTES + wave * (8 * ROW_BYTES);
+    unsigned char* const dB = sB + stage * STAGE_BYTES + wave * (PIECE_ROWS * ROW_BYTES);
     int wk = kt * (BK * 2);
     if (MODE == CONV_MODE_DGRAD) {
       wk = ((wr * a.kw + ws) * a.Cin + wc0) * 2;
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
     const unsigned char* pa = sA + buf * (DMA ? STAGE_BYTES : A_BYTES);
     const unsigned char* pb = sB + buf * (DMA ? STAGE_BYTES : B_BYTES);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       u32x4_t fa[MT], fb[NT], fl[SPLITW ? NT : 1];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -338,7 +354,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   const int erow = lane / LPR;
   constexpr bool PREFETCH_RES = MT * PASSES <= 8;
   float* const epi = (float*)smem + wave * (16 * EPI_LD);
-  static_assert(WARPS_M * WARPS_N * 16 * EPI_LD * 4 <= (A_BYTES + B_BYTES), "epilogue LDS");
+  // (with 32-deep K steps K >= 64 means both stages are always allocated)
+  static_assert(WARPS_M * WARPS_N * 16 * EPI_LD * 4 <= (BKT == 64 ? 1 : 2) * (A_BYTES + B_BYTES), "epilogue LDS");
 
   for (;;) {
     // the epilogue of THIS tile runs after the staging coordinates have moved on
@@ -595,14 +612,14 @@ bool use_dma() {
 
 thread_local char g_cfg_name[64] = "";
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST = 0>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST = 0, int BKT = 64>
 int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
-  const size_t stage = (size_t)(BM + (SPLITW ? 2 : 1) * BN) * ROW_BYTES;
+  const size_t stage = (size_t)(BM + (SPLITW ? 2 : 1) * BN) * (BKT * 2);
   const int stages = (!DMA || DMA >= 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
   const size_t lds_full = stages * stage;
-  const int kt = a.K / BK;
+  const int kt = a.K / BKT;
   const size_t lds = DMA == 3 ? lds_full : (kt < stages ? kt : stages) * stage;  // hybrid: both stages are written
-  auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA, PERSIST>;
+  auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA, PERSIST, BKT>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
@@ -630,6 +647,16 @@ int launch_hybrid(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
     return -3;
 }
 
+// 32-deep K steps, LDS-DMA, two stages: half the LDS per block (e.g. 256x128: 48 KB, three blocks per CU)
+template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW>
+int launch_bk32(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
+  if constexpr (MODE != CONV_MODE_STEM && (WARPS_M * WARPS_N * 64 / 4) % 16 == 0 && BM % (WARPS_M * WARPS_N * 16) == 0 &&
+                ((SPLITW ? 2 : 1) * BN) % (WARPS_M * WARPS_N * 16) == 0)
+    return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, 2, 0, 32>(a, s, m_tiles, n_tiles);
+  else
+    return -3;
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N>
 int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
   const int m_tiles = (a.M + BM - 1) / BM;
@@ -642,6 +669,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.dma == 2) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0, 1>(a, s, m_tiles, n_tiles); \
     if (a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 2>(a, s, m_tiles, n_tiles); \
     if (a.dma == 4) return launch_hybrid<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 5) return launch_bk32<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0>(a, s, m_tiles, n_tiles);      \
   } while (0)
   if (mode == CONV_MODE_STEM) {
@@ -793,8 +821,8 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
-      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid
-      for (int dma = (cfg == 6 ? 3 : 0); dma < 5; ++dma) {
+      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid, 5 LDS-DMA 2-stage BK 32
+      for (int dma = (cfg == 6 ? 3 : 0); dma < 6; ++dma) {  // 5: LDS-DMA 2-stage with 32-deep K steps
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
         (void)hipEventRecord(e0, s);

@@ -413,6 +413,91 @@ void run(const char* name, const unsigned char* src, unsigned window, float* out
   hipEventDestroy(e1);
 }
 
+// V2 with 32-deep K steps (64-B LDS rows): half the stage, twice the resident blocks
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k32(const unsigned char* src, unsigned window, int KT,
+                                                             float* out) {
+  constexpr int NW = WARPS_M * WARPS_N, NT_ = NW * 64;
+  constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N, MT = WM / 16, NT = WN / 16;
+  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int ROWS_PER_PASS = NT_ / 4;  // 4 chunks per 64-B row
+  constexpr int PER_TILE = (BM + BN) / ROWS_PER_PASS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WARPS_N, wn = wave % WARPS_N;
+  const int frow = lane & 15, fq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, window, 0x00020000);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid * 16; i < 2 * STAGE; i += NT_ * 16) *(u32x4*)(smem + i) = u32x4{0x3c003c00u, 0, 0, 0};
+  __syncthreads();
+  int dma_stage = 0;
+  unsigned goff = (blockIdx.x * 7919u * 4096u) % window;
+  auto issue = [&]() {
+    unsigned char* d = smem + dma_stage * STAGE + wave * (16 * 64);
+#pragma unroll
+    for (int i = 0; i < PER_TILE; ++i) {
+      const unsigned off = (goff + (unsigned)(i * ROWS_PER_PASS * 64 + tid * 16)) % window;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(d + i * ROWS_PER_PASS * 64), 16, off, 0, 0, 0);
+    }
+    goff = (goff + STAGE) % window;
+    dma_stage ^= 1;
+  };
+  auto off32 = [&](int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); };
+  issue();
+  int cs = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue();
+    const unsigned char* pa = smem + cs * STAGE;
+    const unsigned char* pb = pa + BM * 64;
+    u32x4 fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = *(const u32x4*)(pa + off32(wm * WM + i * 16 + frow, fq));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(pb + off32(wn * WN + j * 16 + frow, fq));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mma(fa[i], fb[j], acc[i][j]);
+    cs ^= 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  if (t == 12345.678f) out[blockIdx.x * NT_ + tid] = t;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+void run32(const char* name, const unsigned char* src, unsigned window, float* out, int blocks, int KT) {
+  auto kern = k32<BM, BN, WARPS_M, WARPS_N>;
+  const int lds = 2 * (BM + BN) * 64;
+  hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  const int threads = WARPS_M * WARPS_N * 64;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, src, window, KT, out);
+  hipEventRecord(e0, 0);
+  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, 0, src, window, KT, out);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  ms /= 5;
+  const double fl = (double)blocks * KT * BM * BN * 32 * 2;
+  printf("%-34s %dx%d BK32 w%dx%d blocks %5d KT %3d lds %6d: %8.1f us  %7.1f TFLOP/s  (%s)\n", name, BM, BN, WARPS_M,
+         WARPS_N, blocks, KT, lds, ms * 1000, fl / ms / 1e9, hipGetErrorString(hipGetLastError()));
+}
+
 int main(int argc, char** argv) {
   const unsigned big = 512u << 20, small = 8u << 20;
   unsigned char* src;
@@ -424,7 +509,17 @@ int main(int argc, char** argv) {
   for (int pass = 0; pass < 1; ++pass) {
     const unsigned win = argc > 1 ? (unsigned)atoi(argv[1]) << 20 : small;
     printf("---- DMA window %u MiB, KT %d ----\n", win >> 20, KT);
-    if (argc > 2 && argv[2][0] == '3') {  // 3x3 halo slab: one activation tile feeds 3 taps (B tile and MFMAs x3)
+    if (argc > 2 && argv[2][0] == 'k') {  // 32-deep K steps
+      run<128, 128, 2, 2, 2, 2>("BK64: dma 2 stages", src, win, out, 8192, KT);
+      run32<128, 128, 2, 2>("BK32: dma 2 stages", src, win, out, 8192, 2 * KT);
+      run<128, 64, 2, 2, 2, 2>("BK64: dma 2 stages", src, win, out, 8192, KT);
+      run32<128, 64, 2, 2>("BK32: dma 2 stages", src, win, out, 8192, 2 * KT);
+      run<64, 64, 2, 2, 2, 2>("BK64: dma 2 stages", src, win, out, 16384, KT);
+      run32<64, 64, 2, 2>("BK32: dma 2 stages", src, win, out, 16384, 2 * KT);
+      run<256, 128, 4, 2, 2, 2>("BK64: dma 2 stages", src, win, out, 2048, KT);
+      run32<256, 128, 4, 2>("BK32: dma 2 stages", src, win, out, 2048, 2 * KT);
+      run32<256, 256, 2, 4>("BK32: dma 2 stages", src, win, out, 1024, 2 * KT);
+    } else if (argc > 2 && argv[2][0] == '3') {  // 3x3 halo slab: one activation tile feeds 3 taps (B tile and MFMAs x3)
       run<128, 128, 2, 2, 2, 2, 1>("now: dma 2 stages", src, win, out, 8192, KT);
       run<128, 128, 2, 2, 2, 2, 3>("slab: dma 2 stages", src, win, out, 2048, KT);
       run<128, 128, 2, 2, 4, 2, 3>("slab: dma spread", src, win, out, 2048, KT);
