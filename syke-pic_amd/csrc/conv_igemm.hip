@@ -69,7 +69,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   // DMA == 3: hybrid, two stages: weights by LDS-DMA, activations through two register sets whose
   // LDS stores are interleaved with the MFMA rows (the LDS-DMA path sustains ~70 GB/s per CU, half
   // of what register loads get from L2: splitting the tile over both paths relieves it)
-  constexpr int STAGES = (!DMA || DMA >= 2) ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2));
+  // DMA == 4: ONE stage, no prefetch inside the block (load, wait, multiply): a third of the LDS of the two-stage
+  // loop at the same tile, so more blocks are resident and THEIR phases overlap
+  constexpr int STAGES = DMA == 4 ? 1 : ((!DMA || DMA >= 2) ? 2 : (STAGE_BYTES <= 32768 ? 4 : (STAGE_BYTES <= 49152 ? 3 : 2)));
   static_assert(DMA != 3 || MODE != CONV_MODE_STEM, "no hybrid stem");
   constexpr int PER_TILE = A_ITERS + B_ITERS;  // DMA instructions per wave per tile
   static_assert(!DMA || ROWS_PER_PASS % 16 == 0, "swizzle must not depend on the pass");
@@ -452,6 +454,15 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // dead loads/stores of the last step
       __builtin_amdgcn_s_barrier();  // tile buffers are reused by the epilogue
+    } else if (DMA == 4) {
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt) __builtin_amdgcn_s_barrier();  // every wave is done reading the stage
+        issue_loads(kt, ra0, rb0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        compute(0);
+      }
+      __builtin_amdgcn_s_barrier();  // the tile buffer is reused by the epilogue
     } else if (DMA) {
     // One barrier per K step.  At the top of step kt the wave waits until its own
     // pieces of tile kt have landed (all but the STAGES-2 younger tiles' DMAs
@@ -615,7 +626,7 @@ thread_local char g_cfg_name[64] = "";
 template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST = 0, int BKT = 64>
 int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   const size_t stage = (size_t)(BM + (SPLITW ? 2 : 1) * BN) * (BKT * 2);
-  const int stages = (!DMA || DMA >= 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2));
+  const int stages = DMA == 4 ? 1 : ((!DMA || DMA >= 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2)));
   const size_t lds_full = stages * stage;
   const int kt = a.K / BKT;
   const size_t lds = DMA == 3 ? lds_full : (kt < stages ? kt : stages) * stage;  // hybrid: both stages are written
@@ -670,6 +681,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 2>(a, s, m_tiles, n_tiles); \
     if (a.dma == 4) return launch_hybrid<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
     if (a.dma == 5) return launch_bk32<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 6) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 4>(a, s, m_tiles, n_tiles); \
     return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0>(a, s, m_tiles, n_tiles);      \
   } while (0)
   if (mode == CONV_MODE_STEM) {
@@ -821,8 +833,8 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
-      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid, 5 LDS-DMA 2-stage BK 32
-      for (int dma = (cfg == 6 ? 3 : 0); dma < 6; ++dma) {  // 5: LDS-DMA 2-stage with 32-deep K steps
+      // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid, 5 LDS-DMA 2-stage BK 32, 6 LDS-DMA 1 stage
+      for (int dma = (cfg == 6 ? 3 : 0); dma < 7; ++dma) {  // 5: LDS-DMA 2-stage, 32-deep K steps; 6: LDS-DMA 1 stage
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
         (void)hipEventRecord(e0, s);

@@ -105,6 +105,30 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void k(const unsigned char* 
       cs = cs + 1 == STAGES ? 0 : cs + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (V == 12) {
+    // V12: ONE stage per block (no intra-block prefetch): load, wait, multiply; the overlap comes from the
+    // other blocks resident on the CU (a third of the LDS of the two-stage loop at the same tile)
+    for (int kt = 0; kt < KT; ++kt) {
+      __builtin_amdgcn_s_barrier();  // everyone is done reading the stage
+      issue();
+      dma_stage = 0;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const unsigned char* pa = smem;
+      const unsigned char* pb = pa + BM * 128;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 fa[MT], fb[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *(const u32x4*)(pa + lds_off(wm * WM + i * 16 + frow, ks * 4 + fq));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = *(const u32x4*)(pb + lds_off(wn * WN * NBM + j * 16 + frow, ks * 4 + fq));
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j % NTA] = mma(fa[i], fb[j], acc[i][j % NTA]);
+      }
+    }
   } else if (V == 4 || V == 5 || V == 6) {
     // V4: all fragments up front, DMA pieces spread between the MFMA rows
     // V5: DMA + MFMA on constant operands (no ds_read); V6: ds_read + DMA, no MFMA
@@ -509,7 +533,19 @@ int main(int argc, char** argv) {
   for (int pass = 0; pass < 1; ++pass) {
     const unsigned win = argc > 1 ? (unsigned)atoi(argv[1]) << 20 : small;
     printf("---- DMA window %u MiB, KT %d ----\n", win >> 20, KT);
-    if (argc > 2 && argv[2][0] == 'k') {  // 32-deep K steps
+    if (argc > 2 && argv[2][0] == '1') {  // one stage per block, more blocks per CU
+      run<256, 128, 4, 2, 2, 2>("2 stages", src, win, out, 2048, KT);
+      run<256, 128, 4, 2, 12, 1>("1 stage", src, win, out, 2048, KT);
+      run<128, 128, 2, 2, 2, 2>("2 stages", src, win, out, 8192, KT);
+      run<128, 128, 2, 2, 12, 1>("1 stage", src, win, out, 8192, KT);
+      run<256, 256, 2, 4, 2, 2>("2 stages", src, win, out, 1024, KT);
+      run<256, 256, 2, 4, 12, 1>("1 stage", src, win, out, 1024, KT);
+      run<128, 64, 2, 2, 12, 1>("1 stage", src, win, out, 8192, KT);
+      run<256, 128, 4, 2, 2, 2, 2>("split 2 stages", src, win, out, 2048, KT);
+      run<256, 128, 4, 2, 12, 1, 2>("split 1 stage", src, win, out, 2048, KT);
+      run<128, 128, 2, 2, 12, 1, 2>("split 1 stage", src, win, out, 4096, KT);
+      run<128, 64, 2, 2, 12, 1, 2>("split 1 stage", src, win, out, 8192, KT);
+    } else if (argc > 2 && argv[2][0] == 'k') {  // 32-deep K steps
       run<128, 128, 2, 2, 2, 2>("BK64: dma 2 stages", src, win, out, 8192, KT);
       run32<128, 128, 2, 2>("BK32: dma 2 stages", src, win, out, 8192, 2 * KT);
       run<128, 64, 2, 2, 2, 2>("BK64: dma 2 stages", src, win, out, 8192, KT);
