@@ -677,7 +677,7 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
 #define SPK_GO(MODE, DT, SW)                                                                   \
   do {                                                                                         \
     if (a.dma >= 0 ? a.dma == 1 : use_dma()) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 1>(a, s, m_tiles, n_tiles); \
-    if (a.dma == 2) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 0, 1>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 2) return -3; /* the persistent register-staged flavour never won a layer: not instantiated */ \
     if (a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW, 2>(a, s, m_tiles, n_tiles); \
     if (a.dma == 4) return launch_hybrid<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
     if (a.dma == 5) return launch_bk32<BM, BN, WARPS_M, WARPS_N, MODE, DT, SW>(a, s, m_tiles, n_tiles); \
@@ -834,7 +834,8 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (cfg == 1 && a.Cout != 64) continue;
       if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
       // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid, 5 LDS-DMA 2-stage BK 32, 6 LDS-DMA 1 stage
-      for (int dma = (cfg == 6 ? 3 : 0); dma < 7; ++dma) {  // 5: LDS-DMA 2-stage, 32-deep K steps; 6: LDS-DMA 1 stage
+      for (int dma = (cfg == 6 ? 3 : 0); dma < 7; ++dma) {
+        if (dma == 2) continue;  // 5: LDS-DMA 2-stage, 32-deep K steps; 6: LDS-DMA 1 stage
         a.dma = dma;
         if (launch_with(a, mode, cfg, s, nullptr)) continue;  // warm-up
         (void)hipEventRecord(e0, s);
