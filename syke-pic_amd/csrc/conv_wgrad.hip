@@ -18,6 +18,11 @@
 // atomics).
 #include "spk_common.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <tuple>
+
 struct WgradArgs {
   const bf16_t* x;
   const bf16_t* dy;
@@ -56,7 +61,10 @@ __device__ __forceinline__ u32x4_t tr_frag(const unsigned char* tile, int k0, in
   return u32x4_t{a[0], a[1], b[0], b[1]};
 }
 
-template <int BCO, int BCI, bool STEM>
+// NBUF: LDS stages.  2: the next pixel block is stored while the current one is multiplied (one barrier per
+// step).  1: half the LDS - twice the resident blocks, whose phases overlap instead (two barriers per step);
+// which one is faster depends on the layer, spk_wgrad_launch times both once per problem.
+template <int BCO, int BCI, bool STEM, int NBUF>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_tiles) {
   constexpr int BK = 64;  // pixels per LDS stage
   constexpr int WCO = BCO / 2, WCI = BCI / 2;
@@ -67,8 +75,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
   constexpr int DY_IT = BK / DY_RPP, X_IT = BK / X_RPP;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const sD = smem;                  // [2][BK][BCO]
-  unsigned char* const sX = smem + 2 * DY_BYTES;   // [2][BK][BCI]
+  unsigned char* const sD = smem;                     // [NBUF][BK][BCO]
+  unsigned char* const sX = smem + NBUF * DY_BYTES;   // [NBUF][BK][BCI]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
   }
   __syncthreads();
   for (int st = 0; st < nsteps; ++st) {
-    const int buf = st & 1;
+    const int buf = NBUF == 2 ? (st & 1) : 0;
     if (st + 1 < nsteps) issue(p_begin + (st + 1) * BK);
     const unsigned char* pd = sD + buf * DY_BYTES;
     const unsigned char* px = sX + buf * X_BYTES;
@@ -163,7 +171,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma16<DT_BF16>(fa[i], fb[j], acc[i][j]);
     }
-    if (st + 1 < nsteps) stash(buf ^ 1);
+    if (NBUF == 1) __syncthreads();  // every wave is done reading the only stage
+    if (st + 1 < nsteps) stash(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -182,12 +191,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
       }
 }
 
-template <int BCO, int BCI, bool STEM>
-int launch(const WgradArgs& a, int splits, hipStream_t s) {
+template <int BCO, int BCI, bool STEM, int NBUF>
+int launch_nb(const WgradArgs& a, int splits, hipStream_t s) {
   const int co_tiles = a.Cout / BCO;
   const int k_tiles = a.Ktot / BCI;
-  const size_t lds = 2 * (size_t)64 * (BCO + BCI) * 2;
-  auto k = conv_wgrad_kernel<BCO, BCI, STEM>;
+  const size_t lds = NBUF * (size_t)64 * (BCO + BCI) * 2;
+  auto k = conv_wgrad_kernel<BCO, BCI, STEM, NBUF>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -195,6 +204,44 @@ int launch(const WgradArgs& a, int splits, hipStream_t s) {
   }
   hipLaunchKernelGGL(k, dim3(co_tiles * k_tiles, splits), dim3(256), lds, s, a, co_tiles);
   return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// one- vs two-stage: timed once per problem and process (both give bit-identical slabs)
+std::map<std::tuple<int, int, int, int, int, int, int, int>, int> g_wg_tuned;
+
+template <int BCO, int BCI, bool STEM>
+int launch(const WgradArgs& a, int splits, hipStream_t s) {
+  static const int forced = getenv("SPK_WGRAD_NBUF") ? atoi(getenv("SPK_WGRAD_NBUF")) : 0;
+  int nbuf = forced;
+  if (nbuf != 1 && nbuf != 2) {
+    const auto key = std::make_tuple(a.M, a.Cin, a.Cout, a.kh, a.stride, (int)STEM, splits, BCO * 1000 + BCI);
+    auto it = g_wg_tuned.find(key);
+    if (it == g_wg_tuned.end()) {
+      hipEvent_t e0, e1;
+      int best = 2;
+      if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        float tbest = 1e30f;
+        for (int nb = 2; nb >= 1; --nb) {
+          if (nb == 2 ? launch_nb<BCO, BCI, STEM, 2>(a, splits, s) : launch_nb<BCO, BCI, STEM, 1>(a, splits, s)) continue;
+          (void)hipEventRecord(e0, s);
+          for (int r = 0; r < 2; ++r)
+            nb == 2 ? launch_nb<BCO, BCI, STEM, 2>(a, splits, s) : launch_nb<BCO, BCI, STEM, 1>(a, splits, s);
+          (void)hipEventRecord(e1, s);
+          float ms = 1e30f;
+          if (hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+          if (ms < tbest) { tbest = ms; best = nb; }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (getenv("SPK_TUNE_LOG"))
+          fprintf(stderr, "[spk tune] wgrad M%d C%d->%d k%d s%d: %d stage(s) (%.1f us)\n", a.M, a.Cin, a.Cout, a.kh,
+                  a.stride, best, tbest * 500.f);
+      }
+      it = g_wg_tuned.emplace(key, best).first;
+    }
+    nbuf = it->second;
+  }
+  return nbuf == 1 ? launch_nb<BCO, BCI, STEM, 1>(a, splits, s) : launch_nb<BCO, BCI, STEM, 2>(a, splits, s);
 }
 
 }  // namespace
