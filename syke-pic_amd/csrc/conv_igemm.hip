@@ -690,11 +690,12 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
   }
   if (mode == CONV_MODE_DGRAD) SPK_GO(CONV_MODE_DGRAD, DT_BF16, 0);
   if (a.dt == DT_F16 && (a.cin_s > 0 || a.cout_s > 0)) {
-    // stored channels != padded GEMM channels: the two flavours instantiated with the channel checks
+    // stored channels != padded GEMM channels: the three flavours instantiated with the channel checks
 #define SPK_GO_PAD(SW)                                                                                        \
   do {                                                                                                        \
     if (a.dma == 0) return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, SW, 0, 2>(a, s, m_tiles, n_tiles); \
     if (a.dma < 0 || a.dma == 3) return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, SW, 2, 2>(a, s, m_tiles, n_tiles); \
+    if (a.dma == 6) return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, SW, 4, 2>(a, s, m_tiles, n_tiles); \
     return -3;                                                                                                \
   } while (0)
     if (a.splitw) SPK_GO_PAD(1);
