@@ -811,19 +811,21 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
                     a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y) + 2 * (a.cin_s > 0) + 4 * (a.cout_s > 0));
   auto it = g_tuned.find(key);
   if (it == g_tuned.end()) {
+    // in-place accumulation (dgrad into an existing gradient): re-running it would add twice, so the candidates
+    // write to a scratch tensor and read the real one as their shortcut operand - same traffic, nothing clobbered
+    bf16_t* scratch = nullptr;
+    bf16_t* const real_y = a.y;
     if ((const void*)a.res == (const void*)a.y && a.res) {
-      // in-place accumulation (dgrad into an existing gradient): re-running it
-      // would add twice — use the heuristic now; the first-writer launch of the
-      // same problem tunes it
-      const TuneKey k2(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
-                       a.stats != nullptr, false);
-      auto it2 = g_tuned.find(k2);
-      if (it2 == g_tuned.end()) return launch_with(a, mode, pick_cfg(a.M, a.Cout), s, m_tiles_out);
-      a.dma = it2->second.second;
-      return launch_with(a, mode, it2->second.first, s, m_tiles_out);
+      const size_t pixels = a.cls_ph >= 0 ? (size_t)a.N * a.oH * a.oW : (size_t)a.M;
+      if (hipMalloc((void**)&scratch, pixels * a.Cout * 2) != hipSuccess)
+        return launch_with(a, mode, pick_cfg(a.M, a.Cout), s, m_tiles_out);
+      a.y = scratch;
     }
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+      if (scratch) (void)hipFree(scratch);
+      return -1;
+    }
     float best = 1e30f;
     std::pair<int, int> win(pick_cfg(a.M, a.Cout), 0);
     const int cands[] = {0, 1, 2, 3, 4, 5, 6};
@@ -871,6 +873,11 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (scratch) {
+      (void)hipStreamSynchronize(s);
+      (void)hipFree(scratch);
+      a.y = real_y;
+    }
     it = g_tuned.emplace(key, win).first;
     if (getenv("SPK_TUNE_LOG"))
       fprintf(stderr, "[spk tune] mode %d dt %d sw %d N%d %dx%d C%d->%d k%d s%d: cfg %d dma %d (%.1f us)\n", mode,
