@@ -252,10 +252,12 @@ void spk_wgrad_plan(int M, int Cout, int Ktot, int* splits, int* pix_per_split) 
   const int bco = Cout % 128 == 0 ? 128 : 64;
   const int bci = 128;
   const int tiles = (Cout / bco) * ((Ktot + bci - 1) / bci);
-  int sp = (1024 + tiles - 1) / tiles;
+  static const int want = getenv("SPK_WGRAD_BLOCKS") ? atoi(getenv("SPK_WGRAD_BLOCKS")) : 1024;
+  int sp = (want + tiles - 1) / tiles;
   const int max_sp = (M + 511) / 512;
   if (sp > max_sp) sp = max_sp;
-  if (sp > 96) sp = 96;  // slab traffic + the ordered reduce grow with the split count
+  static const int cap = getenv("SPK_WGRAD_SPLIT_CAP") ? atoi(getenv("SPK_WGRAD_SPLIT_CAP")) : 96;
+  if (sp > cap) sp = cap;  // slab traffic + the ordered reduce grow with the split count
   if (sp < 1) sp = 1;
   int pps = ((M + sp - 1) / sp + 63) / 64 * 64;
   sp = (M + pps - 1) / pps;
