@@ -209,3 +209,35 @@ def test_halo_slab_3x3_kernel_matches_the_implicit_gemm():
         assert np.array_equal(outs[name]["a"], ref["a"]), name
         assert np.abs(outs[name]["z"] - ref["z"]).max() < 2e-3 * ref["z"].std() + 1e-2
         assert (outs[name]["z"].argmax(1) == ref["z"].argmax(1)).all()
+
+
+def test_every_main_loop_flavour_gives_the_same_network_output():
+    """Each main-loop flavour of the implicit-GEMM kernel (register-staged, LDS-DMA 3-4 stages, 2 stages,
+    hybrid, 32-deep K steps, single stage) forced for every conv of ResNet-50: all accumulate each output
+    element in the same K order, so the logits are bit-identical whichever the autotuner picks."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from sykepic_hip import arch, synth\n"
+        "from sykepic_hip.net import HipNet\n"
+        "g = arch.build_graph('resnet50', 50)\n"
+        "sd = synth.synth_state_dict(arch.param_specs(g), seed=2)\n"
+        "net = HipNet('resnet50', 50, weights=None)\n"
+        "net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); net.eval()\n"
+        "x = torch.from_numpy(synth.synth_images(6, 3, 96, 128, seed=5)).cuda()\n"
+        "np.save(sys.argv[1], net.forward(x).cpu().numpy())\n"
+    ) % (str(ROOT_DIR), str(ROOT_DIR / "syke-pic_amd"))
+    outs = {}
+    for cfg, dma in ((3, 3), (3, 0), (0, 1), (0, 4), (3, 5), (0, 5), (3, 6), (4, 6), (2, 3)):
+        env = dict(os.environ)
+        env["SPK_CONV_CFG"], env["SPK_CONV_DMA"] = str(cfg), str(dma)
+        path = f"/tmp/flavour_{cfg}_{dma}.npy"
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env)
+        outs[(cfg, dma)] = np.load(path)
+    ref = outs[(3, 3)]
+    assert np.abs(ref).max() > 0.1
+    for key, z in outs.items():
+        assert np.array_equal(z, ref), f"cfg {key[0]} flavour {key[1]}: max diff {np.abs(z - ref).max()}"
