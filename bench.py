@@ -285,13 +285,22 @@ def main():
     for m in modes:
         if rank == 0:
             print(f"[bench] {m}: {args.warmup} warm-up + {args.steps} timed steps", file=sys.stderr, flush=True)
+        if m == "train" and results and args.mode == "both":
+            # the training step rides along under "train": a failure there must not take the headline with it
+            try:
+                results.append(run_mode(m, args, net, x, y, dist, dev, rank, world))
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] train leg failed: {exc!r}", file=sys.stderr, flush=True)
+                results.append({"metric": f"IFCB images/sec, {args.network} 224x224 train step", "value": None,
+                                "error": repr(exc)})
+            continue
         results.append(run_mode(m, args, net, x, y, dist, dev, rank, world))
     if rank == 0:
         out = results[0]
         if len(results) > 1:
             t = results[1]
-            out["train"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline")
-                            if k in t}
+            out["train"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
+                                              "error") if k in t}
             if "cpu_baseline" in t:
                 out["train"]["cpu_baseline"] = t["cpu_baseline"]
         print(json.dumps(out), flush=True)
