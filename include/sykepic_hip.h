@@ -190,6 +190,35 @@ int spk_model_read_activation(spk_model* m, int tensor_id, int n, float* host, i
  * spk_train_forward_backward, float32 NCHW like spk_model_read_activation. */
 int spk_model_read_activation_grad(spk_model* m, int tensor_id, int n, float* host, int64_t numel);
 
+/* --- Test hooks: single operators of the training step on caller-provided device buffers ---
+ * What `out = net(x)` (train mode) and `loss.backward()` run for ONE Conv2d+BatchNorm2d layer
+ * (sykepic/train/train.py:240,242): the same launches spk_train_forward_backward makes, so that a parity
+ * test can hand a kernel known operands and compare with torch autograd on the same bf16-rounded operands.
+ * Activations / gradients: NHWC bf16 device buffers (the 7x7/2 stem input: 4 stored channels, even width);
+ * weights and weight gradients: float32 [Cout][kh][kw][Cin] device buffers; h, w are the conv INPUT size.
+ * Channel counts: multiples of 64 (stem: cin <= 4, cout 64).  Synchronous (the call returns after the work).
+ *
+ * conv -> batch statistics -> normalise (+res) (+ReLU).  raw: conv output before BatchNorm (bf16);
+ * mask: one ReLU bit per element ([M][C/8] bytes; may be NULL when relu == 0); mean_invstd: float[2][C];
+ * running_mean / running_var are updated in place (momentum 0.1, unbiased variance). */
+int spk_op_conv_bn_train_forward(const void* x_dev, const float* w_dev, const float* gamma_dev, const float* beta_dev,
+                                 float* running_mean_dev, float* running_var_dev, const void* res_dev, void* out_dev,
+                                 void* raw_dev, unsigned char* mask_dev, float* mean_invstd_dev, int n, int h, int w,
+                                 int cin, int cout, int k, int stride, int pad, int relu, void* hip_stream);
+/* BatchNorm2d (+ReLU) backward: g = gradient w.r.t. the layer output [M][C]; dy = gradient w.r.t. the conv output;
+ * g_res (optional) receives (or, res_accumulate != 0, adds) the gradient of the shortcut operand;
+ * dgamma / dbeta: float[C] (either may be NULL). */
+int spk_op_bn_backward(const void* g_dev, const unsigned char* mask_dev, const void* raw_dev, const float* mean_dev,
+                       const float* invstd_dev, const float* gamma_dev, float* dgamma_dev, float* dbeta_dev,
+                       void* dy_dev, void* g_res_dev, int res_accumulate, int m_rows, int channels, int relu,
+                       void* hip_stream);
+/* Conv2d data gradient: dx [n,h,w,cin] (= or, accumulate != 0, +=) conv_transpose(dy [n,ho,wo,cout], w). */
+int spk_op_conv_dgrad(const void* dy_dev, const float* w_dev, void* dx_dev, int accumulate, int n, int h, int w,
+                      int cin, int cout, int k, int stride, int pad, void* hip_stream);
+/* Conv2d weight gradient: dw [Cout][kh][kw][Cin] float32 from x [n,h,w,cin] and dy [n,ho,wo,cout]. */
+int spk_op_conv_wgrad(const void* x_dev, const void* dy_dev, float* dw_dev, int n, int h, int w, int cin, int cout,
+                      int k, int stride, int pad, void* hip_stream);
+
 /* --- ROI preprocessing straight from the .roi blob ---
  * One ROI of an IFCB sample: byte offset into the .roi blob, width, height
  * (columns 17/15/16 of the .adc line, sykepic/utils/ifcb.py:100-110). */

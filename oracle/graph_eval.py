@@ -115,3 +115,131 @@ def run_train_forced(graph, state, x, forced, eps=1e-5):
             v = a
         acts[op.dst] = force(v, op.dst)
     return acts
+
+
+def _r16(t):
+    return t.bfloat16().float()
+
+
+def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None, first_op=0):
+    """One training step (forward, mean cross-entropy, backward) with every tensor rounded to bf16 exactly where
+    the HIP path stores one: conv operands, the raw conv output, the post-BatchNorm activation, and — unlike
+    autograd through `run_train_bf16` — every GRADIENT tensor too (the gradient of each activation, the gradient
+    w.r.t. each conv output, accumulation into a tensor with two consumers rounds after each add, in the
+    executor's reverse layer order).  Statistics, parameter gradients and the head stay float32.
+
+    Purpose: it splits the distance between the GPU's gradients and fp32 autograd into
+      |GPU - this|        what the kernels add (expected ~1e-3: accumulation order, rare 1-ulp flips), and
+      |this - autograd|   what bf16 gradient STORAGE costs for any implementation with these rounding points.
+    The chain rule below is the textbook Conv2d / BatchNorm2d(train) / ReLU / MaxPool2d / AdaptiveAvgPool2d /
+    Linear backward (what torch autograd evaluates for the reference at sykepic/train/train.py:242).
+
+    round_grads=False keeps every gradient tensor in float32 on the SAME forward (= exact backpropagation through
+    the rounded forward with straight-through roundings): the difference between the two settings is purely the
+    cost of storing gradients in bf16.
+
+    forced: {tensor id: activation the GPU produced}.  Each layer then starts from the GPU's own input (its own
+    output still decides its ReLU mask and BatchNorm statistics), so a 1-ulp difference cannot grow through the
+    following layers: random-weight nets with train-mode BatchNorm over a handful of samples amplify one flipped
+    bf16 ulp into 10-50 % of a gradient tensor (measured: two float32 evaluation orders of this very function),
+    which says nothing about a kernel.
+
+    first_op > 0 (needs `forced`): only ops[first_op:] are evaluated, from the GPU's activations — a truncated
+    backward over the tail of the network (cheap enough at the benched batch size); x may then be None.
+
+    state: {key: float32 tensor}.  Returns dict(logits, loss, acts, grads {state key: tensor},
+    act_grads {tensor id: tensor})."""
+    rg = _r16 if round_grads else (lambda t: t)
+    acts = {0: _r16(x)} if x is not None else {}
+    if first_op > 0:
+        for op in graph.ops[first_op:]:
+            for t in (op.src, op.res):
+                if t >= 0 and t in forced:
+                    acts.setdefault(t, forced[t].float())
+    saved, own = {}, {}
+    for i, op in enumerate(graph.ops):
+        if i < first_op:
+            continue
+        a = acts[op.src]
+        if op.kind == arch.OP_CONV:
+            wb = _r16(state[op.name + ".weight"])
+            y32 = F.conv2d(a, wb, None, op.stride, op.pad)
+            mean = y32.double().mean((0, 2, 3))
+            var = y32.double().var((0, 2, 3), unbiased=False)
+            invstd = (1.0 / torch.sqrt(var + eps)).float()
+            mean = mean.float()
+            yr = _r16(y32)
+            g, b = state[op.bn + ".weight"], state[op.bn + ".bias"]
+            scale = g * invstd
+            shift = b - mean * scale
+            v = yr * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+            if op.res >= 0:
+                v = v + acts[op.res]
+            pos = None
+            if op.relu:
+                pos = v > 0
+                v = F.relu(v)
+            saved[i] = (a, wb, yr, mean, invstd, pos)
+            v = _r16(v)
+        elif op.kind == arch.OP_MAXPOOL:
+            v, idx = F.max_pool2d(a, op.k, op.stride, op.pad, return_indices=True)
+            saved[i] = (a.shape, idx)
+        elif op.kind == arch.OP_GAVGPOOL:
+            v = a.mean((2, 3))
+            saved[i] = a.shape
+        elif op.kind == arch.OP_LINEAR:
+            v = F.linear(a, state[op.name + ".weight"], state[op.name + ".bias"])
+        else:
+            v = a
+        own[op.dst] = v   # this layer's own output (before forcing): forward check at the GPU's operating point
+        acts[op.dst] = forced[op.dst].to(v.dtype) if forced is not None and op.dst in forced else v
+    last = graph.ops[-1].dst
+    logits = acts[last]
+    n = logits.shape[0]
+    logp = F.log_softmax(logits, 1)
+    loss = -logp[torch.arange(n), y].mean()
+    G = {last: (logp.exp() - F.one_hot(y, logits.shape[1]).float()) / n}
+    grads = {}
+
+    def put(t, val):  # first consumer writes, later ones add and round again
+        G[t] = rg(val) if t not in G else rg(G[t] + val)
+
+    for i in range(len(graph.ops) - 1, first_op - 1, -1):
+        op = graph.ops[i]
+        if op.dst not in G:
+            continue
+        gy = G[op.dst]
+        if op.kind == arch.OP_LINEAR:
+            xin = acts[op.src]
+            grads[op.name + ".weight"] = gy.t() @ xin
+            grads[op.name + ".bias"] = gy.sum(0)
+            G[op.src] = gy @ state[op.name + ".weight"]
+        elif op.kind == arch.OP_GAVGPOOL:
+            shp = saved[i]
+            inv = torch.tensor(1.0 / (shp[2] * shp[3]), dtype=torch.float32)
+            G[op.src] = rg((gy * inv).view(shp[0], shp[1], 1, 1).expand(shp).contiguous())
+        elif op.kind == arch.OP_MAXPOOL:
+            shp, idx = saved[i]
+            gx = torch.zeros(shp[0], shp[1], shp[2] * shp[3])
+            gx.scatter_add_(2, idx.flatten(2), gy.flatten(2))
+            G[op.src] = rg(gx.view(shp))
+        elif op.kind == arch.OP_CONV:
+            a, wb, yr, mean, invstd, pos = saved[i]
+            dz = gy * pos if pos is not None else gy
+            if op.res >= 0:
+                put(op.res, dz)
+            m = dz.shape[0] * dz.shape[2] * dz.shape[3]
+            xhat = (yr - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
+            s1 = dz.double().sum((0, 2, 3))
+            s2 = (dz * xhat).double().sum((0, 2, 3))
+            grads[op.bn + ".bias"] = s1.float()
+            grads[op.bn + ".weight"] = s2.float()
+            c1, c2 = (s1 / m).float().view(1, -1, 1, 1), (s2 / m).float().view(1, -1, 1, 1)
+            k3 = (state[op.bn + ".weight"] * invstd).view(1, -1, 1, 1)
+            dy = rg(k3 * (dz - c1 - xhat * c2))
+            if op.src != 0:
+                put(op.src, torch.nn.grad.conv2d_input(a.shape, wb, dy, op.stride, op.pad))
+            grads[op.name + ".weight"] = torch.nn.grad.conv2d_weight(a, wb.shape, dy, op.stride, op.pad)
+        else:
+            G[op.src] = gy
+    return {"logits": logits, "loss": loss, "acts": acts, "own": own, "grads": grads, "act_grads": G}

@@ -94,4 +94,11 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
                             float* logits_dev);
 int spk_read_flat(spk_model* m, const float* flat, const Param& p, float* host);
 void spk_train_free(spk_model* m);
+// backward of one convolution (train.hip): shared by the training step and the single-operator test hooks
+int spk_conv_dgrad_all(const bf16_t* dy, const bf16_t* wdg, bf16_t* dx, bool accumulate, int n, int oh, int ow,
+                       int cout, int ih, int iw, int cin, int k, int stride, int pad, hipStream_t s);
+size_t spk_conv_wgrad_slab_floats(int M, int cin, int cout, int k, bool stem);
+int spk_conv_wgrad_slabs(const bf16_t* x, const bf16_t* dy, float* slabs, int n, int ih, int iw, int cin, int oh,
+                         int ow, int cout, int k, int stride, int pad, bool stem, hipStream_t s);
+int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cout, int k, bool stem, hipStream_t s);
 void spk_train_mark_dirty(spk_model* m);

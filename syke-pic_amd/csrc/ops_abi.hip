@@ -1,0 +1,135 @@
+// Single-operator entry points of the C-ABI (include/sykepic_hip.h, "test hooks: single operators").
+// Each one runs exactly the launches a training step makes for ONE layer (the shared helpers of train.hip and
+// the spk_launch_* functions), on caller-provided device buffers, so that a parity test can hand a kernel
+// known operands and compare its output with autograd evaluated on the same (bf16-rounded) operands:
+//   conv + train-mode BatchNorm forward   torch Conv2d + BatchNorm2d(+add)(+ReLU), sykepic/train/train.py:240
+//   BatchNorm / conv backward             what loss.backward() runs for that layer,  sykepic/train/train.py:242
+// Scratch is allocated and freed inside the call (these are not on any hot path).
+#include "model.h"
+
+#include <cstring>
+#include <vector>
+
+static int ofail(int code, const std::string& msg) {
+  spk_set_error(msg);
+  return code;
+}
+
+namespace {
+struct Scratch {
+  std::vector<void*> p;
+  ~Scratch() { for (void* q : p) (void)hipFree(q); }
+  template <typename T> T* get(size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, (count ? count : 1) * sizeof(T)) != hipSuccess) return nullptr;
+    p.push_back(q);
+    return (T*)q;
+  }
+};
+bool stem_shape(int cin, int cout, int k, int stride, int pad) {
+  return cin <= 4 && k == 7 && stride == 2 && pad == 3 && cout == 64;
+}
+}  // namespace
+
+#define O_TRY(expr, what)                                                         \
+  do {                                                                            \
+    if ((expr) != 0) return ofail(SPK_ERR_HIP, std::string(what) + " failed");    \
+  } while (0)
+
+extern "C" int spk_op_conv_bn_train_forward(const void* x, const float* w_ohwi, const float* gamma, const float* beta,
+                                            float* running_mean, float* running_var, const void* res, void* out,
+                                            void* raw, unsigned char* mask, float* mean_invstd, int n, int h, int w,
+                                            int cin, int cout, int k, int stride, int pad, int relu, void* stream) {
+  if (!x || !w_ohwi || !gamma || !beta || !running_mean || !running_var || !out || !raw || !mean_invstd || n < 1)
+    return ofail(SPK_ERR_ARG, "op_conv_bn_train_forward: bad arguments");
+  const bool stem = stem_shape(cin, cout, k, stride, pad);
+  if ((!stem && (cin % 64 || cin < 64)) || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64 (or the 7x7/2 stem)");
+  hipStream_t s = (hipStream_t)stream;
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  const int M = n * oh * ow;
+  const int kpad = stem ? 256 : k * k * cin;
+  Scratch sc;
+  bf16_t* wp = sc.get<bf16_t>((size_t)cout * kpad);
+  float* part = sc.get<float>((size_t)((M + 60) / 61) * 2 * cout);
+  float* st = sc.get<float>((size_t)2 * cout);
+  float* tmp = sc.get<float>((size_t)cout * 2 * 64);
+  if (!wp || !part || !st || !tmp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pack_weights(w_ohwi, wp, cout, k, k, cin, stem ? CONV_MODE_STEM : CONV_MODE_GENERIC, DT_BF16, 0, s),
+        "pack_weights");
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.cfg = a.dma = -1;
+  a.cls_ph = a.cls_pw = -1;
+  a.x = (const bf16_t*)x; a.w = wp; a.y = (bf16_t*)raw;
+  const int wst = stem ? (w + 1) & ~1 : w;  // the stem input is stored with an even row pitch (zero pad column)
+  a.N = n; a.H = h; a.W = wst; a.Cin = stem ? 4 : cin; a.Ho = oh; a.Wo = ow; a.Cout = cout;
+  a.kh = a.kw = k; a.stride = stride; a.pad = pad;
+  a.M = M; a.K = kpad; a.dt = DT_BF16;
+  a.x_bytes = (unsigned)((size_t)n * h * wst * a.Cin * 2);
+  a.w_bytes = (unsigned)((size_t)cout * kpad * 2);
+  a.stats = part;
+  int m_tiles = 0;
+  O_TRY(spk_conv_launch(a, stem ? CONV_MODE_STEM : CONV_MODE_GENERIC, s, &m_tiles), "conv launch");
+  O_TRY(spk_launch_bn_finalize(part, m_tiles, cout, (double)M, gamma, beta, running_mean, running_var, mean_invstd,
+                               mean_invstd + cout, st, st + cout, 1e-5f, 0.1f, tmp, s), "bn_finalize");
+  O_TRY(spk_launch_bn_apply((const bf16_t*)raw, st, st + cout, (const bf16_t*)res, (bf16_t*)out, mask,
+                            (size_t)M * cout, cout, relu, s), "bn_apply");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_conv_bn_train_forward: kernel failed");
+  return SPK_OK;
+}
+
+extern "C" int spk_op_bn_backward(const void* g, const unsigned char* mask, const void* raw, const float* mean,
+                                  const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dy,
+                                  void* g_res, int res_accumulate, int M, int C, int relu, void* stream) {
+  if (!g || !raw || !mean || !invstd || !gamma || !dy || M < 1 || C % 8 || (relu && !mask))
+    return ofail(SPK_ERR_ARG, "op_bn_backward: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  Scratch sc;
+  int rpb;
+  const int nb = spk_bn_bwd_blocks(M, C, &rpb);
+  float* part = sc.get<float>((size_t)nb * 2 * C);
+  float* coef = sc.get<float>((size_t)3 * C);
+  float* tmp = sc.get<float>((size_t)C * 2 * 64);
+  if (!part || !coef || !tmp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_bn_bwd((const bf16_t*)g, mask, (const bf16_t*)raw, mean, invstd, gamma, part, coef, dgamma, dbeta,
+                          (bf16_t*)dy, (bf16_t*)g_res, res_accumulate, M, C, relu, tmp, s), "bn_bwd");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_bn_backward: kernel failed");
+  return SPK_OK;
+}
+
+extern "C" int spk_op_conv_dgrad(const void* dy, const float* w_ohwi, void* dx, int accumulate, int n, int h, int w,
+                                 int cin, int cout, int k, int stride, int pad, void* stream) {
+  if (!dy || !w_ohwi || !dx || n < 1) return ofail(SPK_ERR_ARG, "op_conv_dgrad: bad arguments");
+  if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  Scratch sc;
+  bf16_t* wdg = sc.get<bf16_t>((size_t)cin * k * k * cout);
+  if (!wdg) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pack_dgrad(w_ohwi, wdg, cout, k * k, cin, s), "pack_dgrad");
+  const int r = spk_conv_dgrad_all((const bf16_t*)dy, wdg, (bf16_t*)dx, accumulate != 0, n, oh, ow, cout, h, w, cin, k,
+                                   stride, pad, s);
+  if (r != SPK_OK) return r;
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_conv_dgrad: kernel failed");
+  return SPK_OK;
+}
+
+extern "C" int spk_op_conv_wgrad(const void* x, const void* dy, float* dw_ohwi, int n, int h, int w, int cin, int cout,
+                                 int k, int stride, int pad, void* stream) {
+  if (!x || !dy || !dw_ohwi || n < 1) return ofail(SPK_ERR_ARG, "op_conv_wgrad: bad arguments");
+  const bool stem = stem_shape(cin, cout, k, stride, pad);
+  if ((!stem && cin % 64) || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64 (or the 7x7/2 stem)");
+  hipStream_t s = (hipStream_t)stream;
+  const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+  const int M = n * oh * ow;
+  Scratch sc;
+  float* slabs = sc.get<float>(spk_conv_wgrad_slab_floats(M, cin, cout, k, stem));
+  if (!slabs) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  int r = spk_conv_wgrad_slabs((const bf16_t*)x, (const bf16_t*)dy, slabs, n, h, stem ? (w + 1) & ~1 : w, cin, oh, ow,
+                               cout, k, stride, pad, stem, s);
+  if (r != SPK_OK) return r;
+  r = spk_conv_wgrad_reduce(slabs, dw_ohwi, M, cin, cout, k, stem, s);
+  if (r != SPK_OK) return r;
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_conv_wgrad: kernel failed");
+  return SPK_OK;
+}

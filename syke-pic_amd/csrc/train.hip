@@ -228,6 +228,78 @@ static void fill_conv(ConvArgs& a, const bf16_t* x, const bf16_t* w, bf16_t* y, 
   a.w_bytes = (unsigned)((size_t)Cout * K * 2);
 }
 
+
+// ---------------------------------------------------------------------------
+// Backward of one convolution, shared by the training step below and by the single-operator test hooks
+// (ops_abi.hip), so that the isolation tests exercise exactly the launches a training step makes.
+// ---------------------------------------------------------------------------
+// dx (+)= conv_transpose(dy, w): dy [n,oh,ow,cout], wdg = the [Cin][kh][kw][Cout] bf16 image, dx [n,ih,iw,cin]
+int spk_conv_dgrad_all(const bf16_t* dy, const bf16_t* wdg, bf16_t* dx, bool accumulate, int n, int oh, int ow,
+                       int cout, int ih, int iw, int cin, int k, int stride, int pad, hipStream_t s) {
+  ConvArgs a;
+  fill_conv(a, dy, wdg, dx, n, oh, ow, cout, ih, iw, cin, k, stride, pad, k * k * cout);
+  a.res = accumulate ? (const bf16_t*)dx : nullptr;
+  if (stride == 1) {
+    K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
+    return SPK_OK;
+  }
+  if (stride != 2) return tfail(SPK_ERR_UNSUPPORTED, "conv stride must be 1 or 2 on the training path");
+  // one launch per output parity class; a class that no tap can reach (1x1 stride 2: three of four) is all zeros
+  bool need_zero = false;
+  for (int cl = 0; cl < 4; ++cl) {
+    const int ph = cl >> 1, pw = cl & 1;
+    const int r0 = (ph + pad) & 1, s0 = (pw + pad) & 1;
+    const int nr = r0 < k ? (k - r0 + 1) / 2 : 0, ns = s0 < k ? (k - s0 + 1) / 2 : 0;
+    if (nr * ns == 0 && (ih - ph + 1) / 2 > 0 && (iw - pw + 1) / 2 > 0) need_zero = true;
+  }
+  if (need_zero && !accumulate) HIP_TRY(hipMemsetAsync(dx, 0, (size_t)n * ih * iw * cin * 2, s));
+  for (int cl = 0; cl < 4; ++cl) {
+    const int ph = cl >> 1, pw = cl & 1;
+    const int r0 = (ph + pad) & 1, s0 = (pw + pad) & 1;
+    const int nr = r0 < k ? (k - r0 + 1) / 2 : 0, ns = s0 < k ? (k - s0 + 1) / 2 : 0;
+    const int h2 = (ih - ph + 1) / 2, w2 = (iw - pw + 1) / 2;
+    if (nr * ns == 0 || h2 <= 0 || w2 <= 0) continue;
+    ConvArgs c = a;
+    c.cls_ph = ph; c.cls_pw = pw;
+    c.oH = ih; c.oW = iw;
+    c.Ho = h2; c.Wo = w2;
+    c.M = n * h2 * w2;
+    c.kt_count = nr * ns * (cout / 64);
+    K_TRY(spk_conv_launch(c, CONV_MODE_DGRAD, s, nullptr), "conv dgrad (parity class)");
+  }
+  return SPK_OK;
+}
+
+size_t spk_conv_wgrad_slab_floats(int M, int cin, int cout, int k, bool stem) {
+  const int ktot = stem ? 256 : k * k * cin;
+  int sp, pps;
+  spk_wgrad_plan(M, cout, ktot, &sp, &pps);
+  return (size_t)sp * cout * ktot;
+}
+
+// split-K partial weight gradients into `slabs` ...
+int spk_conv_wgrad_slabs(const bf16_t* x, const bf16_t* dy, float* slabs, int n, int ih, int iw, int cin, int oh,
+                         int ow, int cout, int k, int stride, int pad, bool stem, hipStream_t s) {
+  const int ktot = stem ? 256 : k * k * cin;
+  int sp, pps;
+  spk_wgrad_plan(n * oh * ow, cout, ktot, &sp, &pps);
+  K_TRY(spk_wgrad_launch(x, dy, slabs, n, ih, iw, cin, oh, ow, cout, k, stride, pad, stem ? 1 : 0, sp, pps, s),
+        "conv wgrad");
+  return SPK_OK;
+}
+
+// ... and their fixed-order sum into gw ([Cout][kh][kw][Cin] fp32)
+int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cout, int k, bool stem, hipStream_t s) {
+  const int ktot = stem ? 256 : k * k * cin;
+  int sp, pps;
+  spk_wgrad_plan(M, cout, ktot, &sp, &pps);
+  if (stem)
+    K_TRY(spk_launch_stem_wgrad_unpack(slabs, gw, cout, k, k, cin, sp, s), "stem wgrad unpack");
+  else
+    K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)cout * ktot, sp, s), "wgrad reduce");
+  return SPK_OK;
+}
+
 extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, int h, int w, int layout,
                                           int dtype, const int64_t* y, float* stats, float* logits_out) {
   if (!m || !x || !y || !stats || n < 2)
@@ -368,58 +440,19 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         mark(m, PH_BN_BWD);
         if (L.d.res >= 0) has_grad[L.d.res] = 1;
         if (L.d.src != 0) {
-          // data gradient: implicit GEMM over the dgrad weight image
-          ConvArgs a;
-          fill_conv(a, dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), n, o.h, o.w, C, in.h, in.w,
-                    L.d.cin, L.d.k, L.d.stride, L.d.pad, L.d.k * L.d.k * C);
-          const bool accumulate = has_grad[L.d.src] != 0;
-          a.res = accumulate ? (const bf16_t*)t->G(L.d.src) : nullptr;
-          if (L.d.stride == 1) {
-            K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
-          } else if (L.d.stride == 2) {
-            // one launch per output parity class; a class that no tap can reach
-            // (1x1 stride 2: three of four) is all zeros
-            bool need_zero = false;
-            for (int cl = 0; cl < 4; ++cl) {
-              const int ph = cl >> 1, pw = cl & 1;
-              const int nr = (L.d.k - ((ph + L.d.pad) & 1) + 1) / 2, ns = (L.d.k - ((pw + L.d.pad) & 1) + 1) / 2;
-              if (nr * ns == 0 && (in.h - ph + 1) / 2 > 0 && (in.w - pw + 1) / 2 > 0) need_zero = true;
-            }
-            if (need_zero && !accumulate)
-              HIP_TRY(hipMemsetAsync(t->G(L.d.src), 0, (size_t)n * in.h * in.w * L.d.cin * 2, s));
-            for (int cl = 0; cl < 4; ++cl) {
-              const int ph = cl >> 1, pw = cl & 1;
-              const int r0 = (ph + L.d.pad) & 1, s0 = (pw + L.d.pad) & 1;
-              const int nr = r0 < L.d.k ? (L.d.k - r0 + 1) / 2 : 0, ns = s0 < L.d.k ? (L.d.k - s0 + 1) / 2 : 0;
-              const int h2 = (in.h - ph + 1) / 2, w2 = (in.w - pw + 1) / 2;
-              if (nr * ns == 0 || h2 <= 0 || w2 <= 0) continue;
-              ConvArgs c = a;
-              c.cls_ph = ph; c.cls_pw = pw;
-              c.oH = in.h; c.oW = in.w;
-              c.Ho = h2; c.Wo = w2;
-              c.M = n * h2 * w2;
-              c.kt_count = nr * ns * (C / 64);
-              K_TRY(spk_conv_launch(c, CONV_MODE_DGRAD, s, nullptr), "conv dgrad (parity class)");
-            }
-          } else {
-            return tfail(SPK_ERR_UNSUPPORTED, "conv stride must be 1 or 2 on the training path");
-          }
+          // data gradient: implicit GEMM over the dgrad weight image (stride 2: one launch per parity class)
+          SPK_TRY(spk_conv_dgrad_all(dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n,
+                                     o.h, o.w, C, in.h, in.w, L.d.cin, L.d.k, L.d.stride, L.d.pad, s));
           mark(m, PH_CONV_DGRAD);
           has_grad[L.d.src] = 1;
         }
         if (m->params[L.p_w].requires_grad) {
           const bool stem = L.mode == CONV_MODE_STEM;
-          const int ktot = stem ? 256 : L.d.k * L.d.k * L.d.cin;
-          int sp, pps;
-          spk_wgrad_plan(M, C, ktot, &sp, &pps);
-          K_TRY(spk_wgrad_launch((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, L.d.cin, o.h, o.w, C,
-                                 L.d.k, L.d.stride, L.d.pad, stem ? 1 : 0, sp, pps, s), "conv wgrad");
-          mark(m, PH_CONV_WGRAD);
           float* gw = t->gbuf + m->params[L.p_w].off;
-          if (stem)
-            K_TRY(spk_launch_stem_wgrad_unpack(slabs, gw, C, L.d.k, L.d.k, L.d.cin, sp, s), "stem wgrad unpack");
-          else
-            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)C * ktot, sp, s), "wgrad reduce");
+          SPK_TRY(spk_conv_wgrad_slabs((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, L.d.cin, o.h, o.w, C, L.d.k,
+                                       L.d.stride, L.d.pad, stem, s));
+          mark(m, PH_CONV_WGRAD);
+          SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, L.d.cin, C, L.d.k, stem, s));
           mark(m, PH_WGRAD_REDUCE);
         }
         break;

@@ -79,6 +79,10 @@ SYMBOLS = {
     "spk_model_read_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "spk_model_read_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
+    "spk_op_conv_bn_train_forward": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P] + [C.c_int] * 9 + [_P]),
+    "spk_op_bn_backward": (C.c_int, [_P] * 10 + [C.c_int] * 4 + [_P]),
+    "spk_op_conv_dgrad": (C.c_int, [_P, _P, _P] + [C.c_int] * 9 + [_P]),
+    "spk_op_conv_wgrad": (C.c_int, [_P, _P, _P] + [C.c_int] * 8 + [_P]),
     "spk_preprocess_rois": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "spk_predict_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P]),
     "spk_augment_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),

@@ -1,0 +1,121 @@
+"""Single-operator test hooks of the C-ABI (``spk_op_*`` in include/sykepic_hip.h) on torch device tensors.
+
+Each call runs exactly the launches ``spk_train_forward_backward`` makes for ONE Conv2d + BatchNorm2d layer
+(the reference reaches them through ``net(x)`` / ``loss.backward()``, sykepic/train/train.py:240,242), so a
+parity test can feed a kernel known operands.  Tensor conventions: activations and gradients are torch
+``bfloat16`` tensors in NCHW *logical* shape; they are handed to the library as NHWC (``channels_last``
+storage), weights as float32 OIHW (handed over as [Cout][kh][kw][Cin]).  No CPU fallback.
+"""
+
+import ctypes as C
+
+import torch
+
+from . import lib
+
+
+def _nhwc(t):
+    """NCHW logical tensor -> contiguous [N,H,W,C] bf16 device tensor."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(t_nhwc):
+    return t_nhwc.permute(0, 3, 1, 2)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _is_stem(cin, cout, k, stride, pad):
+    return cin <= 4 and k == 7 and stride == 2 and pad == 3 and cout == 64
+
+
+def _stem_input(x):
+    """[N,C<=4,H,W] -> NHWC with 4 stored channels and an even width (the layout spk_launch_to_nhwc4 produces)."""
+    n, c, h, w = x.shape
+    wp = (w + 1) & ~1
+    out = torch.zeros((n, h, wp, 4), dtype=torch.bfloat16, device=x.device)
+    out[:, :, :w, :c] = x.permute(0, 2, 3, 1)
+    return out
+
+
+def conv_bn_train_forward(x, weight, gamma, beta, running_mean, running_var, res=None, relu=True, stride=1, pad=0):
+    """Returns dict(out, raw, mask, mean, invstd); running_mean / running_var (float32 device tensors) are updated
+    in place."""
+    so = lib.load()
+    dev = x.device
+    n, cin, h, w = x.shape
+    cout, _, k, _ = weight.shape
+    stem = _is_stem(cin, cout, k, stride, pad)
+    xh = _stem_input(x) if stem else _nhwc(x.to(torch.bfloat16))
+    wk = weight.float().permute(0, 2, 3, 1).contiguous()
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    out = torch.empty((n, oh, ow, cout), dtype=torch.bfloat16, device=dev)
+    raw = torch.empty_like(out)
+    mask = torch.zeros((n * oh * ow, cout // 8), dtype=torch.uint8, device=dev)
+    stats = torch.empty((2, cout), dtype=torch.float32, device=dev)
+    resh = _nhwc(res.to(torch.bfloat16)) if res is not None else None
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv_bn_train_forward(
+            _p(xh), _p(wk), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(resh), _p(out), _p(raw),
+            _p(mask), _p(stats), n, h, w, cin, cout, k, stride, pad, int(bool(relu)), _stream(dev)))
+    return {"out": _nchw(out), "raw": _nchw(raw), "mask": mask, "mean": stats[0], "invstd": stats[1]}
+
+
+def bn_backward(g, mask, raw, mean, invstd, gamma, relu=True, g_res=None, res_accumulate=False, want_res=False):
+    """g, raw: [N,C,H,W] bf16.  Returns dict(dy, dgamma, dbeta, g_res)."""
+    so = lib.load()
+    dev = g.device
+    n, c, h, w = g.shape
+    gh, rh = _nhwc(g), _nhwc(raw)
+    dy = torch.empty_like(gh)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    gres = None
+    if want_res or g_res is not None:
+        gres = _nhwc(g_res.to(torch.bfloat16)) if g_res is not None else torch.empty_like(gh)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_bn_backward(_p(gh), _p(mask), _p(rh), _p(mean), _p(invstd), _p(gamma), _p(dgamma),
+                                        _p(dbeta), _p(dy), _p(gres), int(bool(res_accumulate)), n * h * w, c,
+                                        int(bool(relu)), _stream(dev)))
+    return {"dy": _nchw(dy), "dgamma": dgamma, "dbeta": dbeta, "g_res": _nchw(gres) if gres is not None else None}
+
+
+def conv_dgrad(dy, weight, in_hw, stride=1, pad=0, accumulate_into=None):
+    """dx [N,Cin,H,W] bf16 = conv_transpose(dy, weight) (+ accumulate_into)."""
+    so = lib.load()
+    dev = dy.device
+    n, cout = dy.shape[:2]
+    _, cin, k, _ = weight.shape
+    h, w = in_hw
+    dyh = _nhwc(dy.to(torch.bfloat16))
+    wk = weight.float().permute(0, 2, 3, 1).contiguous()
+    if accumulate_into is not None:
+        dx = _nhwc(accumulate_into.to(torch.bfloat16))
+    else:
+        # poison: every element must be written (or zeroed) by the launches
+        dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv_dgrad(_p(dyh), _p(wk), _p(dx), int(accumulate_into is not None), n, h, w, cin, cout,
+                                       k, stride, pad, _stream(dev)))
+    return _nchw(dx)
+
+
+def conv_wgrad(x, dy, k, stride=1, pad=0):
+    """dw [Cout,Cin,k,k] float32 from x [N,Cin,H,W] and dy [N,Cout,Ho,Wo] (bf16)."""
+    so = lib.load()
+    dev = x.device
+    n, cin, h, w = x.shape
+    cout = dy.shape[1]
+    stem = _is_stem(cin, cout, k, stride, pad)
+    xh = _stem_input(x.to(torch.bfloat16)) if stem else _nhwc(x.to(torch.bfloat16))
+    dyh = _nhwc(dy.to(torch.bfloat16))
+    dw = torch.full((cout, k, k, cin), float("nan"), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv_wgrad(_p(xh), _p(dyh), _p(dw), n, h, w, cin, cout, k, stride, pad, _stream(dev)))
+    return dw.permute(0, 3, 1, 2)

@@ -30,71 +30,123 @@ def _rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-@pytest.mark.parametrize("network,hw,n", [("resnet18", 64, 8), ("resnet50", 64, 6), ("resnet18", 75, 5)])
-def test_backward_kernels_at_the_gpu_operating_point(network, hw, n):
-    """Autograd evaluated AT the activations the GPU produced (teacher-forced
-    oracle graph: same ReLU masks, same batch statistics) isolates the
-    backward kernels: what remains is the bf16 rounding of the gradient
-    tensors (2^-9 each, a few per layer).  Tolerance: relative L2 <= 0.15 per
-    parameter tensor in the backbone, 1e-4 in the fp32 head."""
+def _torch_state(ref):
+    return {k: v.clone() for k, v in ref.state_dict().items()}
+
+
+def _fp32_autograd(g, specs, state, x, y):
+    """{key: gradient} of the reference's pure-fp32 train-mode forward + mean CE (torch autograd)."""
     import torch.nn.functional as F
+    from oracle import graph_eval
+    kinds = {k: kind for k, _, kind in specs}
+    tsd = {k: v.clone().requires_grad_(v.dtype == torch.float32 and kinds[k] not in ("bn_mean", "bn_var"))
+           for k, v in state.items()}
+    acts = graph_eval.run(g, tsd, x, train=True)
+    out = acts[g.ops[-1].dst]
+    loss = F.cross_entropy(out, y)
+    loss.backward()
+    return out.detach(), float(loss.detach()), {k: t.grad for k, t in tsd.items() if t.grad is not None}
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float(a @ b / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("network,hw,n", [("resnet18", 64, 8), ("resnet50", 64, 6), ("resnet18", 75, 5),
+                                          ("resnet50", 96, 16), ("resnet34", 64, 4)])
+def test_backward_matches_the_bf16_emulating_oracle(network, hw, n):
+    """Whole-network check of every backward kernel: oracle.graph_eval.train_step_bf16 restates the training step
+    with a bf16 rounding exactly where the HIP path stores a tensor (activations AND gradients) and is evaluated
+    layer by layer at the activations the GPU produced (each layer starts from the GPU's own input, its own
+    output decides its ReLU mask and BatchNorm statistics).  What is left is accumulation order and the rare
+    1-ulp flip: measured <= 4e-3, asserted <= 1e-2 relative L2 per parameter-gradient tensor (1e-4 in the fp32
+    head), and the same bound for the gradient w.r.t. every activation.  The forward is checked on the way:
+    every layer's own output, from the GPU's input, equals the GPU's output to <= 4e-3 (bf16: 1-ulp flips).
+
+    Round 1 compared with autograd through a forward that did NOT round the raw conv output before BatchNorm
+    (rel-L2 0.12): its ReLU masks differed from the GPU's on ~0.4 % of the elements of every layer."""
     from oracle import graph_eval
     classes = 10
     g, specs, ref, net = _pair(network, classes, seed=5)
     x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10))
     y = torch.from_numpy(synth.synth_labels(n, classes, seed=11))
     net.train()
+    net.reset_stats()
     net.forward_backward(x.cuda(), y.cuda())
-    sd = {k: v.clone() for k, v in ref.state_dict().items()}
-    probe = graph_eval.run(g, sd, x, train=True)
-    forced = {op.dst: net.read_activation(op.dst, n, tuple(probe[op.dst].shape)) for op in g.ops}
-    tsd = {k: v.clone().requires_grad_(v.dtype == torch.float32) for k, v in ref.state_dict().items()}
-    acts = graph_eval.run_train_forced(g, tsd, x, forced)
-    F.cross_entropy(acts[g.ops[-1].dst], y).backward()
+    state = _torch_state(ref)
+    shapes = {t: tuple(v.shape) for t, v in graph_eval.run(g, state, x, train=True).items()}
+    forced = {op.dst: net.read_activation(op.dst, n, shapes[op.dst]) for op in g.ops}
+    emu = graph_eval.train_step_bf16(g, state, x, y, forced=forced)
+    # forward at the GPU's operating point
+    for op in g.ops:
+        r = _rel(forced[op.dst], emu["own"][op.dst])
+        assert r < 4e-3, f"forward of {op.name or op.kind} from the GPU's own input: relative L2 {r:.3e}"
+    assert abs(net.read_stats()[0] / n - float(emu["loss"])) < 1e-4 * max(1.0, float(emu["loss"]))
     worst = ("", 0.0)
     for k, _, kind in specs:
-        if tsd[k].grad is None:
+        if k not in emu["grads"]:
             continue
-        r = _rel(net._read_grad(k, tuple(tsd[k].shape)), tsd[k].grad)
+        r = _rel(net._read_grad(k, tuple(emu["grads"][k].shape)), emu["grads"][k])
         if r > worst[1]:
             worst = (k, r)
-        assert r < (1e-4 if k.startswith("head.") else 0.15), f"{k}: relative L2 gradient error {r:.3e}"
-    print(f"{network}@{hw}x{n}: worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}")
+        assert r < (1e-4 if k.startswith("head.") else 1e-2), f"{k}: relative L2 gradient error {r:.3e}"
+    worst_a = ("", 0.0)
+    for op in g.ops:
+        t = op.src
+        if t == 0 or t not in emu["act_grads"]:
+            continue
+        r = _rel(net.read_activation_grad(t, n, shapes[t]), emu["act_grads"][t])
+        if r > worst_a[1]:
+            worst_a = (f"input of {op.name}", r)
+        assert r < 1e-2, f"gradient w.r.t. the input of {op.name}: relative L2 {r:.3e}"
+    print(f"{network}@{hw}x{n}: worst parameter gradient rel-L2 {worst[1]:.3e} at {worst[0]}; "
+          f"worst activation gradient {worst_a[1]:.3e} at {worst_a[0]}")
 
 
 @pytest.mark.parametrize("network,hw,n", [("resnet18", 64, 8), ("resnet50", 96, 16)])
 def test_gradients_vs_fp32_autograd(network, hw, n):
-    """Against the reference's pure-fp32 forward/backward.  A bf16 forward
-    differs from the fp32 one by ~1e-2 deep in the net, which flips the ReLU
-    mask of the ~1 % of activations that sit next to zero; every flipped
-    element moves the gradient by its full magnitude, so per-tensor relative
-    L2 lands at 0.1-0.3 for ANY bf16 training path.  Checked here: direction
-    (cosine >= 0.75; measured 0.95 on ResNet-18, 0.79-0.85 on ResNet-50) and size (norm within 20 %) of every gradient, the loss
-    to 2e-2, the logits to 8e-2 relative L2 and the accuracy counter exactly."""
+    """Against the reference's pure-fp32 forward/backward (sykepic/train/train.py:240-242 on the CPU).
+
+    A bf16 FORWARD differs from the fp32 one by ~1e-2 deep in the net, which flips the ReLU mask of the ~1 % of
+    activations that sit next to zero; on these random-weight networks with train-mode BatchNorm over a handful
+    of samples that moves whole gradient tensors.  The decomposition is measured here, not assumed: the same
+    comparison is made for the CPU oracle `train_step_bf16(round_grads=False)` — a bf16-storage forward with EXACT
+    float32 backpropagation and no GPU kernel involved.  It lands at min cosine 0.95 (ResNet-18) / 0.81 (ResNet-50
+    @96 x16; 0.76-0.81 also at 128^2 x32 and 224^2 x32, and two float32 evaluation orders of that same oracle agree
+    with each other only to cosine 0.90) — the cost of bf16 activations on this problem for ANY implementation.
+    Asserted: the GPU is no further from fp32 autograd than that oracle (min and median cosine within 0.05 /
+    0.03), every gradient norm within 20 %, loss to 2e-2, logits to 8e-2 relative L2, accuracy counter exact.
+    The kernels themselves are pinned to <= 1e-2 by test_backward_matches_the_bf16_emulating_oracle and to
+    <= 5e-3 per layer by tests/test_gpu_train_ops.py."""
+    from oracle import graph_eval
     classes = 10
     g, specs, ref, net = _pair(network, classes, seed=5)
     x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10))
     y = torch.from_numpy(synth.synth_labels(n, classes, seed=11))
+    state = _torch_state(ref)
+    out, loss, want = _fp32_autograd(g, specs, state, x, y)
+    emu = graph_eval.train_step_bf16(g, state, x, y, round_grads=False)
     ref.train()
-    out = ref(x)
-    loss = torch.nn.functional.cross_entropy(out, y)
-    loss.backward()
+    ref(x)  # running statistics of the reference module
     net.train()
     net.reset_stats()
     logits = net.forward_backward(x.cuda(), y.cuda(), want_logits=True).cpu()
     loss_n, correct = net.read_stats()
-    assert abs(loss_n / n - float(loss.detach())) < 2e-2 * max(1.0, abs(float(loss.detach())))
+    assert abs(loss_n / n - loss) < 2e-2 * max(1.0, abs(loss))
     assert correct == float((out.argmax(1) == y).sum())
-    assert _rel(logits, out.detach()) < 8e-2
-    worst = 1.0
-    for name, p in ref.named_parameters():
-        got = net._read_grad(name, tuple(p.shape)).double().flatten()
-        want = p.grad.double().flatten()
-        cos = float(got @ want / (got.norm() * want.norm() + 1e-30))
-        ratio = float(got.norm() / (want.norm() + 1e-30))
-        worst = min(worst, cos)
-        assert cos > 0.75 and 0.8 < ratio < 1.2, f"{name}: cos {cos:.4f} ratio {ratio:.3f}"
-    print(f"{network}: min gradient cosine vs fp32 autograd {worst:.4f}")
+    assert _rel(logits, out) < 8e-2
+    cos_gpu, cos_emu = {}, {}
+    for name, wg in want.items():
+        got = net._read_grad(name, tuple(wg.shape))
+        cos_gpu[name], cos_emu[name] = _cos(got, wg), _cos(emu["grads"][name], wg)
+        ratio = float(got.double().norm() / (wg.double().norm() + 1e-30))
+        assert 0.8 < ratio < 1.2, f"{name}: gradient norm ratio {ratio:.3f}"
+    gmin, emin = min(cos_gpu.values()), min(cos_emu.values())
+    gmed, emed = float(np.median(list(cos_gpu.values()))), float(np.median(list(cos_emu.values())))
+    print(f"{network}: cosine vs fp32 autograd  GPU min {gmin:.4f} median {gmed:.4f} | "
+          f"CPU bf16-forward oracle min {emin:.4f} median {emed:.4f}")
+    assert gmin > emin - 0.05 and gmed > emed - 0.03
     # BatchNorm running statistics (momentum 0.1, unbiased variance) and counter
     sd_ref, sd_hip = ref.state_dict(), net.state_dict()
     for k, _, kind in specs:
@@ -102,6 +154,51 @@ def test_gradients_vs_fp32_autograd(network, hw, n):
             assert torch.allclose(sd_hip[k], sd_ref[k], rtol=2e-2, atol=2e-3), k
         if kind == "bn_nbt":
             assert int(sd_hip[k]) == int(sd_ref[k]) == 1
+
+
+def test_resnet50_train_step_at_the_benched_size():
+    """BASELINE config 3 at its real size — ResNet-50, batch 256, 224 x 224, 50 classes, head 256,128 (what
+    bench.py times) — against the oracle: (a) loss / logits of the whole batch vs the fp32 CPU forward with
+    train-mode BatchNorm (bf16 storage: loss 2e-2, logits 8e-2 relative L2), (b) every gradient of layer4 + head
+    and the gradient entering layer4 vs the bf16-emulating oracle run over that tail of the network from the
+    GPU's own activations (<= 1e-2; these are the batch-256 shapes of dgrad / wgrad / bn_bwd: M = 12544 and
+    50176 rows, split-K plans of the real step), (c) every gradient tensor of the net finite and non-zero."""
+    from oracle import graph_eval
+    classes, n, hw = 50, 256, 224
+    g, specs, ref, net = _pair("resnet50", classes, seed=5)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10))
+    y = torch.from_numpy(synth.synth_labels(n, classes, seed=11))
+    net.train()
+    net.reset_stats()
+    logits = net.forward_backward(x.cuda(), y.cuda(), want_logits=True).cpu()
+    loss_n, correct = net.read_stats()
+    state = _torch_state(ref)
+    with torch.no_grad():
+        acts = graph_eval.run(g, state, x, train=True)
+    out = acts[g.ops[-1].dst]
+    loss = float(torch.nn.functional.cross_entropy(out, y))
+    assert abs(loss_n / n - loss) < 2e-2 * max(1.0, loss)
+    assert _rel(logits, out) < 8e-2
+    assert abs(correct - float((out.argmax(1) == y).sum())) <= 3    # near-ties may flip under bf16
+    first = next(i for i, op in enumerate(g.ops) if op.child == 7)
+    need = {t for op in g.ops[first:] for t in (op.src, op.res, op.dst) if t > 0}
+    forced = {t: net.read_activation(t, n, tuple(acts[t].shape)) for t in need}
+    del acts
+    emu = graph_eval.train_step_bf16(g, state, None, y, forced=forced, first_op=first)
+    worst = ("", 0.0)
+    for k, v in emu["grads"].items():
+        r = _rel(net._read_grad(k, tuple(v.shape)), v)
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < (1e-4 if k.startswith("head.") else 1e-2), f"{k}: relative L2 gradient error {r:.3e}"
+    t_in = g.ops[first].src
+    r_in = _rel(net.read_activation_grad(t_in, n, tuple(forced[t_in].shape)), emu["act_grads"][t_in])
+    assert r_in < 1e-2, f"gradient entering layer4: relative L2 {r_in:.3e}"
+    for name, p in net.named_parameters():
+        gr = net._read_grad(name, p.shape)
+        assert torch.isfinite(gr).all() and float(gr.abs().max()) > 0, name
+    print(f"resnet50 b256 224^2: loss {loss_n / n:.4f} vs fp32 {loss:.4f}; logits rel-L2 {_rel(logits, out):.3e}; "
+          f"layer4+head worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}; gradient entering layer4 {r_in:.3e}")
 
 
 @pytest.mark.parametrize("optim_name", ["SGD", "Adam"])
