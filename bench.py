@@ -17,8 +17,11 @@ reference path) on this box's host cores on a bounded sample.
 """
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -53,6 +56,25 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
     return ap.parse_args()
+
+
+def kernel_source_sha():
+    """sha256 over the HIP sources: a committed PMC traffic figure is only quoted for the kernels it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "syke-pic_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for ln in Path("/proc/cpuinfo").read_text().splitlines():
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def host_cores():
@@ -111,6 +133,7 @@ def cpu_baseline(network, classes, size, mode, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": round(bs * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(),
             "sample": f"{iters} x batch {bs} of {network} {mode} fp32 NCHW on host CPU "
                       f"({iters * bs} images, {dt:.1f} s)"}
 
@@ -150,11 +173,19 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     for _ in range(args.warmup):
         step()
     fence()
+    # per-step times from events on the launch stream (the library enqueues on torch's current stream); the
+    # headline stays the wall time of the K steps between the two fences
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)  # noqa: E731
+    step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3)}
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -207,11 +238,17 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
                     "all_kernels_ms_per_step": round(all_ms, 3),
                     "conv1x1_tflops": round(sum(fl for n, _, fl, _ in conv if ".block." in n or n.endswith("8.0")) / 1e12 /
                                             max(sum(ms for n, ms, _, _ in conv) * 1e-3, 1e-9), 1)}
-        pmc = ROOT / "profiles" / f"r01_pmc_traffic_infer_{args.precision}.json"
-        if pmc.is_file() and args.batch == 256 and args.network == "resnet50":
-            # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-            roof["traffic"] = round(json.loads(pmc.read_text())["traffic_bytes_per_launch"])
-            roof["traffic_source"] = str(pmc.relative_to(ROOT))
+        # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the
+        # committed rocprofv3 --pmc passes of this same command (tools/pmc_traffic.py) and is quoted ONLY if it
+        # was taken on the kernel sources of this build (sha over csrc/), else null
+        cands = sorted((ROOT / "profiles").glob(f"r*_pmc_traffic_infer_{args.precision}.json"))
+        if cands and args.batch == 256 and args.network == "resnet50" and args.size == 224:
+            rec = json.loads(cands[-1].read_text())
+            if rec.get("kernel_src_sha") == kernel_source_sha():
+                roof["traffic"] = round(rec["traffic_bytes_per_launch"])
+                roof["traffic_source"] = str(cands[-1].relative_to(ROOT))
+            else:
+                roof["traffic_source"] = f"{cands[-1].name} is stale (taken on other kernel sources): not quoted"
         table = [{"layer": n, "ms": round(ms, 4), "gflop": round(fl / 1e9, 3), "mbytes": round(by / 1e6, 2),
                   "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
                   "gbs": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
@@ -222,9 +259,10 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
 
     total_images = args.batch * world * args.steps
     out = {
-        "metric": f"IFCB images/sec, {args.network} 224x224 {mode} step",
+        "metric": f"IFCB images/sec, {args.network} {args.size}x{args.size} {mode} step",
         "value": round(total_images / dt, 1), "unit": "images/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "step_ms": step_ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": f"{args.network}_{mode}_b{args.batch}x{world}_"
@@ -242,9 +280,23 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks (one process per GPU) before anything touches the GPU and relay
+        # rank 0's JSON line — a bare `python bench.py --gpus 8` must not print a 1-GPU number
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): refusing to report a number "
+              f"for the wrong GPU count", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -272,7 +324,12 @@ def main():
         net.set_precision(split_weights=False, bf16=True)
     else:
         net.set_precision(split_weights={"mixed": 3, "precise": 1, "balanced": 2, "fast": 0}[args.precision])
-    # same generator, different seed per rank: every rank has its own shard
+    # the job's batch is world x per-GPU batch images (weak scaling); rank r holds the contiguous shard
+    # dp.shard_range gives it — the same split `sykepic prob` makes of a sample's ROI list (prob.process_sample).
+    # Image i of the global batch is generated from seed i // per-GPU batch, so a rank builds only its own shard.
+    from sykepic_hip import dp
+    lo, hi = dp.shard_range(args.batch * world, rank, world)
+    assert (lo, hi) == (rank * args.batch, (rank + 1) * args.batch)
     x = torch.from_numpy(synth.synth_images(args.batch, 3, args.size, args.size, seed=rank)).to(dev)
     y = torch.from_numpy(synth.synth_labels(args.batch, args.classes, seed=1000 + rank)).to(dev)
 
@@ -291,7 +348,7 @@ def main():
                 results.append(run_mode(m, args, net, x, y, dist, dev, rank, world))
             except Exception as exc:  # noqa: BLE001
                 print(f"[bench] train leg failed: {exc!r}", file=sys.stderr, flush=True)
-                results.append({"metric": f"IFCB images/sec, {args.network} 224x224 train step", "value": None,
+                results.append({"metric": f"IFCB images/sec, {args.network} {args.size}x{args.size} train step", "value": None,
                                 "error": repr(exc)})
             continue
         results.append(run_mode(m, args, net, x, y, dist, dev, rank, world))

@@ -771,10 +771,15 @@ static int launch_with(const ConvArgs& a, int mode, int cfg, hipStream_t s, int*
 // depend on the choice (only the grouping of the BN partial sums does).
 // ---------------------------------------------------------------------------
 #include <map>
+#include <mutex>
 #include <tuple>
 namespace {
-typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int, int> TuneKey;
-std::map<TuneKey, std::pair<int, int>> g_tuned;
+// problem without the batch size N; winners are kept per N underneath it
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int, int> TuneKey;
+typedef std::map<int, std::pair<int, int>> ByBatch;   // N -> (tile config, main-loop flavour)
+std::map<TuneKey, ByBatch> g_tuned;
+std::mutex g_tune_mu;   // the maps are process-wide; handles may be driven from several host threads
+bool g_cache_loaded = false;
 
 bool autotune_on() {
   static int v = -1;
@@ -783,6 +788,62 @@ bool autotune_on() {
     v = e ? atoi(e) != 0 : 1;
   }
   return v != 0;
+}
+
+// SPK_TUNE_CACHE=<file>: winners persist across processes (one text line per problem, appended when a problem
+// is tuned).  Ranks of a data-parallel job and re-runs then pick the same configurations, the first call of a
+// process does not pay the tuning, and a rocprofv3 kernel trace of a warm run holds steady-state launches only.
+const char* cache_path() {
+  const char* e = getenv("SPK_TUNE_CACHE");
+  return e && *e ? e : nullptr;
+}
+
+void cache_load_locked() {
+  if (g_cache_loaded) return;
+  g_cache_loaded = true;
+  const char* path = cache_path();
+  if (!path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char line[512];
+  while (fgets(line, sizeof line, f)) {
+    int v[15];
+    if (sscanf(line, "conv %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6],
+               &v[7], &v[8], &v[9], &v[10], &v[11], &v[12], &v[13], &v[14]) == 15) {
+      const TuneKey key(v[0], v[1], v[2], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12]);
+      g_tuned[key][v[3]] = {v[13], v[14]};
+    }
+  }
+  fclose(f);
+}
+
+void cache_append(const TuneKey& k, int n, const std::pair<int, int>& win) {
+  const char* path = cache_path();
+  if (!path) return;
+  FILE* f = fopen(path, "a");
+  if (!f) return;
+  fprintf(f, "conv %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d\n", std::get<0>(k), std::get<1>(k), std::get<2>(k), n,
+          std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), std::get<8>(k), std::get<9>(k),
+          std::get<10>(k), std::get<11>(k), win.first, win.second);
+  fclose(f);
+}
+
+// The winner for batch size n: the exact entry, else the entry of the nearest tuned batch size within a factor of
+// two (a ragged tail batch of `sykepic prob` re-uses the full batch's choice instead of re-timing ~40 candidates
+// for each of the 53 convolutions; every candidate is correct for every M, the choice only affects speed).
+const std::pair<int, int>* find_tuned_locked(const TuneKey& key, int n) {
+  auto it = g_tuned.find(key);
+  if (it == g_tuned.end() || it->second.empty()) return nullptr;
+  const ByBatch& by = it->second;
+  auto ex = by.find(n);
+  if (ex != by.end()) return &ex->second;
+  const std::pair<int, int>* best = nullptr;
+  double best_ratio = 2.0 + 1e-9;
+  for (const auto& kv : by) {
+    const double r = kv.first > n ? (double)kv.first / n : (double)n / kv.first;
+    if (r <= best_ratio) { best_ratio = r; best = &kv.second; }
+  }
+  return best;
 }
 }  // namespace
 
@@ -807,10 +868,16 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
     return launch_with(a, mode, cfg, s, m_tiles_out);
   }
   const int pad_cls = a.pad * 16 + (a.cls_ph >= 0 ? 1 + a.cls_ph * 2 + a.cls_pw : 0);
-  const TuneKey key(mode, a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
+  const TuneKey key(mode, a.dt, a.splitw, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
                     a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y) + 2 * (a.cin_s > 0) + 4 * (a.cout_s > 0));
-  auto it = g_tuned.find(key);
-  if (it == g_tuned.end()) {
+  std::pair<int, int> chosen;
+  bool have = false;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    cache_load_locked();
+    if (const std::pair<int, int>* w = find_tuned_locked(key, a.N)) { chosen = *w; have = true; }
+  }
+  if (!have) {
     // in-place accumulation (dgrad into an existing gradient): re-running it would add twice, so the candidates
     // write to a scratch tensor and read the real one as their shortcut operand - same traffic, nothing clobbered
     bf16_t* scratch = nullptr;
@@ -878,12 +945,17 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       (void)hipFree(scratch);
       a.y = real_y;
     }
-    it = g_tuned.emplace(key, win).first;
+    {
+      std::lock_guard<std::mutex> lk(g_tune_mu);
+      g_tuned[key][a.N] = win;
+      cache_append(key, a.N, win);
+    }
+    chosen = win;
     if (getenv("SPK_TUNE_LOG"))
       fprintf(stderr, "[spk tune] mode %d dt %d sw %d N%d %dx%d C%d->%d k%d s%d: cfg %d dma %d (%.1f us)\n", mode,
               a.dt, a.splitw, a.N, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, win.first, win.second,
               best * 1000.f / 3.f);
   }
-  a.dma = it->second.second;
-  return launch_with(a, mode, it->second.first, s, m_tiles_out);
+  a.dma = chosen.second;
+  return launch_with(a, mode, chosen.first, s, m_tiles_out);
 }

@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <tuple>
 
 struct WgradArgs {
@@ -206,17 +207,43 @@ int launch_nb(const WgradArgs& a, int splits, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// one- vs two-stage: timed once per problem and process (both give bit-identical slabs)
-std::map<std::tuple<int, int, int, int, int, int, int, int>, int> g_wg_tuned;
+// one- vs two-stage: timed once per problem (both give bit-identical slabs); process-wide table behind a mutex,
+// persisted in SPK_TUNE_CACHE like the conv tile choices (conv_igemm.hip)
+typedef std::tuple<int, int, int, int, int, int, int, int> WgKey;
+std::map<WgKey, int> g_wg_tuned;
+std::mutex g_wg_mu;
+bool g_wg_loaded = false;
+
+void wg_cache_load_locked() {
+  if (g_wg_loaded) return;
+  g_wg_loaded = true;
+  const char* path = getenv("SPK_TUNE_CACHE");
+  if (!path || !*path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char line[512];
+  while (fgets(line, sizeof line, f)) {
+    int v[9];
+    if (sscanf(line, "wgrad %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8]) == 9)
+      g_wg_tuned[WgKey(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])] = v[8];
+  }
+  fclose(f);
+}
 
 template <int BCO, int BCI, bool STEM>
 int launch(const WgradArgs& a, int splits, hipStream_t s) {
   static const int forced = getenv("SPK_WGRAD_NBUF") ? atoi(getenv("SPK_WGRAD_NBUF")) : 0;
   int nbuf = forced;
   if (nbuf != 1 && nbuf != 2) {
-    const auto key = std::make_tuple(a.M, a.Cin, a.Cout, a.kh, a.stride, (int)STEM, splits, BCO * 1000 + BCI);
-    auto it = g_wg_tuned.find(key);
-    if (it == g_wg_tuned.end()) {
+    const WgKey key(a.M, a.Cin, a.Cout, a.kh, a.stride, (int)STEM, splits, BCO * 1000 + BCI);
+    bool have = false;
+    {
+      std::lock_guard<std::mutex> lk(g_wg_mu);
+      wg_cache_load_locked();
+      auto it = g_wg_tuned.find(key);
+      if (it != g_wg_tuned.end()) { nbuf = it->second; have = true; }
+    }
+    if (!have) {
       hipEvent_t e0, e1;
       int best = 2;
       if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
@@ -237,9 +264,20 @@ int launch(const WgradArgs& a, int splits, hipStream_t s) {
           fprintf(stderr, "[spk tune] wgrad M%d C%d->%d k%d s%d: %d stage(s) (%.1f us)\n", a.M, a.Cin, a.Cout, a.kh,
                   a.stride, best, tbest * 500.f);
       }
-      it = g_wg_tuned.emplace(key, best).first;
+      {
+        std::lock_guard<std::mutex> lk(g_wg_mu);
+        g_wg_tuned[key] = best;
+        const char* path = getenv("SPK_TUNE_CACHE");
+        if (path && *path) {
+          if (FILE* f = fopen(path, "a")) {
+            fprintf(f, "wgrad %d %d %d %d %d %d %d %d %d\n", a.M, a.Cin, a.Cout, a.kh, a.stride, (int)STEM, splits,
+                    BCO * 1000 + BCI, best);
+            fclose(f);
+          }
+        }
+      }
+      nbuf = best;
     }
-    nbuf = it->second;
   }
   return nbuf == 1 ? launch_nb<BCO, BCI, STEM, 1>(a, splits, s) : launch_nb<BCO, BCI, STEM, 2>(a, splits, s);
 }

@@ -302,8 +302,7 @@ int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cou
 
 extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, int h, int w, int layout,
                                           int dtype, const int64_t* y, float* stats, float* logits_out) {
-  if (!m || !x || !y || !stats || n < 2)
-    return tfail(SPK_ERR_ARG, "train step: bad arguments (batch must be >= 2 for train-mode BatchNorm)");
+  if (!m || !x || !y || !stats || n < 1) return tfail(SPK_ERR_ARG, "train step: bad arguments");
   if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return tfail(SPK_ERR_ARG, "train step: dtype must be f32 or u8");
   HIP_TRY(hipSetDevice(m->device));
   if (m->eval_only)
@@ -317,6 +316,15 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   SPK_TRY(repack_weights(m));
   TrainState* t = m->train;
   hipStream_t s = m->stream;
+  // train-mode BatchNorm2d needs more than one value per channel (torch raises the same ValueError, e.g. for a
+  // last batch of ONE image whose feature map has shrunk to 1x1); a batch of one larger image trains, as in torch
+  for (const Layer& L : m->layers) {
+    const TDim& o = m->tdims[L.d.dst];
+    if (L.d.kind == SPK_OP_CONV && (long)n * o.h * o.w < 2)
+      return tfail(SPK_ERR_ARG, std::string("Expected more than 1 value per channel when training, got input size [") +
+                                    std::to_string(n) + ", " + std::to_string(L.d.cout) + ", " + std::to_string(o.h) +
+                                    ", " + std::to_string(o.w) + "] at " + L.d.bn);
+  }
   m->act_dt = DT_BF16;
   float* part = (float*)((char*)t->arena + t->part_off);
   float* coef = (float*)((char*)t->arena + t->coef_off);

@@ -197,7 +197,12 @@ class ModelData:
             train_x, train_y = self.train_x, self.train_y
         n_cls = len(self.le.classes_)
         train_data = ImageDataset(train_x, train_y, train_transform, num_chans, n_cls)
-        val_data = ImageDataset(self.val_x, self.val_y, eval_transform, num_chans, n_cls)
+        val_x, val_y = self.val_x, self.val_y
+        if world > 1:   # each rank validates a contiguous shard; train_net sums the counters over the ranks
+            from .dp import shard_range
+            b, e = shard_range(len(val_x), rank, world)
+            val_x, val_y = val_x[b:e], val_y[b:e]
+        val_data = ImageDataset(val_x, val_y, eval_transform, num_chans, n_cls)
         sampler = ShardedShuffle(len(train_data), rank, world, self.random_seed) if world > 1 else None
         if device is not None:
             from . import gpu_augment
@@ -205,7 +210,7 @@ class ModelData:
                 G = gpu_augment.GpuLoader
                 self.train_loader = G(train_x, train_y, train_transform, batch_size, device, shuffle=sampler is None,
                                       sampler=sampler)
-                self.val_loader = G(self.val_x, self.val_y, eval_transform, batch_size, device)
+                self.val_loader = G(val_x, val_y, eval_transform, batch_size, device)
                 if self.test_x:
                     self.test_loader = G(self.test_x, self.test_y, eval_transform, batch_size, device)
                 return

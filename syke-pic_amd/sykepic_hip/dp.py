@@ -15,8 +15,38 @@ step the build adds (§8e):
 """
 
 import ctypes
+import os
 
 import torch
+
+
+def init_from_env():
+    """(dist, rank, world, local_rank) from the launcher's environment (`torch.distributed.run`: RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_*); (None, 0, 1, 0) for a plain single-process run.  Backend nccl = RCCL over xGMI."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None, 0, 1, 0
+    import torch.distributed as dist
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    # SPK_DIST_BACKEND=gloo: rehearsal of the N>1 path on fewer GPUs than ranks (RCCL refuses two ranks on one
+    # device); ranks then share the devices round-robin
+    backend = os.environ.get("SPK_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % max(1, torch.cuda.device_count())
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, rank, world, local
+
+
+def rank_world(dist=None):
+    if dist is None or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(), dist.get_world_size()
 
 
 class _DevicePtr:
@@ -71,10 +101,102 @@ class GradSync:
         return tuple(float(v) for v in t.tolist())
 
 
-def gather_rows(rows, dist=None):
-    """Inference: concatenate every rank's [(roi, probs)] on all ranks."""
+def _comm_device(dist, device):
+    """Tensors of a collective live on the GPU for nccl (= RCCL) and on the host for gloo."""
+    return torch.device(device) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def broadcast_state(net, dist=None, src=0):
+    """Every replica starts from rank `src`'s parameters AND buffers (what DistributedDataParallel does at
+    construction).  Without it each rank keeps its own random initialisation (pretrained weights cannot be
+    downloaded here, the head is always random) and the all-reduce averages gradients taken at different
+    weights.  One flat float32 broadcast + one int64 broadcast (num_batches_tracked)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    sd = net.state_dict()
+    fkeys = [k for k, v in sd.items() if v.dtype != torch.int64]
+    ikeys = [k for k, v in sd.items() if v.dtype == torch.int64]
+    dev = _comm_device(dist, getattr(net, "device", "cpu"))
+    flat = torch.cat([sd[k].detach().float().reshape(-1) for k in fkeys]).to(dev)
+    cnt = torch.stack([sd[k].detach().reshape(()) for k in ikeys]).to(dev) if ikeys else None
+    dist.broadcast(flat, src)
+    if cnt is not None:
+        dist.broadcast(cnt, src)
+    if dist.get_rank() == src:
+        return
+    flat = flat.cpu()
+    out, off = {}, 0
+    for k in fkeys:
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].reshape(sd[k].shape).clone()
+        off += n
+    for i, k in enumerate(ikeys):
+        out[k] = cnt[i].cpu().clone()
+    net.load_state_dict(out)
+
+
+def sync_buffers(net, dist=None):
+    """BatchNorm running statistics are rank-local during an epoch (every rank normalises with the statistics of
+    ITS shard, as DDP replicas do); before validation they are averaged so that all ranks evaluate — and rank 0
+    checkpoints — the same model.  Returns the number of tensors averaged."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    if hasattr(net, "_specs"):   # HipNet: read only the running statistics out of the library
+        sd = {k: net._read_tensor(k, shape, torch.float32) for k, shape, kind in net._specs
+              if kind in ("bn_mean", "bn_var")}
+    else:                        # any module with a torch state_dict
+        sd = {k: v.detach().float() for k, v in net.state_dict().items()
+              if k.endswith(("running_mean", "running_var"))}
+    keys = list(sd)
+    if not keys:
+        return 0
+    dev = _comm_device(dist, getattr(net, "device", "cpu"))
+    flat = torch.cat([sd[k].reshape(-1) for k in keys]).to(dev)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat = (flat / dist.get_world_size()).cpu()
+    out, off = {}, 0
+    for k in keys:
+        n = sd[k].numel()
+        out[k] = flat[off:off + n].reshape(sd[k].shape).clone()
+        off += n
+    net.load_state_dict(out, strict=False)
+    return len(keys)
+
+
+def broadcast_object(obj, dist=None, src=0):
+    """Small Python value from rank `src` to everyone (model id, run directory)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return obj
+    box = [obj if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src)
+    return box[0]
+
+
+def all_ok(ok, dist=None):
+    """True iff `ok` holds on EVERY rank (one tiny all-reduce): lets the replicas leave a loop together instead
+    of one of them blocking the others in the next collective."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def gather_rows(rows, dist=None, dst=None):
+    """Inference: the ranks' [(roi, probs)] lists concatenated and sorted by ROI number, as `net_pass` returns them
+    (reference probability.py:195-197).  dst=None: on every rank; dst=r: on rank r only (None elsewhere).  The
+    exchange is a host-side object gather: the data path itself has no collective."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return sorted(rows)
-    out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, rows)
+    world = dist.get_world_size()
+    if dst is None:
+        out = [None] * world
+        dist.all_gather_object(out, rows)
+    else:
+        out = [None] * world if dist.get_rank() == dst else None
+        dist.gather_object(rows, out, dst=dst)
+        if out is None:
+            return None
     return sorted(r for part in out for r in part)

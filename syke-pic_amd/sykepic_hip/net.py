@@ -445,16 +445,19 @@ class HipNet:
         (reference sykepic/train/train.py:239-242) in one library call."""
         self._ensure_init()
         x, n, h, w, layout, dtype = self._prep(x)
-        if n < 2:
-            raise ValueError("Expected more than 1 value per channel when training (batch of 1)")
         y = y.to(self.device, dtype=torch.int64).contiguous()
         logits = torch.empty((n, self.num_classes), dtype=torch.float32, device=self.device) if want_logits else None
         with torch.cuda.device(self.device):
             lib.check(self._lib.spk_model_set_stream(self._h, self._stream()))
-            lib.check(self._lib.spk_train_forward_backward(
-                self._h, C.c_void_p(x.data_ptr()), n, h, w, layout, dtype, C.c_void_p(y.data_ptr()),
-                C.c_void_p(self._stats_buf().data_ptr()),
-                C.c_void_p(logits.data_ptr()) if want_logits else None))
+            try:
+                lib.check(self._lib.spk_train_forward_backward(
+                    self._h, C.c_void_p(x.data_ptr()), n, h, w, layout, dtype, C.c_void_p(y.data_ptr()),
+                    C.c_void_p(self._stats_buf().data_ptr()),
+                    C.c_void_p(logits.data_ptr()) if want_logits else None))
+            except RuntimeError as e:
+                if "Expected more than 1 value per channel" in str(e):   # torch raises ValueError for this
+                    raise ValueError(str(e).split(": ", 1)[-1]) from None
+                raise
         return logits
 
     def optim_step(self, desc):

@@ -82,37 +82,70 @@ def _batches(items, transform, batch_size):
         yield x, [name for name, _ in chunk]
 
 
-def process_sample(sample_path, net, params, out_dir, force=False):
-    from . import files, ifcb
-    sample_path = Path(sample_path)
-    sample = sample_path.name
-    csv_path = files.sample_csv_path(sample_path, out_dir, suffix=FILE_SUFFIX)
-    if csv_path.is_file():
+def _skip_existing(csv_path, force, dist):
+    """The reference's exists/force rule (probability.py:136-141), decided once by rank 0 for every rank."""
+    from . import dp
+    rank, _ = dp.rank_world(dist)
+    skip = False
+    if rank == 0 and csv_path.is_file():
         if force:
             log.warning(f"{csv_path.name} already exists, overwriting")
         else:
             log.warning(f"{csv_path.name} already exists, skipping")
-            return sample
-    log.debug(f"Computing probabilities for {sample}")
-    from . import gpu_preprocess
-    if gpu_preprocess.supported(params.transform, params.img_shape[0]):
-        # .roi bytes -> GPU -> resized/bordered uint8 batches -> forward: no PNGs, no per-ROI host work
-        gs = gpu_preprocess.SampleOnGpu(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"),
-                                        params.device)
-        th, tw = params.transform.target_dims
-        code = gpu_preprocess.border_code(params.transform)
+            skip = True
+    return dp.broadcast_object(skip, dist)
 
-        def gpu_batches():
-            for b in range(0, len(gs), params.batch_size):
-                e = min(len(gs), b + params.batch_size)
-                yield gs.batch(b, e, th, tw, code), [f"{sample}_{num:05d}.png" for num in gs.numbers[b:e]]
-        probabilities = net_pass(net, gpu_batches(), params.device)
-        probabilities_to_csv(probabilities, params.classes, csv_path)
+
+def _finish(rows, error, what, classes, csv_path, dist):
+    """Rows of this rank's shard -> the sample's CSV.  Ranks leave together: if any of them failed on this sample
+    all of them raise (the caller logs and goes on to the next sample, as the reference does), so no rank is left
+    waiting in the gather."""
+    from . import dp
+    rank, _ = dp.rank_world(dist)
+    if not dp.all_ok(error is None, dist):
+        raise error if error is not None else RuntimeError(f"another rank failed on {what}")
+    probabilities = dp.gather_rows(rows, dist, dst=0)
+    if rank == 0:
+        probabilities_to_csv(probabilities, classes, csv_path)
+
+
+def process_sample(sample_path, net, params, out_dir, force=False, dist=None):
+    """One IFCB sample -> `<out>/YYYY/MM/DD/<sample>.prob.csv`.  Under `torch.distributed` (one process per GPU)
+    the ROI list is split into contiguous shards (`dp.shard_range`), every rank runs `net_pass` on its shard
+    with its full weight replica, rank 0 merges the rows by ROI number and writes the file: the batch split of
+    SURVEY.md section 8e, no collective on the data path."""
+    from . import dp, files, ifcb
+    sample_path = Path(sample_path)
+    sample = sample_path.name
+    csv_path = files.sample_csv_path(sample_path, out_dir, suffix=FILE_SUFFIX)
+    if _skip_existing(csv_path, force, dist):
         return sample
-    rois = ifcb.read_rois(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"))
-    items = [(f"{sample}_{num:05d}.png", _as_chans(img, params.img_shape[0])) for num, img in rois]
-    probabilities = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
-    probabilities_to_csv(probabilities, params.classes, csv_path)
+    log.debug(f"Computing probabilities for {sample}")
+    rank, world = dp.rank_world(dist)
+    rows, error = [], None
+    try:
+        from . import gpu_preprocess
+        if gpu_preprocess.supported(params.transform, params.img_shape[0]):
+            # .roi bytes -> GPU -> resized/bordered uint8 batches -> forward: no PNGs, no per-ROI host work
+            gs = gpu_preprocess.SampleOnGpu(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"),
+                                            params.device)
+            th, tw = params.transform.target_dims
+            code = gpu_preprocess.border_code(params.transform)
+            lo, hi = dp.shard_range(len(gs), rank, world)
+
+            def gpu_batches():
+                for b in range(lo, hi, params.batch_size):
+                    e = min(hi, b + params.batch_size)
+                    yield gs.batch(b, e, th, tw, code), [f"{sample}_{num:05d}.png" for num in gs.numbers[b:e]]
+            rows = net_pass(net, gpu_batches(), params.device)
+        else:
+            rois = ifcb.read_rois(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"))
+            lo, hi = dp.shard_range(len(rois), rank, world)
+            items = [(f"{sample}_{num:05d}.png", _as_chans(img, params.img_shape[0])) for num, img in rois[lo:hi]]
+            rows = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
+    except Exception as e:  # noqa: BLE001 - re-raised below on every rank
+        error = e
+    _finish(rows, error, sample, params.classes, csv_path, dist)
     return sample
 
 
@@ -123,24 +156,30 @@ def _as_chans(gray, num_chans):
     return np.repeat(gray[:, :, None], 3, axis=2)
 
 
-def process_images(img_paths, net, params, csv_path, force=False):
-    from . import pngio
+def process_images(img_paths, net, params, csv_path, force=False, dist=None):
+    from . import dp, pngio
     csv_path = Path(csv_path)
-    if csv_path.is_file():
-        if force:
-            log.warning(f"{csv_path.name} already exists, overwriting")
-        else:
-            log.warning(f"{csv_path.name} already exists, skipping")
-            return
-    items = [(str(p), pngio.read_image(p, params.img_shape[0])) for p in img_paths]
-    probabilities = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
-    probabilities_to_csv(probabilities, params.classes, csv_path)
+    if _skip_existing(csv_path, force, dist):
+        return
+    rank, world = dp.rank_world(dist)
+    img_paths = list(img_paths)
+    lo, hi = dp.shard_range(len(img_paths), rank, world)
+    rows, error = [], None
+    try:
+        items = [(str(p), pngio.read_image(p, params.img_shape[0])) for p in img_paths[lo:hi]]
+        rows = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
+    except Exception as e:  # noqa: BLE001 - re-raised below on every rank
+        error = e
+    _finish(rows, error, csv_path.name, params.classes, csv_path, dist)
 
 
 def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=False,
          progress_bar=True, samples_as_images=False):
-    net, classes, img_shape, eval_transform, device = prepare_model(model_dir)
+    from . import dp
+    dist, rank, world, local = dp.init_from_env()   # one process per GPU under torch.distributed.run
+    net, classes, img_shape, eval_transform, device = prepare_model(model_dir, f"cuda:{local}")
     params = EvalParams(batch_size, num_workers, classes, img_shape, eval_transform, device)
+    progress_bar = progress_bar and rank == 0
     try:
         from tqdm import tqdm
     except ImportError:  # pragma: no cover
@@ -150,7 +189,7 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
         if progress_bar and tqdm:
             it = tqdm(it, desc="Processing samples")
         for sample, img_paths in it:
-            process_images(img_paths, net, params, Path(out_dir) / f"{sample}{FILE_SUFFIX}.csv", force)
+            process_images(img_paths, net, params, Path(out_dir) / f"{sample}{FILE_SUFFIX}.csv", force, dist)
         return None
     it = sample_paths
     if progress_bar and tqdm:
@@ -158,7 +197,7 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
     done = set()
     for sample_path in it:
         try:
-            done.add(process_sample(sample_path, net, params, out_dir, force))
+            done.add(process_sample(sample_path, net, params, out_dir, force, dist))
         except ValueError:
             log.exception(f"Faulty raw data for {Path(sample_path).name}")
         except Exception:

@@ -25,21 +25,13 @@ import torch
 
 from . import data, schedule
 from .config import get_img_shape, get_network, get_transforms
+from . import dp
 from .dp import GradSync
 from .optim import HipOptimizer
 
 
 def _dist():
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
-        return None, 0, 1, 0
-    import torch.distributed as dist
-    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
-    if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    return dist, rank, world, local
+    return dp.init_from_env()
 
 
 def main(args):
@@ -112,7 +104,8 @@ def main(args):
     model_id = config.get("model", "id")
     model_dir = Path(config.get("model", "path"))
     if model_id == "auto":
-        model_id = data.auto_id(model_network, model_dir)
+        # one id for the whole job: rank 0 picks it (another rank could see the directory rank 0 has just made)
+        model_id = dp.broadcast_object(data.auto_id(model_network, model_dir) if chief else None, dist)
     model_name = model_network + (f"_{model_id}" if model_id else "")
     model_dir = model_dir / model_name
     if chief:
@@ -132,6 +125,7 @@ def main(args):
     optimizer_name = config.get("train", "optimizer")
 
     net = get_network(config, num_classes, device=device)
+    dp.broadcast_state(net, dist)   # every replica starts from rank 0's (random / pretrained) tensors
     schedule.freeze(net.base)
     initial = [p for p in net.parameters() if p.requires_grad]
     optimizer = HipOptimizer(net, optimizer_name, [{"params": initial, "lr": lr},
@@ -175,6 +169,7 @@ def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epo
     fused into the training step (the only loss the reference constructs)."""
     net = net.to(device)
     chief = dist is None or dist.get_rank() == 0
+    parallel = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
     sync = GradSync(net, dist)
     max_val_acc, min_val_loss, no_improvement = 0, 0, 0
     train_accs, train_losses, val_accs, val_losses = [], [], [], []
@@ -208,6 +203,10 @@ def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epo
             if chief:
                 print(f"[STAT] Train Acc: {train_acc:.3f}, Train Loss: {train_loss:.3f}")
 
+            # validation: every rank holds the same model (running statistics averaged), evaluates ITS shard of
+            # the validation set, and the counters are summed: checkpoint, early-stop and learning-rate decisions
+            # below are then identical on every rank by construction
+            dp.sync_buffers(net, dist)
             net.eval()
             net.reset_stats()
             seen = 0
@@ -215,6 +214,7 @@ def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epo
                 net.eval_step(batch[0], batch[1])
                 seen += len(batch[1])
             loss_sum, correct = net.read_stats()
+            loss_sum, correct, seen = sync.reduce_stats(loss_sum, correct, seen)
             val_acc, val_loss = correct / seen, loss_sum / seen
             val_accs.append(val_acc)
             val_losses.append(val_loss)
@@ -243,6 +243,10 @@ def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epo
         print("[INFO] Stopping early")
     except Exception as e:  # the reference swallows every error here (quirk Q5)
         print(f"[ERROR] {e}")
+        if parallel:
+            # ... but one replica leaving the loop would leave the others blocked in the next all-reduce:
+            # under data parallelism the error ends the rank (non-zero exit; the launcher stops the job)
+            raise
     return best_state
 
 

@@ -130,6 +130,62 @@ def golden_net_pass(effnet=False):
     np.savez_compressed(HERE / ("net_pass_effnet.npz" if effnet else "net_pass.npz"), **out)
 
 
+def golden_net_pass_diverse():
+    """A second net_pass fixture whose 8 images have (almost) all-different arg-max classes, so that the tests'
+    top-1 assertion bites: 48 candidate images go through the reference's net_pass; 8 are picked greedily for
+    distinct top-1 classes with a top-2 margin above 4e-3; those 8 go through the reference's net_pass again
+    (two ragged batches, unsorted sparse ROI ids) and are stored with their indices into the candidate batch."""
+    from sykepic.compute.probability import net_pass
+    out = {}
+    for network, hw in (("resnet18", 180), ("resnet50", 224)):
+        net = build_ref_net(network, 50, seed=2)
+        with torch.no_grad():
+            # standardise every class's logit over a calibration batch (row scale of the last Linear + bias
+            # shift, both stored and re-applied by the tests): a random-weight net otherwise lets the two or
+            # three classes with the largest logit variance win every image
+            net.eval()
+            xc = torch.from_numpy(synth.synth_images(32, 3, hw, hw, seed=99))
+            z = net(xc)
+            row_scale = 4.0 / z.std(0)
+            net.head[-1].weight *= row_scale[:, None]
+            net.head[-1].bias *= row_scale
+            adj = -net(xc).mean(0)
+            net.head[-1].bias += adj
+        cand = torch.from_numpy(synth.synth_images(48, 3, hw, hw, seed=7))
+        res = net_pass(net, [(cand[i:i + 16], [f"/x/S_{j:05d}.png" for j in range(i, i + 16)]) for i in (0, 16, 32)], "cpu")
+        probs = np.array([p for _, p in res], dtype=np.float64)      # ROI ids == candidate indices
+        top2 = np.sort(probs, axis=1)[:, -2:]
+        margin = top2[:, 1] - top2[:, 0]
+        pick, seen = [], set()
+        for i in np.argsort(-margin):
+            c = int(probs[i].argmax())
+            if c not in seen and margin[i] > 4e-3:
+                pick.append(int(i))
+                seen.add(c)
+            if len(pick) == 8:
+                break
+        for i in np.argsort(-margin):   # fill up if fewer than 8 distinct classes exist
+            if len(pick) == 8:
+                break
+            if int(i) not in pick:
+                pick.append(int(i))
+        x = cand[pick]
+        rois = [int(r) for r in (synth.hash_u32(8, 78) % 1000 + 2)]
+        paths = [f"/x/D20180712T065600_IFCB114_{r:05d}.png" for r in rois]
+        res = net_pass(net, [(x[:3], paths[:3]), (x[3:], paths[3:])], "cpu")
+        tag = f"{network}_{hw}"
+        out[f"{tag}_index"] = np.array(pick, dtype=np.int64)
+        out[f"{tag}_rois_in"] = np.array(rois, dtype=np.int64)
+        out[f"{tag}_bias_adj"] = adj.numpy()
+        out[f"{tag}_row_scale"] = row_scale.numpy()
+        out[f"{tag}_rois_out"] = np.array([r for r, _ in res], dtype=np.int64)
+        out[f"{tag}_probs"] = np.array([p for _, p in res], dtype=np.float32)
+        distinct = len(set(out[f"{tag}_probs"].argmax(1).tolist()))
+        print(tag, "top1", out[f"{tag}_probs"].argmax(1), "distinct", distinct)
+        assert distinct >= 6, "fixture must have at least 6 distinct arg-max classes"
+    np.savez_compressed(HERE / "net_pass_diverse.npz", **out)
+
+
 class SnapshotLoader:
     """Validation 'dataloader' that snapshots the net each time the
     reference's train_net starts its validation phase (i.e. right after the
@@ -274,6 +330,8 @@ if __name__ == "__main__":
         golden_net_pass()
     if "effnet" in which:
         golden_net_pass(effnet=True)
+    if "diverse" in which:
+        golden_net_pass_diverse()
     if "train" in which:
         for name in ("SGD", "Adam"):
             with tempfile.TemporaryDirectory() as tmp:

@@ -73,6 +73,155 @@ def test_gradient_allreduce_world2(tmp_path):
     assert [k for k, _ in r[0]["rows"]] == [0, 1, 2, 100, 101, 102]
 
 
+def _replica_worker(rank, world, port, out_dir):
+    """Two replicas that start from DIFFERENT random initialisations (the default start: nothing can be
+    downloaded, the head is always random) run the data-parallel recipe of sykepic_hip.train.train_net on the CPU
+    oracle network: broadcast_state -> per step: local forward/backward, flat-gradient all-reduce, identical SGD
+    step -> sync_buffers before "validation"."""
+    for p in (ROOT, ROOT / "syke-pic_amd"):
+        sys.path.insert(0, str(p))
+    import torch.distributed as dist
+    from oracle import refnet
+    from sykepic_hip import dp, synth
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    classes, n, hw = 6, 8, 32
+    torch.manual_seed(100 + rank)                 # rank-dependent start, as unseeded processes would have
+    net = refnet.RefNet("resnet18", classes)
+    for p in net.parameters():
+        p.data.normal_(0, 0.05)
+    before = torch.cat([p.detach().flatten() for p in net.parameters()]).clone()
+    dp.broadcast_state(net, dist)
+    after_bc = torch.cat([p.detach().flatten() for p in net.parameters()]).clone()
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    for step in range(3):
+        x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=20 + step))
+        y = torch.from_numpy(synth.synth_labels(n, classes, seed=40 + step))
+        b, e = dp.shard_range(n, rank, world)
+        opt.zero_grad()
+        torch.nn.functional.cross_entropy(net(x[b:e]), y[b:e]).backward()
+        flat = torch.cat([p.grad.flatten() for p in net.parameters()])
+        dp.GradSync(None, dist, view=flat).all_reduce()
+        off = 0
+        for p in net.parameters():
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p) / world)
+            off += p.numel()
+        opt.step()
+    stats_before = {k: v.clone() for k, v in net.state_dict().items() if k.endswith("running_mean")}
+    n_synced = dp.sync_buffers(net, dist)
+    ok_all = dp.all_ok(True, dist)
+    ok_one = dp.all_ok(rank != 1, dist)
+    mid = dp.broadcast_object("resnet18_7" if rank == 0 else None, dist)
+    torch.save({"before": before, "after_bc": after_bc, "state": net.state_dict(), "stats_before": stats_before,
+                "n_synced": n_synced, "ok_all": ok_all, "ok_one": ok_one, "mid": mid}, Path(out_dir) / f"s{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_replicas_start_equal_and_stay_bit_equal_world2(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_replica_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"s{i}.pt") for i in range(world)]
+    assert not torch.equal(r[0]["before"], r[1]["before"])          # the starts really differed
+    assert torch.equal(r[0]["after_bc"], r[1]["after_bc"]) and torch.equal(r[0]["after_bc"], r[0]["before"])
+    # running statistics were rank-local during the steps (different shards) ...
+    k = next(iter(r[0]["stats_before"]))
+    assert not torch.equal(r[0]["stats_before"][k], r[1]["stats_before"][k])
+    # ... and after sync_buffers every tensor of the two state_dicts is bit-equal
+    assert r[0]["n_synced"] == r[1]["n_synced"] > 0
+    for key, v in r[0]["state"].items():
+        assert torch.equal(v, r[1]["state"][key]), key
+    assert torch.allclose(r[0]["state"][k], (r[0]["stats_before"][k] + r[1]["stats_before"][k]) / 2, atol=1e-7)
+    assert r[0]["ok_all"] and r[1]["ok_all"] and not r[0]["ok_one"] and not r[1]["ok_one"]
+    assert r[0]["mid"] == r[1]["mid"] == "resnet18_7"
+
+
+class _FakeNet:
+    """Stands in for HipNet in prob.net_pass on the CPU: 'probabilities' are a fixed function of each image."""
+
+    def to(self, device):
+        return self
+
+    def eval(self):
+        return self
+
+    def probabilities(self, x, base):
+        feats = torch.stack([x.mean((1, 2, 3)), x.std((1, 2, 3)), x[:, 0].amax((1, 2)), x[:, 0, ::2].mean((1, 2))], 1)
+        w = torch.linspace(-3, 3, 4 * 5).reshape(4, 5)
+        return torch.softmax(feats.double() @ w.double() * float(np.log(base)), 1).float()
+
+
+def _write_sample(raw_dir, n_rois=23, seed=3):
+    """A synthetic IFCB sample: .adc (24 comma-separated columns; 16/17/18 = width/height/start byte, 1-based
+    as in the reference's fixture) + .roi, with an empty ROI in the middle (ids stay sparse, quirk Q11)."""
+    rng = np.random.default_rng(seed)
+    raw_dir.mkdir(parents=True, exist_ok=True)
+    name = "D20200101T000000_IFCB999"
+    blob, lines, start = [], [], 0
+    for i in range(n_rois):
+        w, h = (0, 0) if i == 7 else (int(rng.integers(20, 90)), int(rng.integers(20, 70)))
+        cols = ["0"] * 24
+        cols[15], cols[16], cols[17] = str(w), str(h), str(start)
+        lines.append(",".join(cols))
+        if w * h:
+            blob.append(rng.integers(0, 256, w * h, dtype=np.uint8))
+            start += w * h
+    (raw_dir / f"{name}.adc").write_text("\n".join(lines) + "\n")
+    (raw_dir / f"{name}.roi").write_bytes(np.concatenate(blob).tobytes())
+    return raw_dir / name
+
+
+def _prob_worker(rank, world, port, root):
+    for p in (ROOT, ROOT / "syke-pic_amd"):
+        sys.path.insert(0, str(p))
+    import torch.distributed as dist
+    from sykepic_hip import gpu_preprocess, prob
+    from sykepic_hip import preprocess as P
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gpu_preprocess.supported = lambda *a, **k: False          # host pipeline (no GPU here)
+    tf = P.Compose([P.Resize(), P.ToTensor()], (48, 48), "mode")
+    params = prob.EvalParams(4, 0, [f"c{i}" for i in range(5)], (3, 48, 48), tf, "cpu")
+    sample = Path(root) / "raw" / "D20200101T000000_IFCB999"
+    prob.process_sample(sample, _FakeNet(), params, Path(root) / f"out_w{world}", force=False, dist=dist)
+    # a sample that fails on every rank (missing .roi) must raise everywhere and leave no rank behind
+    try:
+        prob.process_sample(Path(root) / "raw" / "missing_IFCB999", _FakeNet(), params, Path(root) / f"out_w{world}",
+                            force=False, dist=dist)
+        raised = False
+    except Exception:
+        raised = True
+    assert raised
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prob_batch_split_world2_equals_single_process(tmp_path):
+    """`sykepic prob` under 2 ranks: each rank runs net_pass on its contiguous shard of the ROI list, rank 0 merges
+    by ROI id and writes the CSV — byte-identical to the single-process file (reference net_pass order,
+    probability.py:195-197)."""
+    sys.path.insert(0, str(ROOT / "syke-pic_amd"))
+    from sykepic_hip import gpu_preprocess, prob
+    from sykepic_hip import preprocess as P
+    sample = _write_sample(tmp_path / "raw")
+    keep = gpu_preprocess.supported
+    gpu_preprocess.supported = lambda *a, **k: False
+    try:
+        tf = P.Compose([P.Resize(), P.ToTensor()], (48, 48), "mode")
+        params = prob.EvalParams(4, 0, [f"c{i}" for i in range(5)], (3, 48, 48), tf, "cpu")
+        prob.process_sample(sample, _FakeNet(), params, tmp_path / "out_w1")
+    finally:
+        gpu_preprocess.supported = keep
+    mp.spawn(_prob_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    one = list((tmp_path / "out_w1").rglob("*.prob.csv"))
+    two = list((tmp_path / "out_w2").rglob("*.prob.csv"))
+    assert len(one) == len(two) == 1 and one[0].name == two[0].name
+    assert one[0].read_bytes() == two[0].read_bytes()
+    rows = one[0].read_text().splitlines()
+    assert len(rows) == 1 + 22 and [int(r.split(",")[0]) for r in rows[1:]] == [i + 1 for i in range(23) if i != 7]
+
+
 def test_sharding_helpers():
     sys.path.insert(0, str(ROOT / "syke-pic_amd"))
     from sykepic_hip import dp

@@ -53,3 +53,90 @@ def test_bench_two_ranks_like_the_driver(tmp_path):
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["global_batch"] == 32
     assert res["value"] > 0 and res["train"]["value"] > 0 and res["config"]["parallelism"] == "dp2"
+
+
+def _synthetic_sample(raw_dir, n_rois=150, seed=5):
+    """.adc + .roi of a synthetic IFCB sample (column 16/17/18 = width/height/start byte, one empty trigger)."""
+    rng = np.random.default_rng(seed)
+    raw_dir.mkdir(parents=True, exist_ok=True)
+    name = "D20200101T000000_IFCB999"
+    blob, lines, start = [], [], 0
+    for i in range(n_rois):
+        w, h = (0, 0) if i == 40 else (int(rng.integers(24, 120)), int(rng.integers(24, 90)))
+        cols = ["0"] * 24
+        cols[15], cols[16], cols[17] = str(w), str(h), str(start)
+        lines.append(",".join(cols))
+        if w * h:
+            bg = int(rng.integers(150, 220))
+            img = np.clip(rng.normal(bg, 6, (h, w)), 0, 255).astype(np.uint8)
+            img[h // 4: h // 2, w // 4: w // 2] = int(rng.integers(20, 120))
+            blob.append(img.reshape(-1))
+            start += w * h
+    (raw_dir / f"{name}.adc").write_text("\n".join(lines) + "\n")
+    (raw_dir / f"{name}.roi").write_bytes(np.concatenate(blob).tobytes())
+    return name
+
+
+def test_prob_cli_two_ranks_equals_one_rank(tmp_path, golden_dir):
+    """`sykepic prob` launched as the multi-GPU job (torch.distributed.run, one process per rank; here 2 ranks on
+    the one test GPU over gloo): every rank preprocesses and classifies ITS contiguous shard of the sample's ROI
+    list with a full weight replica, rank 0 merges the rows by ROI id and writes the CSV.  The file must equal the
+    single-process file byte for byte (same kernels, same per-image arithmetic: a row does not depend on which
+    images share its batch)."""
+    import shutil
+    model = tmp_path / "model"
+    model.mkdir()
+    shutil.copy(golden_dir / "ref_data" / "class_names.txt", model / "class_names.txt")
+    shutil.copy(golden_dir / "ref_data" / "config.ini", model / "config.ini")
+    g = arch.build_graph("resnet18", 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, model / "best_state.pth")
+    name = _synthetic_sample(tmp_path / "raw")
+    env = dict(os.environ, PYTHONPATH=f"{ROOT / 'syke-pic_amd'}:{os.environ.get('PYTHONPATH', '')}", MASTER_ADDR="127.0.0.1")
+    base = ["-m", "sykepic_hip", "prob", "-r", str(tmp_path / "raw"), "-m", str(model), "-b", "32"]
+    one = subprocess.run([sys.executable] + base + ["-o", str(tmp_path / "out1")], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519"] + base + ["-o", str(tmp_path / "out2")],
+                         env=dict(env, SPK_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    f1 = list((tmp_path / "out1").rglob(f"{name}.prob.csv"))
+    f2 = list((tmp_path / "out2").rglob(f"{name}.prob.csv"))
+    assert len(f1) == len(f2) == 1
+    rows = f1[0].read_text().splitlines()
+    assert len(rows) == 1 + 149 and rows[1].startswith("1,") and rows[-1].startswith("150,")
+    assert f1[0].read_bytes() == f2[0].read_bytes()
+
+
+def test_tune_cache_persists_and_is_reused(tmp_path):
+    """SPK_TUNE_CACHE: the first process times the candidates and appends its winners; a second process loads the
+    file and tunes nothing (no `[spk tune]` lines), also for a ragged tail batch (nearest tuned batch size within
+    a factor of two) — and both produce bit-identical probabilities."""
+    cache = tmp_path / "tune.txt"
+    code = (
+        "import sys, numpy as np, torch\n"
+        f"sys.path[:0] = [{str(ROOT)!r}, {str(ROOT / 'syke-pic_amd')!r}]\n"
+        "from sykepic_hip import arch, synth\n"
+        "from sykepic_hip.net import HipNet\n"
+        "g = arch.build_graph('resnet18', 10)\n"
+        "sd = synth.synth_state_dict(arch.param_specs(g), seed=2)\n"
+        "net = HipNet('resnet18', 10, weights=None)\n"
+        "net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})\n"
+        "net.eval()\n"
+        "x = torch.from_numpy(synth.synth_images(48, 3, 64, 64, seed=0)).cuda()\n"
+        "p = net.probabilities(x).cpu(); q = net.probabilities(x[:37]).cpu()\n"
+        "np.save(sys.argv[1], np.concatenate([p.numpy(), q.numpy()]))\n")
+    env = dict(os.environ, SPK_TUNE_CACHE=str(cache), SPK_TUNE_LOG="1")
+    first = subprocess.run([sys.executable, "-c", code, str(tmp_path / "a.npy")], env=env, capture_output=True,
+                           text=True, timeout=600)
+    assert first.returncode == 0, first.stderr[-2000:]
+    assert "[spk tune]" in first.stderr and cache.is_file()
+    lines = cache.read_text().splitlines()
+    assert lines and all(ln.startswith(("conv ", "wgrad ")) for ln in lines)
+    second = subprocess.run([sys.executable, "-c", code, str(tmp_path / "b.npy")], env=env, capture_output=True,
+                            text=True, timeout=600)
+    assert second.returncode == 0, second.stderr[-2000:]
+    assert "[spk tune]" not in second.stderr
+    assert cache.read_text().splitlines() == lines              # nothing re-tuned, nothing appended
+    assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))

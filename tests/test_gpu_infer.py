@@ -60,10 +60,32 @@ def test_probabilities_match_reference_golden(golden_dir, network, hw):
     assert np.allclose(p.sum(1), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("network,hw", [("resnet18", 180), ("resnet50", 224)])
+def test_probabilities_match_reference_golden_diverse_top1(golden_dir, network, hw):
+    """The reference's net_pass on 8 images with 8 DIFFERENT arg-max classes (net_pass_diverse.npz): the top-1
+    assertion cannot pass by always answering the same class; ragged batches of 3 + 5, unsorted sparse ROI ids."""
+    from test_oracle_golden import diverse_case
+    from sykepic_hip.prob import net_pass
+    g, sd, x, paths, rois_out, ref = diverse_case(golden_dir, network, hw)
+    assert len(set(ref.argmax(1).tolist())) >= 6
+    net = _hipnet(network, sd)
+    xc = x.cuda()
+    res = net_pass(net, [(xc[:3], paths[:3]), (xc[3:], paths[3:])], "cuda:0")
+    assert [r for r, _ in res] == rois_out
+    p = np.array([q for _, q in res], dtype=np.float64)
+    err = np.abs(p - ref).max()
+    print(f"{network}_{hw} (diverse): max |dp| = {err:.2e}, top-1 {p.argmax(1).tolist()}")
+    assert err <= PROB_TOL
+    top2 = np.sort(ref, axis=1)[:, -2:]
+    assert ((top2[:, 1] - top2[:, 0]) > 2 * PROB_TOL).all()      # every image is decided in this fixture
+    assert (p.argmax(1) == ref.argmax(1)).all()
+
+
 @pytest.mark.parametrize("network,hw,n", [("resnet18", 96, 5), ("resnet50", 64, 3), ("resnet34", 64, 2)])
 def test_layerwise_vs_oracle(network, hw, n):
-    """Every activation of the graph against the torch fp32 interpreter
-    (bf16 storage => relative tolerance 2^-7 of the layer's scale)."""
+    """Every activation of the graph against the torch fp32 interpreter: maximum element error <= 4e-3 of the
+    layer's largest value (measured worst case 1.1e-3: fp16 storage 2^-11 per tensor plus accumulation over
+    the depth; a wrong halo tap or a dropped K chunk on ONE edge pixel is an O(1) error of that element)."""
     from oracle import graph_eval, refnet
     g = arch.build_graph(network, 50)
     sd = synth.synth_state_dict(arch.param_specs(g), seed=3)
@@ -83,9 +105,9 @@ def test_layerwise_vs_oracle(network, hw, n):
         scale = float(want.abs().max()) + 1e-6
         err = float((got - want).abs().max()) / scale
         worst = max(worst, err)
-        assert err < 0.03, f"{network} {op.name or op.kind} id {op.dst}: rel err {err:.3e}"
+        assert err < 4e-3, f"{network} {op.name or op.kind} id {op.dst}: rel err {err:.3e}"
     print(f"{network}@{hw}: worst layer rel err {worst:.2e}")
-    assert float((z - z_ref).abs().max()) / (float(z_ref.abs().max()) + 1e-6) < 0.03
+    assert float((z - z_ref).abs().max()) / (float(z_ref.abs().max()) + 1e-6) < 4e-3
 
 
 def test_ragged_batches_and_odd_sizes():

@@ -56,16 +56,23 @@ def _cos(a, b):
 @pytest.mark.parametrize("network,hw,n", [("resnet18", 64, 8), ("resnet50", 64, 6), ("resnet18", 75, 5),
                                           ("resnet50", 96, 16), ("resnet34", 64, 4)])
 def test_backward_matches_the_bf16_emulating_oracle(network, hw, n):
-    """Whole-network check of every backward kernel: oracle.graph_eval.train_step_bf16 restates the training step
-    with a bf16 rounding exactly where the HIP path stores a tensor (activations AND gradients) and is evaluated
-    layer by layer at the activations the GPU produced (each layer starts from the GPU's own input, its own
-    output decides its ReLU mask and BatchNorm statistics).  What is left is accumulation order and the rare
-    1-ulp flip: measured <= 4e-3, asserted <= 1e-2 relative L2 per parameter-gradient tensor (1e-4 in the fp32
-    head), and the same bound for the gradient w.r.t. every activation.  The forward is checked on the way:
-    every layer's own output, from the GPU's input, equals the GPU's output to <= 4e-3 (bf16: 1-ulp flips).
-
+    """Whole-network check of every backward kernel at the GPU's own operating point.
+    oracle.graph_eval.train_step_bf16 restates the training step with a bf16 rounding exactly where the HIP path
+    stores a tensor and is evaluated layer by layer from the activations the GPU produced (each layer starts from
+    the GPU's own input; its own output decides its ReLU mask and BatchNorm statistics).  Two settings:
+      exact  (round_grads=False): float32 gradients = exact backpropagation through that forward;
+      bf16   (round_grads=True):  gradients rounded where the GPU stores them.
+    |bf16 - exact| is what bf16 gradient STORAGE costs by construction: a random walk that grows from 2e-3 behind
+    the loss to ~1e-2 at the stem of ResNet-50 (measured, tests/diagnostics/grad_err_depth.py).  Two
+    implementations of the same rounding points decorrelate within ~4 layers (one flipped ulp perturbs every sum
+    it enters), so beyond the tail of the net the GPU cannot equal the emulation bit for bit; what must hold is
+      (1) near the loss (last block + head) the GPU equals the bf16 emulation: <= 3e-3 (measured 3e-5 ... 1.9e-3);
+      (2) everywhere the GPU is as close to EXACT backpropagation as the emulation of its rounding points is:
+          |GPU - exact| <= 1.5 |bf16 - exact| + 2e-3 per tensor, and <= 3e-2 absolutely;
+      (3) the forward of every layer from the GPU's own input equals the GPU's output to <= 4e-3 (measured 1e-4).
     Round 1 compared with autograd through a forward that did NOT round the raw conv output before BatchNorm
-    (rel-L2 0.12): its ReLU masks differed from the GPU's on ~0.4 % of the elements of every layer."""
+    (rel-L2 0.12): its ReLU masks differed from the GPU's on ~0.4 % of the elements of every layer.  The single
+    kernels are pinned to their own output rounding (1.7e-3 bf16, 2e-7 float32) in tests/test_gpu_train_ops.py."""
     from oracle import graph_eval
     classes = 10
     g, specs, ref, net = _pair(network, classes, seed=5)
@@ -78,30 +85,46 @@ def test_backward_matches_the_bf16_emulating_oracle(network, hw, n):
     shapes = {t: tuple(v.shape) for t, v in graph_eval.run(g, state, x, train=True).items()}
     forced = {op.dst: net.read_activation(op.dst, n, shapes[op.dst]) for op in g.ops}
     emu = graph_eval.train_step_bf16(g, state, x, y, forced=forced)
-    # forward at the GPU's operating point
-    for op in g.ops:
+    exact = graph_eval.train_step_bf16(g, state, x, y, forced=forced, round_grads=False)
+    for op in g.ops:   # (3)
         r = _rel(forced[op.dst], emu["own"][op.dst])
         assert r < 4e-3, f"forward of {op.name or op.kind} from the GPU's own input: relative L2 {r:.3e}"
     assert abs(net.read_stats()[0] / n - float(emu["loss"])) < 1e-4 * max(1.0, float(emu["loss"]))
-    worst = ("", 0.0)
+    convs = [o for o in g.ops if o.kind == arch.OP_CONV]
+    blk = convs[-1].name.rsplit(".", 1)[0]                      # last residual block, e.g. base.7.2
+    tail_keys = set()
+    for o in convs:
+        if o.name.startswith(blk + "."):
+            tail_keys |= {o.name + ".weight", o.bn + ".weight", o.bn + ".bias"}
+    worst, worst_tail = ("", 0.0, 0.0), ("", 0.0)
     for k, _, kind in specs:
         if k not in emu["grads"]:
             continue
-        r = _rel(net._read_grad(k, tuple(emu["grads"][k].shape)), emu["grads"][k])
-        if r > worst[1]:
-            worst = (k, r)
-        assert r < (1e-4 if k.startswith("head.") else 1e-2), f"{k}: relative L2 gradient error {r:.3e}"
-    worst_a = ("", 0.0)
+        got = net._read_grad(k, tuple(emu["grads"][k].shape))
+        if k.startswith("head."):
+            assert _rel(got, exact["grads"][k]) < 1e-4, k
+            continue
+        noise, err = _rel(emu["grads"][k], exact["grads"][k]), _rel(got, exact["grads"][k])
+        if err > worst[1]:
+            worst = (k, err, noise)
+        assert err <= 1.5 * noise + 2e-3 and err < 3e-2, f"{k}: |GPU - exact| {err:.3e} vs |bf16 emulation - exact| {noise:.3e}"
+        if k in tail_keys:   # (1)
+            r = _rel(got, emu["grads"][k])
+            worst_tail = max(worst_tail, (k, r), key=lambda t: t[1])
+            assert r < 3e-3, f"{k} (last block): |GPU - bf16 emulation| {r:.3e}"
+    worst_a = ("", 0.0, 0.0)
     for op in g.ops:
         t = op.src
         if t == 0 or t not in emu["act_grads"]:
             continue
-        r = _rel(net.read_activation_grad(t, n, shapes[t]), emu["act_grads"][t])
-        if r > worst_a[1]:
-            worst_a = (f"input of {op.name}", r)
-        assert r < 1e-2, f"gradient w.r.t. the input of {op.name}: relative L2 {r:.3e}"
-    print(f"{network}@{hw}x{n}: worst parameter gradient rel-L2 {worst[1]:.3e} at {worst[0]}; "
-          f"worst activation gradient {worst_a[1]:.3e} at {worst_a[0]}")
+        got = net.read_activation_grad(t, n, shapes[t])
+        noise, err = _rel(emu["act_grads"][t], exact["act_grads"][t]), _rel(got, exact["act_grads"][t])
+        if err > worst_a[1]:
+            worst_a = (f"input of {op.name}", err, noise)
+        assert err <= 1.5 * noise + 2e-3 and err < 3e-2, f"gradient w.r.t. the input of {op.name}: {err:.3e} vs {noise:.3e}"
+    print(f"{network}@{hw}x{n}: worst |GPU - exact| {worst[1]:.3e} at {worst[0]} (bf16 emulation there: {worst[2]:.3e}); "
+          f"activation gradients {worst_a[1]:.3e} at {worst_a[0]} (emulation {worst_a[2]:.3e}); "
+          f"last block |GPU - bf16 emulation| {worst_tail[1]:.3e} at {worst_tail[0]}")
 
 
 @pytest.mark.parametrize("network,hw,n", [("resnet18", 64, 8), ("resnet50", 96, 16)])
@@ -154,6 +177,32 @@ def test_gradients_vs_fp32_autograd(network, hw, n):
             assert torch.allclose(sd_hip[k], sd_ref[k], rtol=2e-2, atol=2e-3), k
         if kind == "bn_nbt":
             assert int(sd_hip[k]) == int(sd_ref[k]) == 1
+
+
+def test_last_batch_of_one_image_trains_as_in_torch():
+    """The reference's loaders keep drop_last=False (data.py:178-180): len(train) % batch_size == 1 yields a batch
+    of ONE image.  torch trains it (BatchNorm2d normalises over H*W) unless a feature map has shrunk to 1x1, where
+    it raises ValueError.  Same here: a 64x64 image (layer4: 2x2) trains and matches the bf16-emulating oracle;
+    a 32x32 image (layer4: 1x1) raises ValueError with torch's message."""
+    from oracle import graph_eval
+    g, specs, ref, net = _pair("resnet18", 10, seed=5)
+    x = torch.from_numpy(synth.synth_images(1, 3, 64, 64, seed=10))
+    y = torch.from_numpy(synth.synth_labels(1, 10, seed=11))
+    net.train()
+    net.reset_stats()
+    net.forward_backward(x.cuda(), y.cuda())
+    state = _torch_state(ref)
+    shapes = {t: tuple(v.shape) for t, v in graph_eval.run(g, state, x, train=True).items()}
+    forced = {op.dst: net.read_activation(op.dst, 1, shapes[op.dst]) for op in g.ops}
+    exact = graph_eval.train_step_bf16(g, state, x, y, forced=forced, round_grads=False)
+    assert abs(net.read_stats()[0] - float(exact["loss"])) < 1e-4 * max(1.0, float(exact["loss"]))
+    for k, v in exact["grads"].items():
+        r = _rel(net._read_grad(k, tuple(v.shape)), v)
+        assert r < (1e-4 if k.startswith("head.") else 3e-2), f"{k}: {r:.3e}"
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        net.forward_backward(torch.from_numpy(synth.synth_images(1, 3, 32, 32, seed=1)).cuda(), y.cuda())
+    net.forward_backward(torch.from_numpy(synth.synth_images(2, 3, 32, 32, seed=1)).cuda(),
+                         torch.from_numpy(synth.synth_labels(2, 10, seed=2)).cuda())   # two images: fine
 
 
 def test_resnet50_train_step_at_the_benched_size():

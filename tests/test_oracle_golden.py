@@ -39,6 +39,35 @@ def test_net_pass_matches_reference(golden_dir, network, hw):
     assert np.abs(z.numpy() - gold[f"{tag}_logits"]).max() < 2e-3 * np.abs(gold[f"{tag}_logits"]).max()
 
 
+def diverse_case(golden_dir, network, hw):
+    """State dict, images, ROI ids and reference rows of the fixture whose 8 images have 8 different arg-max
+    classes (tests/golden/make_golden.py `diverse`: class-standardised last Linear, images picked out of 48)."""
+    gold = np.load(golden_dir / "net_pass_diverse.npz")
+    tag = f"{network}_{hw}"
+    g = arch.build_graph(network, 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    wkey = [k for k in sd if k.startswith("head.") and k.endswith(".weight")][-1]
+    bkey = wkey[:-len("weight")] + "bias"
+    scale = gold[f"{tag}_row_scale"]
+    sd[wkey] = sd[wkey] * scale[:, None]
+    sd[bkey] = sd[bkey] * scale + gold[f"{tag}_bias_adj"]
+    x = torch.from_numpy(synth.synth_images(48, 3, hw, hw, seed=7))[gold[f"{tag}_index"].tolist()]
+    rois = gold[f"{tag}_rois_in"].tolist()
+    paths = [f"/x/D20180712T065600_IFCB114_{r:05d}.png" for r in rois]
+    return g, sd, x, paths, gold[f"{tag}_rois_out"].tolist(), gold[f"{tag}_probs"].astype(np.float64)
+
+
+@pytest.mark.parametrize("network,hw", [("resnet18", 180), ("resnet50", 224)])
+def test_net_pass_matches_reference_on_diverse_images(golden_dir, network, hw):
+    g, sd, x, paths, rois_out, probs = diverse_case(golden_dir, network, hw)
+    assert len(set(probs.argmax(1).tolist())) >= 6            # the fixture's point: varied arg-max
+    res = refnet.net_pass(_net(network, 50, sd), [(x[:3], paths[:3]), (x[3:], paths[3:])])
+    assert [r for r, _ in res] == rois_out
+    p = np.array([q for _, q in res])
+    assert np.abs(p - probs).max() < 1e-6
+    assert (p.argmax(1) == probs.argmax(1)).all()
+
+
 @pytest.mark.parametrize("network", ["efficientnet_b0", "efficientnet_b4"])
 def test_efficientnet_net_pass_matches_reference(golden_dir, network):
     """EfficientNet (torchvision MBConv topology restated in oracle/backbones.py; parameter
