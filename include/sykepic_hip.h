@@ -64,10 +64,17 @@ extern "C" {
 #define SPK_DTYPE_I64 1
 #define SPK_DTYPE_U8 2
 
-/* optimizers (reference: any torch.optim class by name; Adam is the default,
- * train.ini.example:74) */
+/* optimizers (reference: `getattr(optim, name)` with only `lr` given, sykepic/train/train.py:131-138; Adam is the
+ * default, train.ini.example:74): the first-order torch.optim classes with their torch default hyper-parameters */
 #define SPK_OPT_SGD 0
 #define SPK_OPT_ADAM 1
+#define SPK_OPT_ADAMW 2     /* decoupled weight decay (default 0.01) */
+#define SPK_OPT_RMSPROP 3   /* alpha 0.99, eps 1e-8, optional momentum; centered = False */
+#define SPK_OPT_ADAGRAD 4   /* lr_decay, initial_accumulator_value, eps 1e-10 */
+#define SPK_OPT_ADAMAX 5
+#define SPK_OPT_NADAM 6     /* momentum_decay 4e-3 */
+#define SPK_OPT_RADAM 7
+#define SPK_OPT_ADADELTA 8  /* rho 0.9, eps 1e-6 */
 
 typedef struct spk_model spk_model;
 
@@ -93,8 +100,12 @@ typedef struct {
   float lr[3];
   float beta1, beta2, eps;  /* Adam */
   float weight_decay;
-  float momentum;           /* SGD */
+  float momentum;           /* SGD, RMSprop */
   float grad_scale;         /* multiplies every gradient first (1/world for DP mean) */
+  float alpha;              /* RMSprop smoothing constant / Adadelta rho */
+  float momentum_decay;     /* NAdam */
+  float lr_decay;           /* Adagrad */
+  float initial_accumulator_value; /* Adagrad */
 } spk_optim_desc;
 
 const char* spk_last_error(void);
@@ -240,8 +251,10 @@ int spk_preprocess_rois(const unsigned char* blob_dev, int64_t blob_bytes, const
  * image in the DataLoader workers.  The random draws stay on the host (Python `random`, reference call order);
  * ops_dev is [n_ops][n]: op j of every sample, applied in order, each rounding to uint8 as the host does.
  *   FLIP_H / FLIP_V: i0 = apply flag            TRANSLATE: i0 = x shift, i1 = y shift (constant border)
- *   ZOOM: i0 = side of the resized square (round(w * f)); centred pad (i0 < w) or crop
- *   ROTATE: d[0..5] = inverse affine map (row major 2x3), bilinear, constant border
+ *   ZOOM: d[0] = zoom factor f, i0 = side of the resized square (cvRound(w * f)); cv2.resize(fx = fy = f), then
+ *         centred pad (f < 1) or crop
+ *   ROTATE: d[0..5] = the 2x3 matrix as cv::warpAffine inverts it (row major); OpenCV's fixed-point bilinear
+ *           warp (1/32-pixel coordinates, 15-bit weight table), constant border
  *   BRIGHT: d[0] = factor, truncating
  * border_dev: [n][4] bytes (one value per channel).  tmp_dev: scratch of the batch size (needed when n_ops > 1).
  * The result is written to out_dev. */

@@ -189,6 +189,12 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
             saved[i] = a.shape
         elif op.kind == arch.OP_LINEAR:
             v = F.linear(a, state[op.name + ".weight"], state[op.name + ".bias"])
+        elif op.kind == arch.OP_DROPOUT and forced is not None and op.dst in forced and op.p > 0:
+            # nn.Dropout(p) in train mode: the kept set is whatever the GPU drew (its generator is its own, as
+            # torch's is); the arithmetic y = x * keep / (1 - p) and its backward are checked on that set
+            keep = (forced[op.dst] != 0) | (a == 0)
+            v = a * keep / (1.0 - op.p) if op.p < 1 else torch.zeros_like(a)
+            saved[i] = keep
         else:
             v = a
         own[op.dst] = v   # this layer's own output (before forcing): forward check at the GPU's operating point
@@ -240,6 +246,8 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
             if op.src != 0:
                 put(op.src, torch.nn.grad.conv2d_input(a.shape, wb, dy, op.stride, op.pad))
             grads[op.name + ".weight"] = torch.nn.grad.conv2d_weight(a, wb.shape, dy, op.stride, op.pad)
+        elif op.kind == arch.OP_DROPOUT and i in saved:
+            G[op.src] = gy * saved[i] / (1.0 - op.p) if op.p < 1 else torch.zeros_like(gy)
         else:
             G[op.src] = gy
     return {"logits": logits, "loss": loss, "acts": acts, "own": own, "grads": grads, "act_grads": G}

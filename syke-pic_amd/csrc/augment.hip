@@ -38,35 +38,27 @@ __global__ __launch_bounds__(256) void augment_kernel(const unsigned char* __res
         case SPK_AUG_FLIP_H: v = src[((size_t)y * w + (op.i0 ? w - 1 - x : x)) * c + ch]; break;
         case SPK_AUG_FLIP_V: v = src[((size_t)(op.i0 ? h - 1 - y : y) * w + x) * c + ch]; break;
         case SPK_AUG_TRANSLATE:  // dst(x, y) = src(x - tx, y - ty), constant border
+          // cv2.warpAffine with an integer shift lands on table entry (0,0): weights 32767 on the pixel and 1 on its
+          // lower-right neighbour -> (32767 a + b + 16384) >> 15 = a for 8-bit a, b: an exact copy
           v = tap_u8(src, h, w, c, ch, (long long)y - op.i1, (long long)x - op.i0, bv[ch]);
           break;
-        case SPK_AUG_ZOOM: {  // resize to i0 x i0, then centred pad (i0 < w) or crop (i0 >= w); square images
+        case SPK_AUG_ZOOM: {  // cv2.resize(img, None, fx=f, fy=f) to i0 x i0 (source coordinates with scale 1/f),
+                              // then centred pad (f < 1) or crop; square images
           const int z = op.i0;
-          if (z < w) {
+          const double sc = 1.0 / op.d[0];
+          if (op.d[0] < 1.0) {
             const int p1 = (w - z) / 2;  // int((w - zw) / 2), non-negative
             const int ry = y - p1, rx = x - p1;
-            v = (ry >= 0 && ry < z && rx >= 0 && rx < z) ? resize_u8_at(src + ch, c, w, h, z, z, rx, ry) : bv[ch];
+            v = (ry >= 0 && ry < z && rx >= 0 && rx < z) ? resize_u8_at(src + ch, c, w, h, z, z, sc, sc, rx, ry) : bv[ch];
           } else {
             const int c1 = (z - w) / 2;  // int((zw - w) / 2)
-            v = resize_u8_at(src + ch, c, w, h, z, z, x + c1, y + c1);
+            v = resize_u8_at(src + ch, c, w, h, z, z, sc, sc, x + c1, y + c1);
           }
           break;
         }
-        case SPK_AUG_ROTATE: {  // bilinear warp through the inverse affine map d[0..5], constant border
-          const double xs = (double)x, ys = (double)y;
-          const double sx = op.d[0] * xs + op.d[1] * ys + op.d[2];
-          const double sy = op.d[3] * xs + op.d[4] * ys + op.d[5];
-          const double fx0 = floor(sx), fy0 = floor(sy);
-          const long long x0 = (long long)fx0, y0 = (long long)fy0;
-          const double fx = sx - fx0, fy = sy - fy0;
-          const double t00 = tap_u8(src, h, w, c, ch, y0, x0, bv[ch]);
-          const double t01 = tap_u8(src, h, w, c, ch, y0, x0 + 1, bv[ch]);
-          const double t10 = tap_u8(src, h, w, c, ch, y0 + 1, x0, bv[ch]);
-          const double t11 = tap_u8(src, h, w, c, ch, y0 + 1, x0 + 1, bv[ch]);
-          const double o = t00 * (1 - fx) * (1 - fy) + t01 * fx * (1 - fy) + t10 * (1 - fx) * fy + t11 * fx * fy;
-          v = (int)fmin(fmax(rint(o), 0.0), 255.0);
+        case SPK_AUG_ROTATE:  // cv2.warpAffine through the inverted matrix d[0..5] (resize_u8.h), constant border
+          v = warp_affine_u8_at(src, h, w, c, ch, op.d, x, y, bv[ch]);
           break;
-        }
         case SPK_AUG_BRIGHT: {  // (img * v).clip(0, 255).astype(uint8): truncation
           const double o = (double)src[((size_t)y * w + x) * c + ch] * op.d[0];
           v = (int)fmin(fmax(o, 0.0), 255.0);

@@ -19,7 +19,8 @@ struct Param {
   int requires_grad = 0;
   int group = -1;          // optimizer param group, -1: not in the optimizer
   size_t off = 0;          // element offset in the flat fp32 buffers
-  long step = 0;           // per-tensor Adam step count (torch keeps it per parameter)
+  long step = 0;           // per-tensor step count (torch keeps it per parameter)
+  double mu_product = 1.0; // NAdam: running product of the momentum schedule
 };
 
 struct TDim {
@@ -38,6 +39,7 @@ struct Layer {
   size_t wpack_off = 0, sb_off = 0;
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
+  bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)
 };
 
 struct TrainState;

@@ -142,6 +142,12 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     for (const Layer& Q : m->layers)
       if (Q.d.kind == SPK_OP_CONV && Q.d.res == L.d.dst) L.trunk_writer = true;
   }
+  // the 3x3 conv in the middle of a bottleneck: its input comes from a 1x1 conv that is not a trunk writer
+  for (Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV || L.d.k != 3 || L.trunk_writer) continue;
+    for (const Layer& Q : m->layers)
+      if (Q.d.kind == SPK_OP_CONV && Q.d.dst == L.d.src && Q.d.k == 1 && !Q.trunk_writer) L.inner3x3 = true;
+  }
   for (int oi : order) {
     Layer& L = m->layers[oi];
     const std::string nm = L.d.name, bn = L.d.bn;
@@ -384,9 +390,11 @@ extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
 static int layer_split(const spk_model* m, const Layer& L) {
   if (m->infer_dt != DT_F16 || m->splitw == 0) return 0;
   if (m->splitw == 4) return m->split_mask[&L - m->layers.data()] ? 1 : 0;
-  // 3: every conv except the 3x3 convs inside a residual block (tests/diagnostics/split_rules.py: their
-  // weight rounding adds the least logit error per MFMA cycle a lo-product costs)
-  if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 ? 1 : 0;
+  // 3: every conv except the 3x3 conv in the middle of a BOTTLENECK block, i.e. a 3x3 conv that neither writes the
+  // trunk nor reads it (tests/diagnostics/split_rules.py: its weight rounding adds the least logit error per MFMA
+  // cycle a lo-product costs).  The first 3x3 conv of a basic block (ResNet-18/34) reads the trunk and stays split:
+  // un-split it costs 1.1e-3 of probability on the class-standardised golden fixture (tests/diagnostics/diverse_prec.py)
+  if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 || !L.inner3x3 ? 1 : 0;
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;
 }
 

@@ -6,10 +6,11 @@
 // sykepic/train/image.py:25-56,183-237).  SURVEY.md §8f rank 1: once the
 // forward runs at >3e4 img/s the per-ROI host pipeline is the bottleneck.
 //
-// Arithmetic is integer / double and replicates sykepic_hip/preprocess.py
-// (the host restatement of OpenCV's 8-bit INTER_LINEAR: 11-bit fixed-point
-// coefficients, the (b*(S>>4))>>16 vertical pass, the exact-2x INTER_AREA
-// shortcut) bit for bit — tests compare the two byte-wise.
+// Arithmetic replicates sykepic_hip/preprocess.py (the host restatement of
+// OpenCV 4.5.5's 8-bit INTER_LINEAR cv::resize: float32 source coordinates,
+// 11-bit fixed-point coefficients, the (b*(S>>4))>>16 vertical pass, the
+// exact-2x INTER_AREA shortcut; see resize_u8.h) bit for bit — tests compare
+// the two byte-wise.
 // One workgroup per ROI: LDS histogram for the mode, then 4 output pixels
 // (12 B = three dword stores) per thread per step.
 #include "../../include/sykepic_hip.h"
@@ -61,7 +62,8 @@ __global__ __launch_bounds__(256) void roi_preprocess_kernel(const unsigned char
   if (ok) { new_h = max(new_h, 1); new_w = max(new_w, 1); }
   const int top = max(out_h - new_h, 0) / 2, left = max(out_w - new_w, 0) / 2;
   const bool identity = (h == new_h && w == new_w);
-  const bool half = (w == 2 * new_w && h == 2 * new_h);
+  const double scale_x = ok ? resize_scale(w, new_w) : 1.0, scale_y = ok ? resize_scale(h, new_h) : 1.0;
+  const bool half = (scale_x == 2.0 && scale_y == 2.0);
 
   unsigned char* dst = out + (size_t)blockIdx.x * out_h * out_w * 3;
   const int quads = (out_h * out_w + 3) / 4;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void roi_preprocess_kernel(const unsigned char
           const unsigned char* q = src + (2 * ry) * w + 2 * rx;
           v = (q[0] + q[1] + q[w] + q[w + 1] + 2) >> 2;
         } else {
-          const Axis ax = coeff(rx, w, new_w), ay = coeff(ry, h, new_h);
+          const Axis ax = coeff<false>(rx, w, scale_x), ay = coeff<true>(ry, h, scale_y);
           const int r0 = src[ay.i0 * w + ax.i0] * ax.a0 + src[ay.i0 * w + ax.i1] * ax.a1;
           const int r1 = src[ay.i1 * w + ax.i0] * ax.a0 + src[ay.i1 * w + ax.i1] * ax.a1;
           v = (((ay.a0 * (r0 >> 4)) >> 16) + ((ay.a1 * (r1 >> 4)) >> 16) + 2) >> 2;

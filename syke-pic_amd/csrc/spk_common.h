@@ -146,7 +146,8 @@ struct OptEntry {
   unsigned long long off;  // element offset in the flat buffers
   unsigned int n;
   float lr, bc1, bc2s;
-  int first;               // SGD momentum: first step of this tensor
+  int first;               // first step of this tensor (momentum buffers / accumulators start here)
+  float c0, c1;            // per-tensor, per-step scalars of the other optimizers (see opt_generic_kernel)
 };
 struct OptTable {
   OptEntry e[64];
@@ -171,12 +172,15 @@ int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* g
                            int c, int k, int stride, int pad, int ho, int wo, hipStream_t s);
 int spk_launch_gavgpool_bwd(const float* gy, bf16_t* gx, int n, int hw, int c, hipStream_t s);
 int spk_launch_colsum(const float* dy, float* db, int n, int c, hipStream_t s);
+int spk_launch_dropout_fwd(const float* x, float* y, unsigned char* mask, size_t n, float p, unsigned long long seed,
+                           hipStream_t s);
+int spk_launch_dropout_bwd(const float* gy, const unsigned char* mask, float* gx, size_t n, float p, hipStream_t s);
 int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s);
 int spk_launch_stem_wgrad_unpack(const float* slabs, float* out, int cout, int kh, int kw, int cin,
                                  int splits, hipStream_t s);
 int spk_launch_pack_dgrad(const float* w, bf16_t* out, int cout, int taps, int cin, hipStream_t s);
-int spk_launch_opt_multi(int adam, float* p, const float* g, float* m, float* v, const OptTable& t,
-                         float b1, float b2, float eps, float wd, float momentum, float gscale,
+int spk_launch_opt_multi(int kind, float* p, const float* g, float* m, float* v, const OptTable& t,
+                         float b1, float b2, float eps, float wd, float momentum, float gscale, float alpha,
                          hipStream_t s);
 void spk_wgrad_plan(int M, int Cout, int Ktot, int* splits, int* pix_per_split);
 int spk_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* slabs, int N, int H, int W, int Cin,

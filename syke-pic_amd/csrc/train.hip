@@ -63,6 +63,7 @@ struct TrainState {
   std::vector<ConvTrain> conv;  // indexed by layer
   bool weights_dirty = true;
   bool sgd_started = false;
+  unsigned long long steps = 0;   // training steps so far (dropout masks differ from step to step)
 
   // per (n,h,w) plan
   void* arena = nullptr;
@@ -179,6 +180,9 @@ static int plan_train(spk_model* m, int n, int h, int w) {
     } else if (L.d.kind == SPK_OP_MAXPOOL) {
       t->idx_off = total;
       total += al256((size_t)n * o.h * o.w * o.c);
+    } else if (L.d.kind == SPK_OP_DROPOUT) {
+      t->conv[i].mask_off = total;   // one byte per element of the head tensor
+      total += al256((size_t)n * o.c);
     }
   }
   t->dy_off = total;      total += al256(max_conv);
@@ -308,9 +312,6 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   if (m->eval_only)
     return tfail(SPK_ERR_UNSUPPORTED,
                  "this network (EfficientNet: depthwise / squeeze-excitation / SiLU layers) has an inference path only");
-  for (const Layer& L : m->layers)
-    if (L.d.kind == SPK_OP_DROPOUT && L.d.p > 0.f)
-      return tfail(SPK_ERR_UNSUPPORTED, "Dropout(p>0) in the head is not implemented on the MI355X training path yet");
   SPK_TRY(ensure_state(m));
   SPK_TRY(plan_train(m, n, h, w));
   SPK_TRY(repack_weights(m));
@@ -378,11 +379,18 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                     (float*)m->T(L.d.dst), n, L.d.cin, L.d.cout, s), "linear");
         mark(m, PH_HEAD_FWD);
         break;
+      case SPK_OP_DROPOUT:  // nn.Dropout(p) between head layers, train mode (reference network.py:59-61)
+        K_TRY(spk_launch_dropout_fwd((const float*)m->T(L.d.src), (float*)m->T(L.d.dst), t->MASK(i), (size_t)n * in.c,
+                                     L.d.p, (m->seed * 0x100000001B3ull) ^ (t->steps << 8) ^ (unsigned long long)i, s),
+              "dropout");
+        mark(m, PH_HEAD_FWD);
+        break;
       default:
         HIP_TRY(hipMemcpyAsync(m->T(L.d.dst), m->T(L.d.src), (size_t)n * in.c * 4, hipMemcpyDeviceToDevice, s));
         break;
     }
   }
+  t->steps += 1;
   m->dirty = true;  // running statistics moved: the eval-BN fold is stale
 
   // ------------------------- loss + dlogits -------------------------
@@ -419,7 +427,9 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         break;
       }
       case SPK_OP_DROPOUT:
-        HIP_TRY(hipMemcpyAsync(t->G(L.d.src), t->G(L.d.dst), (size_t)n * in.c * 4, hipMemcpyDeviceToDevice, s));
+        K_TRY(spk_launch_dropout_bwd((const float*)t->G(L.d.dst), t->MASK(i), (float*)t->G(L.d.src), (size_t)n * in.c,
+                                     L.d.p, s), "dropout bwd");
+        mark(m, PH_HEAD_BWD);
         has_grad[L.d.src] = 1;
         break;
       case SPK_OP_GAVGPOOL:
@@ -472,19 +482,19 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
 
 extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
   if (!m || !opt) return tfail(SPK_ERR_ARG, "optim_step: bad arguments");
-  if (opt->kind != SPK_OPT_SGD && opt->kind != SPK_OPT_ADAM)
-    return tfail(SPK_ERR_UNSUPPORTED, "optimizer kind not supported (SGD, Adam)");
+  if (opt->kind < SPK_OPT_SGD || opt->kind > SPK_OPT_ADADELTA)
+    return tfail(SPK_ERR_UNSUPPORTED, "optimizer kind not supported (SGD, Adam, AdamW, RMSprop, Adagrad, Adamax, NAdam, RAdam, Adadelta)");
   if (!m->train) return tfail(SPK_ERR_STATE, "optim_step before any training step");
   HIP_TRY(hipSetDevice(m->device));
   TrainState* t = m->train;
   const float gscale = opt->grad_scale == 0.f ? 1.f : opt->grad_scale;
+  const double b1 = opt->beta1, b2 = opt->beta2;
   OptTable tab;
   tab.count = 0;
   auto flush = [&]() -> int {
     if (tab.count == 0) return 0;
-    const int r = spk_launch_opt_multi(opt->kind == SPK_OPT_ADAM, m->pbuf, t->gbuf, t->m1, t->m2, tab,
-                                       opt->beta1, opt->beta2, opt->eps, opt->weight_decay, opt->momentum,
-                                       gscale, m->stream);
+    const int r = spk_launch_opt_multi(opt->kind, m->pbuf, t->gbuf, t->m1, t->m2, tab, opt->beta1, opt->beta2,
+                                       opt->eps, opt->weight_decay, opt->momentum, gscale, opt->alpha, m->stream);
     tab.count = 0;
     return r;
   };
@@ -495,9 +505,31 @@ extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
     e.off = p.off;
     e.n = (unsigned)p.numel;
     e.lr = opt->lr[p.group];
-    e.bc1 = (float)(1.0 - std::pow((double)opt->beta1, (double)p.step));
-    e.bc2s = (float)std::sqrt(1.0 - std::pow((double)opt->beta2, (double)p.step));
+    const double bc1 = 1.0 - std::pow(b1, (double)p.step), bc2 = 1.0 - std::pow(b2, (double)p.step);
+    e.bc1 = (float)bc1;
+    e.bc2s = (float)std::sqrt(bc2);
     e.first = p.step == 1;
+    e.c0 = e.c1 = 0.f;
+    if (opt->kind == SPK_OPT_ADAGRAD) {
+      e.c0 = (float)((double)e.lr / (1.0 + (double)(p.step - 1) * opt->lr_decay));
+      e.c1 = opt->initial_accumulator_value;
+    } else if (opt->kind == SPK_OPT_NADAM) {
+      // torch.optim.NAdam: mu_t = beta1 (1 - 0.5 * 0.96^(t * momentum_decay))
+      const double md = opt->momentum_decay;
+      const double mu = b1 * (1.0 - 0.5 * std::pow(0.96, (double)p.step * md));
+      const double mu_next = b1 * (1.0 - 0.5 * std::pow(0.96, (double)(p.step + 1) * md));
+      p.mu_product *= mu;
+      e.c0 = (float)((double)e.lr * (1.0 - mu) / (1.0 - p.mu_product));
+      e.c1 = (float)((double)e.lr * mu_next / (1.0 - p.mu_product * mu_next));
+    } else if (opt->kind == SPK_OPT_RADAM) {
+      const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+      const double rho_t = rho_inf - 2.0 * (double)p.step * std::pow(b2, (double)p.step) / bc2;
+      if (rho_t > 5.0) {
+        const double rect = std::sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+        e.c0 = (float)((double)e.lr * rect * std::sqrt(bc2));
+        e.c1 = 1.f;
+      }
+    }
     if (tab.count == 64) K_TRY(flush(), "optimizer");
   }
   K_TRY(flush(), "optimizer");

@@ -446,6 +446,112 @@ __global__ void adam_multi_kernel(float* __restrict__ p, const float* __restrict
   }
 }
 
+// The other first-order torch.optim classes (reference: `getattr(optim, name)(groups)` with torch's default
+// hyper-parameters, sykepic/train/train.py:131-138), one tensor of the flat buffers per blockIdx.y.  The per-tensor
+// scalars that depend on the step count come precomputed in the table entry (bc1, bc2s, c0, c1).
+//   2 AdamW     p *= 1 - lr*wd;  then Adam
+//   3 RMSprop   v = a v + (1-a) g^2;  d = g / (sqrt(v) + eps);  momentum: buf = mom*buf + d, d = buf;  p -= lr d
+//   4 Adagrad   v (+)= g^2 (first: init + g^2);  p -= c0 * g / (sqrt(v) + eps)              c0 = lr / (1 + (t-1) lr_decay)
+//   5 Adamax    m = b1 m + (1-b1) g;  u = max(b2 u, |g| + eps);  p -= (lr / bc1) m / u
+//   6 NAdam     m, v as Adam;  den = sqrt(v)/bc2s + eps;  p -= c0 g/den + c1 m/den   c0 = lr(1-mu_t)/(1-prod), c1 = lr mu_next/(1-prod mu_next)
+//   7 RAdam     m, v as Adam;  c1 > 0 (rho_t > 5): p -= (m/bc1) c0 / (sqrt(v) + eps), c0 = lr rect sqrt(bc2);  else p -= lr m/bc1
+//   8 Adadelta  sq = rho sq + (1-rho) g^2;  d = sqrt(acc + eps)/sqrt(sq + eps) g;  acc = rho acc + (1-rho) d^2;  p -= lr d
+__global__ void opt_generic_kernel(int kind, float* __restrict__ p, const float* __restrict__ g,
+                                   float* __restrict__ m, float* __restrict__ v, OptTable t, float b1, float b2,
+                                   float eps, float wd, float momentum, float gscale, float alpha) {
+  const OptEntry e = t.e[blockIdx.y];
+  float* pp = p + e.off;
+  const float* gg = g + e.off;
+  float* mm = m + e.off;
+  float* vv = v + e.off;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < e.n; i += gridDim.x * blockDim.x) {
+    float pi = pp[i];
+    float gi = gg[i] * gscale;
+    if (kind == 2) pi *= 1.f - e.lr * wd;
+    else gi += wd * pi;
+    switch (kind) {
+      case 2: {
+        const float mi = b1 * mm[i] + (1.f - b1) * gi, vi = b2 * vv[i] + (1.f - b2) * gi * gi;
+        mm[i] = mi; vv[i] = vi;
+        pi -= (e.lr / e.bc1) * mi / (sqrtf(vi) / e.bc2s + eps);
+        break;
+      }
+      case 3: {
+        const float vi = alpha * vv[i] + (1.f - alpha) * gi * gi;
+        vv[i] = vi;
+        float d = gi / (sqrtf(vi) + eps);
+        if (momentum > 0.f) { d = (e.first ? 0.f : momentum * mm[i]) + d; mm[i] = d; }
+        pi -= e.lr * d;
+        break;
+      }
+      case 4: {
+        const float vi = (e.first ? e.c1 : vv[i]) + gi * gi;
+        vv[i] = vi;
+        pi -= e.c0 * gi / (sqrtf(vi) + eps);
+        break;
+      }
+      case 5: {
+        const float mi = b1 * mm[i] + (1.f - b1) * gi;
+        const float ui = fmaxf(b2 * vv[i], fabsf(gi) + eps);
+        mm[i] = mi; vv[i] = ui;
+        pi -= (e.lr / e.bc1) * mi / ui;
+        break;
+      }
+      case 6: {
+        const float mi = b1 * mm[i] + (1.f - b1) * gi, vi = b2 * vv[i] + (1.f - b2) * gi * gi;
+        mm[i] = mi; vv[i] = vi;
+        const float den = sqrtf(vi) / e.bc2s + eps;
+        pi -= e.c0 * gi / den;
+        pi -= e.c1 * mi / den;
+        break;
+      }
+      case 7: {
+        const float mi = b1 * mm[i] + (1.f - b1) * gi, vi = b2 * vv[i] + (1.f - b2) * gi * gi;
+        mm[i] = mi; vv[i] = vi;
+        const float mh = mi / e.bc1;
+        pi -= e.c1 > 0.f ? mh * e.c0 / (sqrtf(vi) + eps) : mh * e.lr;
+        break;
+      }
+      default: {  // 8 Adadelta: mm = square_avg, vv = acc_delta
+        const float sq = alpha * mm[i] + (1.f - alpha) * gi * gi;
+        const float acc = vv[i];
+        const float d = sqrtf(acc + eps) / sqrtf(sq + eps) * gi;
+        mm[i] = sq;
+        vv[i] = alpha * acc + (1.f - alpha) * d * d;
+        pi -= e.lr * d;
+        break;
+      }
+    }
+    pp[i] = pi;
+  }
+}
+
+// ---- Dropout(p) in the head (reference network.py:59-61), train mode: y = x * keep / (1 - p) ----
+// keep ~ Bernoulli(1 - p) from a counter hash of (seed, element index): reproducible for a given seed
+// (spk_model_set_seed) and step, independent of the launch geometry.  torch draws from its own generator, so the
+// masks differ from a torch run element by element (as they do between two torch runs with different seeds).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__global__ void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                   unsigned char* __restrict__ mask, size_t n, float p, unsigned long long seed) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float u = (float)(mix64(seed + 0x9E3779B97F4A7C15ull * (i + 1)) >> 40) * (1.0f / 16777216.0f);  // [0, 1)
+    const bool keep = u >= p;
+    mask[i] = keep ? 1 : 0;
+    y[i] = keep ? x[i] * scale : 0.f;
+  }
+}
+__global__ void dropout_bwd_kernel(const float* __restrict__ gy, const unsigned char* __restrict__ mask,
+                                   float* __restrict__ gx, size_t n, float p) {
+  const float scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    gx[i] = mask[i] ? gy[i] * scale : 0.f;
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   if (g > 256 * 8 * 4) g = 256 * 8 * 4;
@@ -534,6 +640,17 @@ int spk_launch_gavgpool_bwd(const float* gy, bf16_t* gx, int n, int hw, int c, h
   return LAUNCH_OK();
 }
 
+int spk_launch_dropout_fwd(const float* x, float* y, unsigned char* mask, size_t n, float p, unsigned long long seed,
+                           hipStream_t s) {
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, y, mask, n, p, seed);
+  return LAUNCH_OK();
+}
+
+int spk_launch_dropout_bwd(const float* gy, const unsigned char* mask, float* gx, size_t n, float p, hipStream_t s) {
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, gy, mask, gx, n, p);
+  return LAUNCH_OK();
+}
+
 int spk_launch_colsum(const float* dy, float* db, int n, int c, hipStream_t s) {
   hipLaunchKernelGGL(colsum_kernel, dim3((c + 63) / 64), dim3(64), 0, s, dy, db, n, c);
   return LAUNCH_OK();
@@ -558,15 +675,18 @@ int spk_launch_pack_dgrad(const float* w, bf16_t* out, int cout, int taps, int c
   return LAUNCH_OK();
 }
 
-int spk_launch_opt_multi(int adam, float* p, const float* g, float* m, float* v, const OptTable& t,
-                         float b1, float b2, float eps, float wd, float momentum, float gscale,
+int spk_launch_opt_multi(int kind, float* p, const float* g, float* m, float* v, const OptTable& t,
+                         float b1, float b2, float eps, float wd, float momentum, float gscale, float alpha,
                          hipStream_t s) {
   if (t.count <= 0) return 0;
   dim3 grid(96, t.count);
-  if (adam)
+  if (kind == 1)
     hipLaunchKernelGGL(adam_multi_kernel, grid, dim3(256), 0, s, p, g, m, v, t, b1, b2, eps, wd, gscale);
-  else
+  else if (kind == 0)
     hipLaunchKernelGGL(sgd_multi_kernel, grid, dim3(256), 0, s, p, g, m, t, wd, momentum, gscale);
+  else
+    hipLaunchKernelGGL(opt_generic_kernel, grid, dim3(256), 0, s, kind, p, g, m, v, t, b1, b2, eps, wd, momentum,
+                       gscale, alpha);
   return LAUNCH_OK();
 }
 

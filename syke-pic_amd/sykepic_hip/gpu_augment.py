@@ -59,17 +59,14 @@ def draw_ops(transform, dims):
                     op.i0, op.i1 = 0, random.randint(-limit, limit)
             elif isinstance(t, P.Zoom):
                 f = round(random.uniform(*t.zoom_range), 2)
-                op.kind, op.i0 = lib.AUG_ZOOM, int(round(tw * f))
+                op.kind, op.i0 = lib.AUG_ZOOM, int(np.rint(tw * f))
+                op.d[0] = f
             elif isinstance(t, P.Rotate):
                 angle = random.randint(-t.max_angle, t.max_angle)
-                a = math.radians(angle)
-                ca, sa = math.cos(a), math.sin(a)
-                cx, cy = tw // 2, th // 2
-                fwd = np.array([[ca, sa, (1 - ca) * cx - sa * cy], [-sa, ca, sa * cx + (1 - ca) * cy], [0, 0, 1]])
-                minv = np.linalg.inv(fwd)[:2]
+                minv = P.invert_affine(P.rotation_matrix_2d((tw // 2, th // 2), angle, 1.0))
                 op.kind = lib.AUG_ROTATE
                 for k in range(6):
-                    op.d[k] = float(minv[k // 3, k % 3])
+                    op.d[k] = minv[k]
             elif isinstance(t, P.ChangeBrightness):
                 op.kind = lib.AUG_BRIGHT
                 op.d[0] = random.uniform(*t.brightness_range)

@@ -25,7 +25,8 @@ class OptimDesc(C.Structure):
     _fields_ = [
         ("kind", C.c_int32), ("lr", C.c_float * 3), ("beta1", C.c_float), ("beta2", C.c_float),
         ("eps", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float),
-        ("grad_scale", C.c_float),
+        ("grad_scale", C.c_float), ("alpha", C.c_float), ("momentum_decay", C.c_float),
+        ("lr_decay", C.c_float), ("initial_accumulator_value", C.c_float),
     ]
 
 
@@ -47,7 +48,7 @@ class LayerTime(C.Structure):
 
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8 = 0, 1, 2
-OPT_SGD, OPT_ADAM = 0, 1
+OPT_SGD, OPT_ADAM, OPT_ADAMW, OPT_RMSPROP, OPT_ADAGRAD, OPT_ADAMAX, OPT_NADAM, OPT_RADAM, OPT_ADADELTA = range(9)
 
 # every symbol include/sykepic_hip.h declares: (restype, argtypes)
 _P = C.c_void_p

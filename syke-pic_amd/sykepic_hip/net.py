@@ -232,6 +232,11 @@ class HipNet:
         lib.check(self._lib.spk_model_set_precision(self._h, int(split_weights), int(bool(precise_residual))))
         return self
 
+    def set_seed(self, seed):
+        """Seed of the Dropout masks drawn by training steps (reproducible runs)."""
+        lib.check(self._lib.spk_model_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))
+        return self
+
     def conv_ops(self):
         """[(op index, conv name)] of the graph's convolutions, in execution order."""
         return [(i, op.name) for i, op in enumerate(self.graph.ops) if op.kind == arch.OP_CONV]

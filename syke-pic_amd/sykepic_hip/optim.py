@@ -7,16 +7,29 @@ itself is one fused multi-tensor kernel launch inside ``libsykepic_hip.so``.
 
 from . import lib
 
+# torch.optim's own defaults: the reference constructs `getattr(optim, name)(groups)` with nothing but `lr`
+# (sykepic/train/train.py:131-138), so these are the hyper-parameters a reference run uses.
 _DEFAULTS = {
     "SGD": dict(momentum=0.0, weight_decay=0.0),
     "Adam": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
+    "AdamW": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01),
+    "RMSprop": dict(alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0),
+    "Adagrad": dict(lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10),
+    "Adamax": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
+    "NAdam": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, momentum_decay=4e-3),
+    "RAdam": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
+    "Adadelta": dict(rho=0.9, eps=1e-6, weight_decay=0.0),
 }
+_KINDS = {"SGD": lib.OPT_SGD, "Adam": lib.OPT_ADAM, "AdamW": lib.OPT_ADAMW, "RMSprop": lib.OPT_RMSPROP,
+          "Adagrad": lib.OPT_ADAGRAD, "Adamax": lib.OPT_ADAMAX, "NAdam": lib.OPT_NADAM, "RAdam": lib.OPT_RADAM,
+          "Adadelta": lib.OPT_ADADELTA}
 
 
 class HipOptimizer:
     def __init__(self, net, name, param_groups, **kw):
         if name not in _DEFAULTS:
-            raise ValueError(f"optimizer {name!r} has no MI355X kernel yet (supported: {sorted(_DEFAULTS)})")
+            raise ValueError(f"optimizer {name!r} has no MI355X kernel (supported: {sorted(_DEFAULTS)}; LBFGS needs a "
+                             "closure the reference's loop does not pass, ASGD / Rprop / SparseAdam are not built)")
         self.net, self.name = net, name
         self.defaults = dict(_DEFAULTS[name])
         self.defaults.update(kw)
@@ -47,7 +60,7 @@ class HipOptimizer:
 
     def step(self):
         d = lib.OptimDesc()
-        d.kind = lib.OPT_ADAM if self.name == "Adam" else lib.OPT_SGD
+        d.kind = _KINDS[self.name]
         for i in range(3):
             d.lr[i] = float(self.param_groups[i]["lr"])
         b1, b2 = self.defaults.get("betas", (0.9, 0.999))
@@ -56,6 +69,10 @@ class HipOptimizer:
         d.weight_decay = float(self.defaults.get("weight_decay", 0.0))
         d.momentum = float(self.defaults.get("momentum", 0.0))
         d.grad_scale = float(self.grad_scale)
+        d.alpha = float(self.defaults.get("alpha", self.defaults.get("rho", 0.99)))
+        d.momentum_decay = float(self.defaults.get("momentum_decay", 4e-3))
+        d.lr_decay = float(self.defaults.get("lr_decay", 0.0))
+        d.initial_accumulator_value = float(self.defaults.get("initial_accumulator_value", 0.0))
         self.net.optim_step(d)
 
     def __repr__(self):

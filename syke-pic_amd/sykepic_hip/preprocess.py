@@ -6,11 +6,19 @@ Host-side mirror of the reference's ``Compose``/``Resize``/... in
 ``sykepic/train/image.py`` (``Compose.__call__`` :25-56, ``get_new_dims``
 :183, ``resize_with_border`` :201, ``mode_pixel_value`` :229) and of
 ``ToTensor``/``Normalize`` (``sykepic/train/config.py:52-56``).  The reference
-delegates the pixel work to OpenCV, which is not available in this image; the
-resize below restates OpenCV's published 8-bit INTER_LINEAR algorithm
-(11-bit fixed-point coefficients, the same rounding), the warps use plain
-bilinear sampling.  Augmentations draw from Python's global ``random`` in the
-same order as the reference so a seeded run makes the same decisions.
+delegates the pixel work to OpenCV (pinned opencv-python-headless 4.5.5.64,
+requirements/cpu.txt:146), which cannot be imported in this image (not
+installed, no network): the functions below restate OpenCV 4.5.5's published
+8-bit algorithms step by step, citing the OpenCV source they follow —
+``cv::resize`` INTER_LINEAR (modules/imgproc/src/resize.cpp: float32 source
+coordinates, 11-bit fixed-point coefficients, the (b*(S>>4))>>16 vertical
+pass, the exact-2x INTER_AREA shortcut) and ``cv::warpAffine`` INTER_LINEAR
+(modules/imgproc/src/imgwarp.cpp: matrix inversion, 10-bit fixed-point
+coordinates rounded to 1/32 pixel, ``remap`` with the 32x32 table of 15-bit
+bilinear weights, constant border taken tap by tap).  Parity with a real cv2
+is therefore by construction from the published source, not by a run.
+Augmentations draw from Python's global ``random`` in the same order as the
+reference so a seeded run makes the same decisions.
 """
 
 import math
@@ -36,39 +44,75 @@ def get_new_dims(h, w, target_h, target_w):
     return int(h * (target_w / float(w))), target_w
 
 
-def _coeffs(src, dst):
-    """OpenCV resizeLinear index/weight tables for one axis (8-bit path)."""
-    scale = src / float(dst)
+INTER_RESIZE_COEF_SCALE = 2048      # 1 << INTER_RESIZE_COEF_BITS (11), resize.cpp
+
+
+def _src_coords(src, dst, scale):
+    """resize.cpp, cv::resize (linear branch): ``fx = (float)((dx+0.5)*scale_x - 0.5); sx = cvFloor(fx); fx -= sx``
+    with scale_x a double and fx a FLOAT.  scale = 1/inv_scale, inv_scale = (double)dst/src when dsize is given
+    (hal::resize: ``double scale_x = 1./inv_scale_x``) or the caller's fx when dsize is empty."""
+    if scale is None:
+        scale = 1.0 / (float(dst) / float(src))
     d = np.arange(dst, dtype=np.float64)
-    f = (d + 0.5) * scale - 0.5
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
     s = np.floor(f).astype(np.int64)
-    f = f - s
+    return s, (f - s.astype(np.float32)).astype(np.float32)
+
+
+def _weights(f):
+    """``cbuf[0] = 1.f - fx; cbuf[1] = fx; ialpha = saturate_cast<short>(cbuf[k]*INTER_RESIZE_COEF_SCALE)``:
+    float32 arithmetic, cvRound (round half to even)."""
+    one, sc = np.float32(1.0), np.float32(INTER_RESIZE_COEF_SCALE)
+    a0 = np.rint((one - f) * sc).astype(np.int64)
+    a1 = np.rint(f * sc).astype(np.int64)
+    return np.clip(a0, -32768, 32767), np.clip(a1, -32768, 32767)
+
+
+def _coeffs_x(src, dst, scale=None):
+    """Horizontal tables.  ``if (sx < 0) fx = 0, sx = 0;  if (sx >= ssize.width-1) fx = 0, sx = ssize.width-1``
+    (resize.cpp; HResizeLinear then reads S[sx] and S[sx+cn], the latter with weight 0 at the right edge)."""
+    s, f = _src_coords(src, dst, scale)
     lo = s < 0
     f[lo], s[lo] = 0.0, 0
     hi = s >= src - 1
     f[hi], s[hi] = 0.0, src - 1
-    a1 = np.rint(f * 2048.0).astype(np.int64)
-    a0 = np.rint((1.0 - f) * 2048.0).astype(np.int64)
+    a0, a1 = _weights(f)
     return s, np.minimum(s + 1, src - 1), a0, a1
 
 
-def resize_linear_u8(img, new_w, new_h):
-    """cv2.resize(img, (new_w, new_h), interpolation=INTER_LINEAR) for uint8."""
+def _coeffs_y(src, dst, scale=None):
+    """Vertical tables: the weights stay as computed, only the two source rows are clamped
+    (resizeGeneric_Invoker: ``sy = clip(sy0 - ksize2 + 1 + k, 0, ssize.height)``)."""
+    s, f = _src_coords(src, dst, scale)
+    a0, a1 = _weights(f)
+    return np.clip(s, 0, src - 1), np.clip(s + 1, 0, src - 1), a0, a1
+
+
+def resize_linear_u8(img, new_w, new_h, scale_x=None, scale_y=None):
+    """cv2.resize(img, (new_w, new_h), interpolation=INTER_LINEAR) for uint8 (OpenCV 4.5.5 resize.cpp).
+    scale_x / scale_y: 1/fx, 1/fy when the reference calls ``cv2.resize(img, None, fx=, fy=)`` (the scale is then
+    the caller's, not src/dst)."""
     h, w = img.shape[:2]
-    if (h, w) == (new_h, new_w):
-        return img.copy()
     new_w, new_h = max(int(new_w), 1), max(int(new_h), 1)
+    sx = (1.0 / (float(new_w) / float(w))) if scale_x is None else float(scale_x)
+    sy = (1.0 / (float(new_h) / float(h))) if scale_y is None else float(scale_y)
+    if (h, w) == (new_h, new_w) and sx == 1.0 and sy == 1.0:
+        return img.copy()
     src = img.astype(np.int64)
     if src.ndim == 2:
         src = src[:, :, None]
-    if w == 2 * new_w and h == 2 * new_h:
-        # OpenCV switches exact 2x down-scaling to its INTER_AREA fast path
-        out = (src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2
+    if sx == 2.0 and sy == 2.0:
+        # "if (interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation =
+        # INTER_AREA": resizeAreaFast, 2x2 boxes, (sum + 2) >> 2
+        ys, xs = 2 * np.arange(new_h), 2 * np.arange(new_w)
+        y1, x1 = np.minimum(ys + 1, h - 1), np.minimum(xs + 1, w - 1)
+        out = (src[ys][:, xs] + src[ys][:, x1] + src[y1][:, xs] + src[y1][:, x1] + 2) >> 2
     else:
-        x0, x1, ax0, ax1 = _coeffs(w, new_w)
-        y0, y1, ay0, ay1 = _coeffs(h, new_h)
-        rows = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]  # x2048
+        x0, x1, ax0, ax1 = _coeffs_x(w, new_w, sx)
+        y0, y1, ay0, ay1 = _coeffs_y(h, new_h, sy)
+        rows = src[:, x0] * ax0[None, :, None] + src[:, x1] * ax1[None, :, None]  # HResizeLinear: x2048, int
         r0, r1 = rows[y0], rows[y1]
+        # VResizeLinear<uchar,int,short>: ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2
         out = (((ay0[:, None, None] * (r0 >> 4)) >> 16) + ((ay1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
     out = np.clip(out, 0, 255).astype(np.uint8)
     return out[:, :, 0] if img.ndim == 2 else out
@@ -93,25 +137,85 @@ def pad_constant(img, top, bot, left, right, border):
     return out
 
 
-def _warp_affine(img, minv, border):
-    """dst(x,y) = bilinear src at minv @ (x,y,1); constant border."""
+INTER_BITS, INTER_TAB_SIZE = 5, 32           # imgproc.hpp
+AB_BITS, AB_SCALE = 10, 1024                 # imgwarp.cpp: AB_BITS = MAX(10, INTER_BITS)
+INTER_REMAP_COEF_BITS = 15
+
+
+def bilinear_tab_i():
+    """imgwarp.cpp initInterTab2D(INTER_LINEAR, fixpt): BilinearTab_i[fy*32 + fx] = the four 15-bit weights
+    saturate_cast<short>(vy*vx*32768) of taps (0,0) (0,1) (1,0) (1,1).  Every product is a multiple of 32, so the
+    weights sum to 32768 exactly — except entry (0,0), whose 32768 saturates to 32767: the `isum != SCALE` repair
+    then adds the missing 1 to element [1][1] (for ksize 2 its search window k1,k2 in {1,2} only finds zeros)."""
+    fy, fx = np.mgrid[0:INTER_TAB_SIZE, 0:INTER_TAB_SIZE]
+    t = np.stack([(32 - fy) * (32 - fx), (32 - fy) * fx, fy * (32 - fx), fy * fx], -1).astype(np.int64) * 32
+    t = t.reshape(INTER_TAB_SIZE * INTER_TAB_SIZE, 4)
+    t[0] = (32767, 0, 0, 1)
+    return t
+
+
+_BILINEAR_TAB = bilinear_tab_i()
+
+
+def invert_affine(m):
+    """cv::warpAffine without WARP_INVERSE_MAP (imgwarp.cpp): the 2x3 forward matrix, as doubles, inverted with
+    exactly these operations."""
+    M = [float(v) for v in np.asarray(m, dtype=np.float64).reshape(6)]
+    D = M[0] * M[4] - M[1] * M[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[4] * D, M[0] * D
+    M[0] = A11
+    M[1] *= -D
+    M[3] *= -D
+    M[4] = A22
+    b1 = -M[0] * M[2] - M[1] * M[5]
+    b2 = -M[3] * M[2] - M[4] * M[5]
+    M[2], M[5] = b1, b2
+    return M
+
+
+def warp_affine_u8(img, m_forward, border):
+    """cv2.warpAffine(img, M, (w, h), borderValue=border): INTER_LINEAR, BORDER_CONSTANT, uint8 (OpenCV 4.5.5
+    imgwarp.cpp: WarpAffineInvoker + remapBilinear<FixedPtCast<int, uchar, 15>>).
+      adelta[x] = saturate_cast<int>(M[0]*x*AB_SCALE), bdelta[x] = saturate_cast<int>(M[3]*x*AB_SCALE)
+      X0 = saturate_cast<int>((M[1]*y + M[2])*AB_SCALE) + round_delta, round_delta = AB_SCALE/INTER_TAB_SIZE/2 = 16
+      X = (X0 + adelta[x]) >> (AB_BITS - INTER_BITS);  sx = X >> INTER_BITS;  fx = X & 31   (likewise Y)
+      dst = (sum of 4 taps * BilinearTab_i[fy*32 + fx] + (1 << 14)) >> 15, a tap outside the image = borderValue
+    (saturate_cast<int> of a double = cvRound: round half to even)."""
     h, w = img.shape[:2]
     c = img.shape[2]
-    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
-    sx = minv[0, 0] * xs + minv[0, 1] * ys + minv[0, 2]
-    sy = minv[1, 0] * xs + minv[1, 1] * ys + minv[1, 2]
-    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
-    fx, fy = (sx - x0)[..., None], (sy - y0)[..., None]
-    bv = np.asarray(border[:c], dtype=np.float64)
+    M = invert_affine(m_forward)
+    xs = np.arange(w, dtype=np.float64)
+    ys = np.arange(h, dtype=np.float64)
+    adelta = np.rint(M[0] * xs * AB_SCALE).astype(np.int64)
+    bdelta = np.rint(M[3] * xs * AB_SCALE).astype(np.int64)
+    round_delta = AB_SCALE // INTER_TAB_SIZE // 2
+    X0 = np.rint((M[1] * ys + M[2]) * AB_SCALE).astype(np.int64) + round_delta
+    Y0 = np.rint((M[4] * ys + M[5]) * AB_SCALE).astype(np.int64) + round_delta
+    X = (X0[:, None] + adelta[None, :]) >> (AB_BITS - INTER_BITS)
+    Y = (Y0[:, None] + bdelta[None, :]) >> (AB_BITS - INTER_BITS)
+    sx = np.clip(X >> INTER_BITS, -32768, 32767)      # saturate_cast<short>
+    sy = np.clip(Y >> INTER_BITS, -32768, 32767)
+    wt = _BILINEAR_TAB[(Y & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (X & (INTER_TAB_SIZE - 1))]   # [h, w, 4]
+    cval = np.asarray([int(v) for v in border[:c]], dtype=np.int64)
 
     def tap(yy, xx):
         ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
-        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.float64)
-        return np.where(ok[..., None], v, bv)
+        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        return np.where(ok[..., None], v, cval)
 
-    out = (tap(y0, x0) * (1 - fx) * (1 - fy) + tap(y0, x0 + 1) * fx * (1 - fy)
-           + tap(y0 + 1, x0) * (1 - fx) * fy + tap(y0 + 1, x0 + 1) * fx * fy)
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    acc = (tap(sy, sx) * wt[..., 0:1] + tap(sy, sx + 1) * wt[..., 1:2]
+           + tap(sy + 1, sx) * wt[..., 2:3] + tap(sy + 1, sx + 1) * wt[..., 3:4])
+    out = (acc + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def rotation_matrix_2d(center, angle, scale=1.0):
+    """cv2.getRotationMatrix2D (imgwarp.cpp): angle in degrees, positive = counter-clockwise."""
+    a = angle * (math.pi / 180.0)
+    alpha, beta = math.cos(a) * scale, math.sin(a) * scale
+    cx, cy = float(np.float32(center[0])), float(np.float32(center[1]))    # Point2f
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]])
 
 
 class Resize:
@@ -142,8 +246,8 @@ class Translate:
             y = random.randint(-limit, limit)
         if width:
             x = random.randint(-limit, limit)
-        minv = np.array([[1.0, 0.0, -x], [0.0, 1.0, -y]])
-        return _warp_affine(img, minv, border)
+        # M = np.float32([[1, 0, x], [0, 1, y]]); cv2.warpAffine(img, M, (w, h), borderValue=border)  (image.py:110-111)
+        return warp_affine_u8(img, np.float32([[1, 0, x], [0, 1, y]]), border)
 
     def __repr__(self):
         return "Translate()"
@@ -159,8 +263,10 @@ class Zoom:
     def __call__(self, img, border):
         f = round(random.uniform(*self.zoom_range), 2)
         h, w = img.shape[:2]
-        zw, zh = int(round(w * f)), int(round(h * f))  # cv2.resize(fx,fy): dsize = round(src*f)
-        img = resize_linear_u8(img, zw, zh)
+        # cv2.resize(img, None, fx=f, fy=f): dsize = saturate_cast<int>(src*f) (round half to even), and the
+        # source coordinates use scale = 1/f, not src/dst (resize.cpp)
+        zw, zh = int(np.rint(w * f)), int(np.rint(h * f))
+        img = resize_linear_u8(img, zw, zh, 1.0 / f, 1.0 / f)
         if f < 1:
             p1 = int((w - zw) / 2)
             p2 = w - zw - p1
@@ -182,12 +288,8 @@ class Rotate:
         h, w = img.shape[:2]
         cx, cy = w // 2, h // 2
         angle = random.randint(-self.max_angle, self.max_angle)
-        a = math.radians(angle)
-        ca, sa = math.cos(a), math.sin(a)
-        # forward map of cv2.getRotationMatrix2D(center, angle, 1): [[ca, sa],[-sa, ca]]
-        fwd = np.array([[ca, sa, (1 - ca) * cx - sa * cy], [-sa, ca, sa * cx + (1 - ca) * cy]])
-        full = np.vstack([fwd, [0, 0, 1]])
-        return _warp_affine(img, np.linalg.inv(full)[:2], border)
+        # M = cv2.getRotationMatrix2D(center, angle, 1.0); cv2.warpAffine(img, M, (w, h), borderValue=border)
+        return warp_affine_u8(img, rotation_matrix_2d((cx, cy), angle, 1.0), border)
 
     def __repr__(self):
         return f"Rotate(max_angle={self.max_angle})"

@@ -37,5 +37,5 @@ def test_error_reporting_without_gpu_or_bad_args():
 
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(lib.LayerDesc) == 11 * 4 + 4 + 96 + 96
-    assert ctypes.sizeof(lib.OptimDesc) == 4 + 12 + 12 + 4 + 4 + 4
+    assert ctypes.sizeof(lib.OptimDesc) == 4 + 12 + 12 + 4 + 4 + 4 + 16
     assert ctypes.sizeof(lib.LayerTime) == 96 + 4 + 4 + 8 + 8  # 4 B padding before the doubles

@@ -290,11 +290,14 @@ def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
     assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == gold["group_sizes"].tolist()
 
 
-def test_optimizers_match_torch_update_rule():
-    """One tensor-level check of the fused Adam / SGD kernels: after a step
-    every updated parameter equals torch.optim's result on the HIP gradients."""
+@pytest.mark.parametrize("name", ["SGD", "Adam", "AdamW", "RMSprop", "Adagrad", "Adamax", "NAdam", "RAdam", "Adadelta"])
+def test_optimizers_match_torch_update_rule(name):
+    """The reference builds `getattr(optim, name)(groups)` with nothing but `lr` (train.py:131-138): every
+    first-order torch.optim class with its torch defaults has a fused multi-tensor kernel.  After each of 3 steps
+    every updated parameter equals torch.optim's result on the same (HIP) gradients (RAdam runs 7 steps: its
+    rho_t > 5 switch to the rectified update happens at step 6)."""
     classes, n, hw = 10, 8, 64
-    for name in ("SGD", "Adam"):
+    for name in (name,):
         g, specs, ref, net = _pair("resnet18", classes, seed=7)
         x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10)).cuda()
         y = torch.from_numpy(synth.synth_labels(n, classes, seed=11)).cuda()
@@ -304,7 +307,7 @@ def test_optimizers_match_torch_update_rule():
         before = net.state_dict()
         tparams = {p.key: torch.nn.Parameter(before[p.key].clone()) for p in params}
         topt = getattr(torch.optim, name)(list(tparams.values()), lr=0.01)
-        for step in range(2):
+        for step in range(7 if name == "RAdam" else 3):   # RAdam: rho_t > 5 from step 6 on (rectified branch)
             net.forward_backward(x, y)
             for p in params:
                 tparams[p.key].grad = net._read_grad(p.key, p.shape)
@@ -316,6 +319,61 @@ def test_optimizers_match_torch_update_rule():
             # keep the two trajectories on identical parameters
             for k, tp in tparams.items():
                 tp.data.copy_(after[k])
+
+
+def test_head_dropout_trains():
+    """`[model] dropout = 1,0.5` (reference network.py:59-61): nn.Dropout between the head's Linear layers, active
+    in train mode, identity in eval mode.  The kept set comes from the library's own counter-based generator
+    (seeded: spk_model_set_seed); checked: kept fraction, the 1/(1-p) scale, a fresh mask every step, the same
+    masks for the same seed, eval = identity, and every gradient against the oracle evaluated on the GPU's kept
+    set."""
+    from oracle import graph_eval
+    from sykepic_hip.net import HipNet
+    classes, n, hw, p = 10, 64, 64, 0.5
+    g = arch.build_graph("resnet18", classes, [256, 128], [(1, p)])
+    specs = arch.param_specs(g)
+    sd = synth.synth_state_dict(specs, seed=5, logit_gain=2.0)
+    drop = next(op for op in g.ops if op.kind == arch.OP_DROPOUT)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10))
+    y = torch.from_numpy(synth.synth_labels(n, classes, seed=11))
+
+    def run(seed, steps=1):
+        net = HipNet("resnet18", classes, weights=None, dropout=[(1, p)])
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        net.set_seed(seed)
+        net.train()
+        outs = []
+        for _ in range(steps):
+            net.reset_stats()
+            net.forward_backward(x.cuda(), y.cuda())
+            outs.append((net.read_activation(drop.src, n, (n, 256)), net.read_activation(drop.dst, n, (n, 256))))
+        return net, outs
+
+    net, (first, second) = run(seed=3, steps=2)
+    for a, b in (first, second):
+        keep = b != 0
+        frac = float(keep.float().mean())
+        assert abs(frac - (1 - p)) < 4 * (p * (1 - p) / keep.numel()) ** 0.5 + 0.01, frac
+        assert torch.allclose(b[keep], a[keep] / (1 - p), rtol=1e-6, atol=0)
+    assert not torch.equal(first[1] != 0, second[1] != 0)                     # a new mask every step
+    _, (again,) = run(seed=3)
+    assert torch.equal(again[1] != 0, first[1] != 0)                          # same seed, same first mask
+    _, (other,) = run(seed=4)
+    assert not torch.equal(other[1] != 0, first[1] != 0)
+    # gradients of the second step of `net` on its kept set
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    # (the state moved by no optimizer step: only BN running statistics changed, which train mode does not read)
+    shapes = {t: tuple(v.shape) for t, v in graph_eval.run(g, state, x, train=True).items()}
+    forced = {op.dst: net.read_activation(op.dst, n, shapes[op.dst]) for op in g.ops}
+    exact = graph_eval.train_step_bf16(g, state, x, y, forced=forced, round_grads=False)
+    assert _rel(forced[drop.dst], exact["own"][drop.dst]) < 1e-6
+    for k, v in exact["grads"].items():
+        r = _rel(net._read_grad(k, tuple(v.shape)), v)
+        assert r < (1e-4 if k.startswith("head.") else 3e-2), f"{k}: {r:.3e}"
+    net.eval()
+    z = net(x[:4].cuda())
+    assert torch.equal(net.read_activation(drop.dst, 4, (4, 256)), net.read_activation(drop.src, 4, (4, 256)))
+    assert torch.isfinite(z).all()
 
 
 def test_training_is_bitwise_reproducible():

@@ -98,6 +98,67 @@ def test_preprocess_geometry(golden_dir):
     assert np.array_equal(preprocess.resize_linear_u8(rois[3], 128, 53), rois[3])
 
 
+def test_opencv_resize_restatement_known_answers():
+    """`cv2` cannot be imported here; these answers are worked by hand from OpenCV 4.5.5 resize.cpp (float32
+    source coordinate, zeroed edge coefficients on x, 11-bit weights, the (b*(S>>4))>>16 vertical pass) and are the
+    values cv2.resize(..., INTER_LINEAR) is known to return for them."""
+    r = preprocess.resize_linear_u8
+    assert r(np.array([[0, 200]], np.uint8), 4, 1).tolist() == [[0, 50, 150, 200]]
+    assert r(np.array([[0, 255]], np.uint8), 3, 1).tolist() == [[0, 128, 255]]
+    assert r(np.array([[0], [200]], np.uint8), 1, 4).tolist() == [[0], [50], [150], [200]]     # y: clamped rows
+    ramp = np.arange(0, 64, dtype=np.uint8).reshape(8, 8)
+    half = r(ramp, 4, 4)                                       # exact 2x: INTER_AREA boxes, (sum + 2) >> 2
+    assert half.tolist() == ((ramp[0::2, 0::2].astype(int) + ramp[0::2, 1::2] + ramp[1::2, 0::2] + ramp[1::2, 1::2] + 2) >> 2).tolist()
+    # the source coordinate is rounded to FLOAT before the floor: 3 -> 7 columns, dx = 5: (5.5 * (1/(7/3)) - 0.5)
+    s, f = preprocess._src_coords(3, 7, None)
+    assert s.tolist() == [-1, 0, 0, 1, 1, 1, 2] and f.dtype == np.float32
+    a0, a1 = preprocess._weights(f)
+    assert (a0 + a1).tolist() == [2048] * 7
+    # cv2.resize(img, None, fx=f, fy=f): dsize = cvRound(src * f) and coordinates use 1/f, not src/dst
+    img = (np.arange(180 * 180) % 251).astype(np.uint8).reshape(180, 180)
+    zw = int(np.rint(180 * 1.17))                              # 210.6 -> 211: 1/1.17 = 0.8547 but 180/211 = 0.8531
+    z = r(img, zw, zw, 1 / 1.17, 1 / 1.17)
+    assert z.shape == (211, 211) and not np.array_equal(z, r(img, 211, 211))
+    s17, _ = preprocess._src_coords(180, 211, 1 / 1.17)
+    assert s17[-1] == 179 and preprocess._src_coords(180, 211, None)[0][-1] == 179 and s17[100] == int(np.floor(100.5 / 1.17 - 0.5))
+    odd = r(np.arange(181 * 181, dtype=np.int64).reshape(181, 181).astype(np.uint8), 90, 90, 2.0, 2.0)  # f = 0.5 of an odd size
+    assert odd.shape == (90, 90)
+
+
+def test_opencv_warp_affine_restatement_known_answers():
+    """OpenCV 4.5.5 imgwarp.cpp restated (matrix inversion, 1/32-pixel fixed-point coordinates, 32x32 table of
+    15-bit weights, constant border per tap).  Hand-worked answers: integer shifts and quarter turns are exact
+    copies; a half-pixel shift gives (a + b + 1) >> 1; the weight table sums to 1 << 15 with the (0,0) quirk."""
+    tab = preprocess.bilinear_tab_i()
+    assert tab.shape == (1024, 4) and (tab.sum(1) == 32768).all() and tab[0].tolist() == [32767, 0, 0, 1]
+    assert tab[16].tolist() == [16384, 16384, 0, 0] and tab[32 * 16 + 16].tolist() == [8192] * 4
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    w = preprocess.warp_affine_u8
+    assert np.array_equal(w(img, np.float32([[1, 0, 0], [0, 1, 0]]), (9, 9, 9)), img)
+    sh = w(img, np.float32([[1, 0, 7], [0, 1, -4]]), (9, 8, 7))
+    want = np.empty_like(img)
+    want[:] = (9, 8, 7)
+    want[0:33, 7:53] = img[4:37, 0:46]
+    assert np.array_equal(sh, want)
+    row = np.array([[[10], [20], [31]]], dtype=np.uint8)                       # 1 x 3 x 1
+    assert w(row, np.array([[1, 0, 0.5], [0, 1, 0]]), (100,))[0, :, 0].tolist() == [(100 + 10 + 1) >> 1, 15, 26]
+    sq = rng.integers(0, 256, (41, 41, 3), dtype=np.uint8)
+    for quarter in (1, 2, 3):
+        m = preprocess.rotation_matrix_2d((20, 20), 90 * quarter)
+        assert np.array_equal(w(sq, m, (0, 0, 0)), np.rot90(sq, quarter))
+    m = preprocess.rotation_matrix_2d((90, 90), 17, 1.0)                       # getRotationMatrix2D layout
+    assert np.allclose(m[:, :2], [[np.cos(np.radians(17)), np.sin(np.radians(17))],
+                                  [-np.sin(np.radians(17)), np.cos(np.radians(17))]])
+    assert np.allclose(m @ [90, 90, 1], [90, 90])                              # the centre is the fixed point
+    inv = preprocess.invert_affine(m)
+    assert np.allclose(np.array(inv).reshape(2, 3) @ [90, 90, 1], [90, 90])
+    big = np.repeat(rng.integers(0, 256, (180, 180, 1), dtype=np.uint8), 3, axis=2)
+    out = w(big, m, (200, 200, 200))
+    ref = w(big.astype(np.uint8), m, (200, 200, 200))
+    assert np.array_equal(out, ref) and out.shape == big.shape and (out[0, 0] == 200).all()   # corners leave the image
+
+
 def test_csv_format(tmp_path):
     rows = [(2, [0.5, 0.25, 0.25]), (3, [1 / 3, 1 / 3, 1 / 3])]
     prob.probabilities_to_csv(rows, ["a", "b", "c"], tmp_path / "x" / "s.prob.csv")
