@@ -40,6 +40,8 @@ struct Layer {
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)
+  bool side_branch = false;   // output is only ever a shortcut operand (downsample conv): may run beside the main branch
+  hipEvent_t join = nullptr;  // side branches: recorded on the side stream after the layer
 };
 
 struct TrainState;
@@ -48,6 +50,8 @@ struct spk_model {
   int device = 0;
   int in_chans = 3, num_classes = 0;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;  // second stream for the shortcut (downsample) convs of the eval forward
+  hipEvent_t fork = nullptr;
   std::vector<Layer> layers;
   std::vector<Param> params;
   std::unordered_map<std::string, int> index;

@@ -142,6 +142,17 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     for (const Layer& Q : m->layers)
       if (Q.d.kind == SPK_OP_CONV && Q.d.res == L.d.dst) L.trunk_writer = true;
   }
+  // shortcut convs (ResNet downsample branches): nothing but a later layer's residual add reads their output, so
+  // they are independent of the conv1 -> conv2 chain of their block and may run beside it on a second stream
+  for (Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV) continue;
+    bool as_src = false, as_res = false;
+    for (const Layer& Q : m->layers) {
+      as_src |= Q.d.src == L.d.dst;
+      as_res |= Q.d.kind == SPK_OP_CONV && Q.d.res == L.d.dst;
+    }
+    L.side_branch = as_res && !as_src && L.d.dst != m->layers.back().d.dst;
+  }
   // the 3x3 conv in the middle of a bottleneck: its input comes from a 1x1 conv that is not a trunk writer
   for (Layer& L : m->layers) {
     if (L.d.kind != SPK_OP_CONV || L.d.k != 3 || L.trunk_writer) continue;
@@ -246,6 +257,10 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->wpack) hipFree(m->wpack);
   if (m->scale_bias) hipFree(m->scale_bias);
   if (m->dwpack) hipFree(m->dwpack);
+  if (m->side) hipStreamDestroy(m->side);
+  if (m->fork) hipEventDestroy(m->fork);
+  for (Layer& L : m->layers)
+    if (L.join) hipEventDestroy(L.join);
   spk_train_free(m);
   delete m;
 }
@@ -635,6 +650,44 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
   return fail(SPK_ERR_UNSUPPORTED, "unknown layer kind");
 }
 
+// All layers of one eval forward.  Shortcut convs fork onto the side stream (they only need the block input,
+// which every earlier launch on the main stream has produced) and join before the conv that adds their output:
+// Measured (ResNet-50, batch 256, round 2): 5.40 ms with the fork against 5.30 ms on one stream - the branches
+// already keep several blocks per CU resident and the two grids only contend - so it is OFF unless
+// SPK_SIDE_STREAM=1 asks for it.
+static int run_layers_eval(spk_model* m, int nb) {
+  static const bool two = getenv("SPK_SIDE_STREAM") && atoi(getenv("SPK_SIDE_STREAM")) != 0;
+  bool any = false;
+  for (const Layer& L : m->layers) any |= L.side_branch;
+  if (!two || !any) {
+    for (Layer& L : m->layers) SPK_TRY(spk_run_layer_eval(m, L, nb));
+    return SPK_OK;
+  }
+  if (!m->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
+  }
+  hipStream_t main_s = m->stream;
+  for (Layer& L : m->layers) {
+    if (L.side_branch) {
+      if (!L.join) HIP_TRY(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
+      HIP_TRY(hipEventRecord(m->fork, main_s));
+      HIP_TRY(hipStreamWaitEvent(m->side, m->fork, 0));
+      m->stream = m->side;
+      const int r = spk_run_layer_eval(m, L, nb);
+      m->stream = main_s;
+      if (r != SPK_OK) return r;
+      HIP_TRY(hipEventRecord(L.join, m->side));
+      continue;
+    }
+    if (L.d.kind == SPK_OP_CONV && L.d.res >= 0)
+      for (const Layer& Q : m->layers)
+        if (Q.side_branch && Q.d.dst == L.d.res && Q.join) HIP_TRY(hipStreamWaitEvent(main_s, Q.join, 0));
+    SPK_TRY(spk_run_layer_eval(m, L, nb));
+  }
+  return SPK_OK;
+}
+
 static size_t image_stride_bytes(int c, int h, int w, int dtype) {
   return (size_t)c * h * w * (dtype == SPK_DTYPE_U8 ? 1 : 4);
 }
@@ -654,7 +707,7 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
     const char* xi = (const char*)x + (size_t)i0 * image_stride_bytes(m->in_chans, h, w, dtype);
     if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream))
       return fail(SPK_ERR_HIP, "input conversion launch failed");
-    for (Layer& L : m->layers) SPK_TRY(spk_run_layer_eval(m, L, nb));
+    SPK_TRY(run_layers_eval(m, nb));
     HIP_TRY(hipMemcpyAsync(logits_dev + (size_t)i0 * m->num_classes, m->T(last),
                            (size_t)nb * m->num_classes * 4, hipMemcpyDeviceToDevice, m->stream));
   }
