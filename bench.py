@@ -46,12 +46,13 @@ def parse():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=50)
     ap.add_argument("--mode", default="both", choices=["both", "infer", "train"])
-    ap.add_argument("--precision", default="mixed", choices=["mixed", "precise", "balanced", "fast", "bf16"],
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "precise", "balanced", "fast", "bf16", "fp8"],
                     help="mixed (library default): fp16 + hi/lo split weights on every conv except the 3x3 convs "
                          "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tests/diagnostics/split_rules.py: "
                          "passes the 1e-3 parity tolerance); precise: split on every conv (5.9e-4); balanced: split "
                          "only the layers that write the residual trunk (1.3e-3 worst case); fast: plain fp16 "
-                         "(1.5e-3); bf16 (5e-3)")
+                         "(1.5e-3); bf16 (5e-3); fp8: e4m3 inside the EfficientNet MBConv blocks (BASELINE config 5; "
+                         "EfficientNets only, not a parity mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
@@ -162,7 +163,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
 
         def step():
             return net.probabilities(x)
-        dtype = "bf16" if args.precision == "bf16" else "f16"
+        dtype = "bf16" if args.precision == "bf16" else ("fp8" if args.precision == "fp8" else "f16")
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -320,7 +321,12 @@ def main():
     sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
     net = HipNet(args.network, args.classes, weights=None, device=dev)
     net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
-    if args.precision == "bf16":
+    if args.precision == "fp8":
+        if not args.network.startswith("efficientnet"):
+            print("[bench] --precision fp8 is the EfficientNet mode (BASELINE config 5)", file=sys.stderr)
+            sys.exit(2)
+        net.set_precision(split_weights=3)
+    elif args.precision == "bf16":
         net.set_precision(split_weights=False, bf16=True)
     else:
         net.set_precision(split_weights={"mixed": 3, "precise": 1, "balanced": 2, "fast": 0}[args.precision])
@@ -333,6 +339,9 @@ def main():
     x = torch.from_numpy(synth.synth_images(args.batch, 3, args.size, args.size, seed=rank)).to(dev)
     y = torch.from_numpy(synth.synth_labels(args.batch, args.classes, seed=1000 + rank)).to(dev)
 
+    if args.precision == "fp8":   # activation ranges from the bench batch itself (a deployment calibrates on real ROIs)
+        net.eval()
+        net.set_fp8(True, calibration_batch=x[:min(args.batch, 64)])
     # headline = the inference step (net_pass body); the training step of the
     # same model/config rides along under "train" (BASELINE metric names both)
     modes = ["infer", "train"] if args.mode == "both" else [args.mode]

@@ -157,6 +157,16 @@ int spk_model_set_precision(spk_model* m, int split_weights, int precise_residua
  * called again.  `tests/diagnostics/split_search.py` derives the cheapest mask that keeps
  * the reference's 1e-3 probability tolerance. */
 int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops);
+/* fp8 (OCP e4m3) eval mode of the EfficientNet MBConv blocks — BASELINE config 5.  Inside a block (expand 1x1
+ * conv -> depthwise conv -> squeeze-excitation -> project 1x1 conv) the expanded tensors are stored as e4m3
+ * bytes with one scale per tensor, the 1x1 convs run on the fp8 MFMA with e4m3 weights (one scale per output
+ * channel) and the squeeze-excitation gate is applied in the project conv's operand loader; the residual
+ * trunk, the stem, the head and any block without an expand conv stay fp16.  spk_model_calibrate_fp8 runs one
+ * fp16 forward of a representative device batch (as spk_forward_infer takes it) and records the activation
+ * ranges; it must be called before the first fp8 forward and again after loading other weights.  3 mantissa
+ * bits do not reach the 1e-3 probability tolerance of the reference: the fp16 path stays the parity mode. */
+int spk_model_set_fp8(spk_model* m, int on);
+int spk_model_calibrate_fp8(spk_model* m, const void* x_dev, int n, int h, int w, int layout, int dtype);
 /* Dropout mask seed for training steps. */
 int spk_model_set_seed(spk_model* m, uint64_t seed);
 
@@ -229,6 +239,13 @@ int spk_op_conv_dgrad(const void* dy_dev, const float* w_dev, void* dx_dev, int 
 /* Conv2d weight gradient: dw [Cout][kh][kw][Cin] float32 from x [n,h,w,cin] and dy [n,ho,wo,cout]. */
 int spk_op_conv_wgrad(const void* x_dev, const void* dy_dev, float* dw_dev, int n, int h, int w, int cin, int cout,
                       int k, int stride, int pad, void* hip_stream);
+/* fp8 pointwise conv (the 1x1 convs of the fp8 EfficientNet mode): y = act((e4m3(A) . e4m3(W)^T) * factor + bias)
+ * (+ res).  x: [m_rows][cin] fp16 (a_fp8 = 0: converted as x / a_scale) or e4m3 bytes (a_fp8 = 1: value = byte *
+ * a_scale; gate, optional: fp32 [m_rows / hw][cin] multiplied in and re-rounded); w: float32 [cout][cin];
+ * y: [m_rows][cout] fp16 or e4m3 bytes (out_fp8: byte = e4m3(value / y_scale)); bn_scale / bn_bias: float[cout]. */
+int spk_op_pw_fp8(const void* x_dev, int a_fp8, const float* w_dev, void* y_dev, int out_fp8, const void* res_dev,
+                  const float* bn_scale_dev, const float* bn_bias_dev, const float* gate_dev, int hw, int m_rows, int cin,
+                  int cout, int act, float a_scale, float y_scale, void* hip_stream);
 
 /* --- ROI preprocessing straight from the .roi blob ---
  * One ROI of an IFCB sample: byte offset into the .roi blob, width, height

@@ -357,6 +357,7 @@ int spk_launch_se(const bf16_t* x, bf16_t* y, const float* partial, int chunks, 
                      c, c_p, sq);
   hipLaunchKernelGGL(se_fc2_kernel, dim3(n, (c_p + 255) / 256), dim3(256), (size_t)sq * 4, s, hid, w2t, b2, scale, c, c_p,
                      sq);
+  if (!y) return hipGetLastError() == hipSuccess ? 0 : -1;   // gates only
   const size_t per_img = (size_t)hw * (c_p / 8);
   if (per_img >= ((size_t)1 << 31)) return -2;
   int gx = (int)((per_img + 255) / 256);

@@ -40,6 +40,11 @@ struct Layer {
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)
+  // fp8 mode of the MBConv interior (spk_model_set_fp8): role of this layer and what calibration measured
+  int fp8_role = 0;           // 0 none, 1 expand conv (fp16 in, e4m3 out), 2 depthwise (e4m3 in/out), 3 squeeze-excitation
+                              // (gates only), 4 project conv (e4m3 in x gate, fp16 out)
+  float amax_in = 0.f, amax_out = 0.f;   // max |x| of the input / output tensor on the calibration batch
+  size_t w8_off = 0, s8_off = 0;         // e4m3 weights / [ws, epilogue scale] floats of this layer
   bool side_branch = false;   // output is only ever a shortcut operand (downsample conv): may run beside the main branch
   hipEvent_t join = nullptr;  // side branches: recorded on the side stream after the layer
 };
@@ -83,6 +88,16 @@ struct spk_model {
   std::vector<size_t> toff_lo;  // 0 = no remainder tensor
   bool precise_res = false;     // keep the 16-bit rounding remainder of shortcut tensors
   size_t logits_off = 0;
+
+  // fp8 (e4m3) eval mode of the EfficientNet MBConv interior — BASELINE config 5
+  int fp8 = 0;                  // requested
+  bool fp8_calibrated = false;  // roles assigned + activation ranges measured
+  bool fp8_packed = false;
+  unsigned char* w8pack = nullptr;
+  float* s8 = nullptr;
+  const float* cur_gate = nullptr;   // gates of the squeeze-excitation op that ran last (consumed by the project conv)
+  int cur_gate_stride = 0;
+  std::vector<float> t_fp8_scale;    // per tensor: 0 = 16-bit storage, else value = byte * scale
 
   uint64_t seed = 0;
   TrainState* train = nullptr;

@@ -257,6 +257,8 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->wpack) hipFree(m->wpack);
   if (m->scale_bias) hipFree(m->scale_bias);
   if (m->dwpack) hipFree(m->dwpack);
+  if (m->w8pack) hipFree(m->w8pack);
+  if (m->s8) hipFree(m->s8);
   if (m->side) hipStreamDestroy(m->side);
   if (m->fork) hipEventDestroy(m->fork);
   for (Layer& L : m->layers)
@@ -459,6 +461,124 @@ int spk_commit(spk_model* m) {
   m->packed_split = (int)m->splitw;
   m->packed_epoch = m->split_epoch;
   m->dirty = false;
+  m->fp8_packed = false;
+  return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fp8 (e4m3) mode of the EfficientNet MBConv interior — BASELINE config 5
+// ---------------------------------------------------------------------------
+static float fp8_scale_of(float amax) {
+  // value = byte * scale; 2x headroom over the calibration batch (e4m3 keeps its 3 mantissa bits over 15 binades,
+  // so headroom costs no precision); conversion saturates at +-448
+  return amax > 0.f ? 2.f * amax / 448.f : 1.f;
+}
+
+// expand 1x1 conv -> depthwise conv -> squeeze-excitation -> project 1x1 conv with e4m3 tensors in between
+static void assign_fp8_roles(spk_model* m) {
+  const int nl = (int)m->layers.size();
+  auto consumer = [&](int t, int* idx) {
+    int cnt = 0;
+    for (int j = 0; j < nl; ++j)
+      if (m->layers[j].d.src == t || (m->layers[j].d.kind == SPK_OP_CONV && m->layers[j].d.res == t)) { *idx = j; ++cnt; }
+    return cnt;
+  };
+  for (Layer& L : m->layers) L.fp8_role = 0;
+  for (int i = 0; i < nl; ++i) {
+    Layer& E = m->layers[i];
+    if (E.d.kind != SPK_OP_CONV || E.d.k != 1 || E.d.stride != 1 || E.d.res >= 0 || E.d.cout % 16 || E.d.src == 0) continue;
+    int di, si, pi;
+    if (consumer(E.d.dst, &di) != 1 || m->layers[di].d.kind != SPK_OP_DWCONV) continue;
+    if (consumer(m->layers[di].d.dst, &si) != 1 || m->layers[si].d.kind != SPK_OP_SE) continue;
+    if (consumer(m->layers[si].d.dst, &pi) != 1) continue;
+    Layer& P = m->layers[pi];
+    if (P.d.kind != SPK_OP_CONV || P.d.k != 1 || P.d.stride != 1 || P.d.src != m->layers[si].d.dst) continue;
+    E.fp8_role = 1; m->layers[di].fp8_role = 2; m->layers[si].fp8_role = 3; P.fp8_role = 4;
+  }
+}
+
+extern "C" int spk_model_set_fp8(spk_model* m, int on) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  if (on && !m->eval_only) return fail(SPK_ERR_UNSUPPORTED, "the fp8 mode covers the EfficientNet MBConv blocks only");
+  m->fp8 = on ? 1 : 0;
+  return SPK_OK;
+}
+
+static int fp8_amax(spk_model* m, int t, int nb, unsigned int* dev_word, float* out) {
+  const TDim& d = m->tdims[t];
+  HIP_TRY(hipMemsetAsync(dev_word, 0, 4, m->stream));
+  if (spk_launch_absmax_f16((const bf16_t*)m->T(t), (size_t)nb * d.h * d.w * d.c / 8, dev_word, m->stream))
+    return fail(SPK_ERR_HIP, "absmax launch failed");
+  unsigned int bits = 0;
+  HIP_TRY(hipMemcpyAsync(&bits, dev_word, 4, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  memcpy(out, &bits, 4);
+  return SPK_OK;
+}
+
+extern "C" int spk_model_calibrate_fp8(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype) {
+  if (!m || !x || n <= 0) return fail(SPK_ERR_ARG, "calibrate_fp8: bad arguments");
+  if (!m->eval_only) return fail(SPK_ERR_UNSUPPORTED, "the fp8 mode covers the EfficientNet MBConv blocks only");
+  if (m->infer_dt != DT_F16) return fail(SPK_ERR_STATE, "calibrate_fp8 needs the fp16 eval path");
+  HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_plan(m, n, h, w));
+  if (n > m->mb_limit) return fail(SPK_ERR_ARG, "calibration batch too large for one pass");
+  const int keep = m->fp8;
+  m->fp8 = 0;                                    // the calibration forward itself runs in fp16
+  float* logits = (float*)((char*)m->arena + m->logits_off);
+  const int rc = spk_forward_eval_logits(m, x, n, h, w, layout, dtype, logits);
+  m->fp8 = keep;
+  if (rc != SPK_OK) return rc;
+  assign_fp8_roles(m);
+  unsigned int* word = nullptr;
+  HIP_TRY(hipMalloc((void**)&word, 4));
+  int r = SPK_OK;
+  for (Layer& L : m->layers) {
+    if (!L.fp8_role || L.fp8_role == 3) continue;
+    if (L.fp8_role == 1 && (r = fp8_amax(m, L.d.src, n, word, &L.amax_in)) != SPK_OK) break;   // trunk entering the block
+    if (L.fp8_role != 4 && (r = fp8_amax(m, L.d.dst, n, word, &L.amax_out)) != SPK_OK) break;  // expanded / depthwise out
+  }
+  (void)hipFree(word);
+  if (r != SPK_OK) return r;
+  // a layer's input range is its producer's output range
+  for (Layer& L : m->layers) {
+    if (L.fp8_role == 2)
+      for (const Layer& Q : m->layers) if (Q.fp8_role == 1 && Q.d.dst == L.d.src) L.amax_in = Q.amax_out;
+    if (L.fp8_role == 4)
+      for (const Layer& S : m->layers)
+        if (S.fp8_role == 3 && S.d.dst == L.d.src)
+          for (const Layer& D : m->layers) if (D.fp8_role == 2 && D.d.dst == S.d.src) L.amax_in = D.amax_out;
+  }
+  // storage for the e4m3 weights and their scales
+  size_t wb = 0, sf = 0;
+  for (Layer& L : m->layers) {
+    if (L.fp8_role != 1 && L.fp8_role != 4) continue;
+    const int kpad = (L.d.cin + 63) / 64 * 64;
+    L.w8_off = wb; wb += (size_t)L.cout_p * kpad;
+    L.s8_off = sf; sf += (size_t)2 * L.cout_p;
+  }
+  if (m->w8pack) { (void)hipFree(m->w8pack); m->w8pack = nullptr; }
+  if (m->s8) { (void)hipFree(m->s8); m->s8 = nullptr; }
+  HIP_TRY(hipMalloc((void**)&m->w8pack, std::max<size_t>(wb, 64)));
+  HIP_TRY(hipMalloc((void**)&m->s8, std::max<size_t>(sf, 64) * 4));
+  m->fp8_calibrated = true;
+  m->fp8_packed = false;
+  return SPK_OK;
+}
+
+static int fp8_pack(spk_model* m) {
+  if (m->fp8_packed) return SPK_OK;
+  for (Layer& L : m->layers) {
+    if (L.fp8_role != 1 && L.fp8_role != 4) continue;
+    const int kpad = (L.d.cin + 63) / 64 * 64;
+    float* ws = m->s8 + L.s8_off;
+    if (spk_launch_pack_fp8(m->P(L.p_w), m->w8pack + L.w8_off, ws, L.d.cout, L.d.cin, L.cout_p, kpad, 1.f, m->stream))
+      return fail(SPK_ERR_HIP, "fp8 weight packing failed");
+    // epilogue factor = eval-BN scale x weight scale x scale of the A bytes
+    if (spk_launch_mul3(m->scale_bias + L.sb_off, ws, fp8_scale_of(L.amax_in), ws + L.cout_p, L.cout_p, m->stream))
+      return fail(SPK_ERR_HIP, "fp8 scale folding failed");
+  }
+  m->fp8_packed = true;
   return SPK_OK;
 }
 
@@ -528,7 +648,8 @@ int spk_plan(spk_model* m, int n, int h, int w) {
     if (L.d.kind != SPK_OP_SE) continue;
     const TDim& d = m->tdims[L.d.src];
     // partials [n][chunks][c] (chunks(1) >= chunks(nb)), scales [n][c], hidden units [n][squeeze]
-    se_floats = std::max(se_floats, (size_t)n * ((spk_dw_chunks(1, d.h * ((d.w + 3) / 4), d.c) + 1) * d.c + L.d.k));
+    const int ch = std::max(spk_dw_chunks(1, d.h * ((d.w + 3) / 4), d.c), spk_dw_chunks(1, d.h * ((d.w + 1) / 2), d.c));
+    se_floats = std::max(se_floats, (size_t)n * ((ch + 1) * d.c + L.d.k));
   }
   m->se_off = total;
   total += align256(se_floats * 4);
@@ -599,9 +720,66 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   return SPK_OK;
 }
 
+// fp8 mode: the four layers of an MBConv block with e4m3 tensors between them (pw_fp8.hip)
+static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
+  const TDim& in = m->tdims[L.d.src];
+  const TDim& o = m->tdims[L.d.dst];
+  const float* sc = m->scale_bias + L.sb_off;
+  switch (L.fp8_role) {
+    case 1: {   // expand: trunk fp16 -> e4m3 in the loader; output e4m3 with the expanded tensor's scale
+      const int kpad = (L.d.cin + 63) / 64 * 64;
+      const float ys = fp8_scale_of(L.amax_out);
+      m->t_fp8_scale[L.d.dst] = ys;
+      if (spk_launch_pw_fp8(m->T(L.d.src), 0, m->w8pack + L.w8_off, m->T(L.d.dst), 1, nullptr, m->s8 + L.s8_off + L.cout_p,
+                            sc + L.cout_p, nullptr, 0, in.h * in.w, nb * o.h * o.w, kpad, L.cout_p, in.c, o.c, L.d.relu,
+                            1.f / fp8_scale_of(L.amax_in), 1.f / ys, m->stream))
+        return fail(SPK_ERR_HIP, std::string("fp8 expand conv launch failed for ") + L.d.name);
+      return SPK_OK;
+    }
+    case 2: {   // depthwise on e4m3; pool partials for the squeeze-excitation gate as in the fp16 kernel
+      const float ys = fp8_scale_of(L.amax_out);
+      m->t_fp8_scale[L.d.dst] = ys;
+      const int chunks = spk_dw_chunks(nb, o.h * ((o.w + 1) / 2), in.c);
+      if (spk_launch_dwconv_fp8((const unsigned char*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                                (unsigned char*)m->T(L.d.dst), (float*)((char*)m->arena + m->se_off), nb, in.h, in.w,
+                                in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu, chunks, fp8_scale_of(L.amax_in), 1.f / ys,
+                                m->stream))
+        return fail(SPK_ERR_HIP, std::string("fp8 depthwise launch failed for ") + L.d.name);
+      return SPK_OK;
+    }
+    case 3: {   // squeeze-excitation: the gates only; the project conv multiplies them into its A operand
+      float* partial = (float*)((char*)m->arena + m->se_off);
+      const int chunks = spk_dw_chunks(nb, in.h * ((in.w + 1) / 2), in.c);
+      float* gate = partial + (size_t)nb * chunks * in.c;
+      if (spk_launch_se(nullptr, nullptr, partial, chunks, gate, m->P(L.p_w), m->P(L.p_b), m->dwpack + L.wpack_off,
+                        m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k, DT_F16, m->stream))
+        return fail(SPK_ERR_HIP, std::string("squeeze-excitation launch failed for ") + L.d.name);
+      m->cur_gate = gate;
+      m->cur_gate_stride = in.c;
+      m->t_fp8_scale[L.d.dst] = 0.f;   // not materialised
+      return SPK_OK;
+    }
+    default: {  // 4 project: A = the depthwise output (e4m3) x gate; fp16 trunk out (+ shortcut)
+      int se_src = -1;
+      for (const Layer& S : m->layers) if (S.fp8_role == 3 && S.d.dst == L.d.src) se_src = S.d.src;
+      if (se_src < 0 || !m->cur_gate) return fail(SPK_ERR_STATE, "fp8 project conv without its squeeze-excitation gate");
+      const TDim& e = m->tdims[se_src];
+      const int kpad = (L.d.cin + 63) / 64 * 64;
+      if (spk_launch_pw_fp8(m->T(se_src), 1, m->w8pack + L.w8_off, m->T(L.d.dst), 0,
+                            L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p,
+                            m->cur_gate, m->cur_gate_stride, e.h * e.w, nb * o.h * o.w, kpad, L.cout_p, e.c, o.c, L.d.relu,
+                            1.f, 1.f, m->stream))
+        return fail(SPK_ERR_HIP, std::string("fp8 project conv launch failed for ") + L.d.name);
+      m->t_fp8_scale[L.d.dst] = 0.f;
+      return SPK_OK;
+    }
+  }
+}
+
 int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
+  if (m->fp8 && m->fp8_calibrated && L.fp8_role) return run_layer_fp8(m, L, nb);
   switch (L.d.kind) {
     case SPK_OP_CONV: return run_conv_eval(m, L, nb);
     case SPK_OP_DWCONV: {
@@ -699,6 +877,10 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
   HIP_TRY(hipSetDevice(m->device));
   SPK_TRY(spk_commit(m));
   SPK_TRY(spk_plan(m, n, h, w));
+  if (m->fp8 && !m->fp8_calibrated)
+    return fail(SPK_ERR_STATE, "fp8 mode needs activation ranges first: call spk_model_calibrate_fp8 on a representative batch");
+  if (m->fp8) SPK_TRY(fp8_pack(m));
+  m->t_fp8_scale.assign(m->n_tensors, 0.f);
   const int mb = micro_batch(m, n);
   const int last = m->layers.back().d.dst;
   m->act_dt = m->infer_dt;
@@ -753,6 +935,22 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (!d.bf16) {
     HIP_TRY(hipMemcpy(host, m->T(t), cnt * 4, hipMemcpyDeviceToHost));
+    return SPK_OK;
+  }
+  if (t < (int)m->t_fp8_scale.size() && m->t_fp8_scale[t] > 0.f) {   // e4m3 bytes: value = byte * scale
+    std::vector<unsigned char> b8(cnt);
+    HIP_TRY(hipMemcpy(b8.data(), m->T(t), cnt, hipMemcpyDeviceToHost));
+    const float sc8 = m->t_fp8_scale[t];
+    for (int i = 0; i < n; ++i)
+      for (int y = 0; y < d.h; ++y)
+        for (int x = 0; x < d.w; ++x)
+          for (int c = 0; c < cl; ++c) {
+            const unsigned b = b8[(((size_t)i * d.h + y) * d.w + x) * d.c + c];
+            const int e = (b >> 3) & 15, mant = b & 7;
+            float f = e ? std::ldexp(1.f + mant / 8.f, e - 7) : std::ldexp(mant / 8.f, -6);
+            if (e == 15 && mant == 7) f = NAN;
+            host[(((size_t)i * cl + c) * d.h + y) * d.w + x] = (b & 0x80 ? -f : f) * sc8;
+          }
     return SPK_OK;
   }
   std::vector<bf16_t> tmp(cnt);

@@ -133,3 +133,31 @@ extern "C" int spk_op_conv_wgrad(const void* x, const void* dy, float* dw_ohwi, 
   if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_conv_wgrad: kernel failed");
   return SPK_OK;
 }
+
+// fp8 (e4m3) pointwise conv of the EfficientNet MBConv interior (pw_fp8.hip) on caller-provided buffers:
+// packs the fp32 weights [cout][cin] to e4m3 with per-output-channel scales, folds bn_scale x weight scale x
+// a_scale into the epilogue factor and runs the kernel the eval path runs.
+extern "C" int spk_op_pw_fp8(const void* x, int a_fp8, const float* w, void* y, int out_fp8, const void* res,
+                             const float* bn_scale, const float* bn_bias, const float* gate, int hw, int m_rows, int cin,
+                             int cout, int act, float a_scale, float y_scale, void* stream) {
+  if (!x || !w || !y || !bn_scale || !bn_bias || m_rows < 1 || cin < 1 || cout < 1 || a_scale <= 0.f || y_scale <= 0.f)
+    return ofail(SPK_ERR_ARG, "op_pw_fp8: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int npad = (cout + 63) / 64 * 64, kpad = (cin + 63) / 64 * 64;
+  Scratch sc;
+  unsigned char* w8 = sc.get<unsigned char>((size_t)npad * kpad);
+  float* f = sc.get<float>((size_t)4 * npad);   // ws, epilogue scale, padded bn scale, padded bias
+  if (!w8 || !f) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  if (hipMemsetAsync(f, 0, (size_t)4 * npad * 4, s) != hipSuccess ||
+      hipMemcpyAsync(f + 2 * npad, bn_scale, (size_t)cout * 4, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(f + 3 * npad, bn_bias, (size_t)cout * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return ofail(SPK_ERR_HIP, "op_pw_fp8: staging failed");
+  O_TRY(spk_launch_pack_fp8(w, w8, f, cout, cin, npad, kpad, 1.f, s), "pack_fp8");
+  O_TRY(spk_launch_mul3(f + 2 * npad, f, a_scale, f + npad, npad, s), "scale folding");
+  const int r = spk_launch_pw_fp8(x, a_fp8, w8, y, out_fp8, (const bf16_t*)res, f + npad, f + 3 * npad, gate, cin, hw, m_rows,
+                                  kpad, npad, cin, cout, act, 1.f / a_scale, 1.f / y_scale, s);
+  if (r == -2) return ofail(SPK_ERR_UNSUPPORTED, "op_pw_fp8: shape not supported (cin % 8 / 16, cout % 8)");
+  if (r) return ofail(SPK_ERR_HIP, "op_pw_fp8: launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_pw_fp8: kernel failed");
+  return SPK_OK;
+}

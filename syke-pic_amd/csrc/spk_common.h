@@ -119,11 +119,23 @@ int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, cons
 int spk_dw_chunks(int n, int hw, int c_p);
 int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, float* partial,
                       int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s);
+// y == nullptr: the gates only (scale[n][c_p]); the caller applies them elsewhere (fp8 mode: in the project conv)
 int spk_launch_se(const bf16_t* x, bf16_t* y, const float* partial, int chunks, float* scale, const float* w1,
                   const float* b1, const float* w2t, const float* b2, int n, int hw, int c, int c_p, int sq, int dt,
                   hipStream_t s);
 int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
                             int mode, int dt, int splitw, hipStream_t s);
+// fp8 (e4m3) mode of the MBConv interior (pw_fp8.hip)
+int spk_launch_pw_fp8(const void* x, int a_fp8, const unsigned char* w, void* y, int out_fp8, const bf16_t* res,
+                      const float* scale, const float* bias, const float* gate, int gate_stride, int hw, int M, int Kpad,
+                      int Npad, int cin_s, int cout_s, int act, float a_inv_scale, float y_inv_scale, hipStream_t s);
+int spk_launch_pack_fp8(const float* w, unsigned char* out, float* wscale_out, int cout, int cin, int Npad, int Kpad,
+                        float col_scale, hipStream_t s);
+int spk_launch_absmax_f16(const bf16_t* x, size_t n8, unsigned int* out_bits, hipStream_t s);
+int spk_launch_dwconv_fp8(const unsigned char* x, const float* w, const float* scale, const float* bias, unsigned char* y,
+                          float* partial, int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act,
+                          int chunks, float in_scale, float out_inv_scale, hipStream_t s);
+int spk_launch_mul3(const float* a, const float* b, float c, float* out, int n, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Head (head.hip): fp32 Linear layers, softmax, cross-entropy

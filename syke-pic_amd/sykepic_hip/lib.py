@@ -69,6 +69,8 @@ SYMBOLS = {
     "spk_model_set_infer_dtype": (C.c_int, [_P, C.c_int]),
     "spk_model_set_precision": (C.c_int, [_P, C.c_int, C.c_int]),
     "spk_model_set_split_ops": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "spk_model_set_fp8": (C.c_int, [_P, C.c_int]),
+    "spk_model_calibrate_fp8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "spk_model_set_seed": (C.c_int, [_P, C.c_uint64]),
     "spk_forward_infer": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                     _P]),
@@ -84,6 +86,8 @@ SYMBOLS = {
     "spk_op_bn_backward": (C.c_int, [_P] * 10 + [C.c_int] * 4 + [_P]),
     "spk_op_conv_dgrad": (C.c_int, [_P, _P, _P] + [C.c_int] * 9 + [_P]),
     "spk_op_conv_wgrad": (C.c_int, [_P, _P, _P] + [C.c_int] * 8 + [_P]),
+    "spk_op_pw_fp8": (C.c_int, [_P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_float, C.c_float, _P]),
     "spk_preprocess_rois": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "spk_predict_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P]),
     "spk_augment_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),

@@ -232,6 +232,19 @@ class HipNet:
         lib.check(self._lib.spk_model_set_precision(self._h, int(split_weights), int(bool(precise_residual))))
         return self
 
+    def set_fp8(self, on=True, calibration_batch=None):
+        """fp8 (e4m3) eval mode of the EfficientNet MBConv blocks (BASELINE config 5; include/sykepic_hip.h).
+        `calibration_batch`: a representative image batch (as `forward` takes it) whose activation ranges set the
+        tensor scales; required before the first fp8 forward."""
+        self._ensure_init()
+        lib.check(self._lib.spk_model_set_fp8(self._h, int(bool(on))))
+        if on and calibration_batch is not None:
+            x, n, h, w, layout, dtype = self._prep(calibration_batch)
+            with torch.cuda.device(self.device):
+                lib.check(self._lib.spk_model_set_stream(self._h, self._stream()))
+                lib.check(self._lib.spk_model_calibrate_fp8(self._h, C.c_void_p(x.data_ptr()), n, h, w, layout, dtype))
+        return self
+
     def set_seed(self, seed):
         """Seed of the Dropout masks drawn by training steps (reproducible runs)."""
         lib.check(self._lib.spk_model_set_seed(self._h, int(seed) & 0xFFFFFFFFFFFFFFFF))

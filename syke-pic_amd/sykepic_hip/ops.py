@@ -119,3 +119,23 @@ def conv_wgrad(x, dy, k, stride=1, pad=0):
     with torch.cuda.device(dev):
         lib.check(so.spk_op_conv_wgrad(_p(xh), _p(dyh), _p(dw), n, h, w, cin, cout, k, stride, pad, _stream(dev)))
     return dw.permute(0, 3, 1, 2)
+
+
+def pw_fp8(x, weight, bn_scale, bn_bias, act=0, a_scale=1.0, y_scale=1.0, out_fp8=False, res=None, gate=None, hw=1):
+    """fp8 pointwise conv (spk_op_pw_fp8).  x: [M, cin] float16, or uint8 holding e4m3 bytes (value = byte *
+    a_scale); weight [cout, cin] float32; returns [M, cout] float16, or uint8 e4m3 bytes when out_fp8."""
+    so = lib.load()
+    dev = x.device
+    m, cin = x.shape
+    cout = weight.shape[0]
+    a_fp8 = x.dtype == torch.uint8
+    x = x.contiguous()
+    y = torch.empty((m, cout), dtype=torch.uint8 if out_fp8 else torch.float16, device=dev)
+    w = weight.float().contiguous()
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_pw_fp8(_p(x), int(a_fp8), _p(w), _p(y), int(bool(out_fp8)),
+                                   _p(res.contiguous()) if res is not None else None, _p(bn_scale.float().contiguous()),
+                                   _p(bn_bias.float().contiguous()),
+                                   _p(gate.float().contiguous()) if gate is not None else None, int(hw), m, cin, cout,
+                                   int(act), float(a_scale), float(y_scale), _stream(dev)))
+    return y
