@@ -102,8 +102,14 @@ struct spk_model {
   uint64_t seed = 0;
   TrainState* train = nullptr;
 
+  int img0 = 0;                 // first image of the chunk the eval executor is working on (prefix micro-batching)
   float* P(int pi) const { return pbuf + params[pi].off; }
   void* T(int t) const { return (char*)arena + toff[t]; }
+  // tensor t from image img0 on
+  void* TI(int t) const {
+    const TDim& d = tdims[t];
+    return (char*)arena + toff[t] + (size_t)img0 * d.h * d.w * d.c * (d.bf16 ? 2 : 4);
+  }
   void* TLo(int t) const { return toff_lo[t] ? (char*)arena + toff_lo[t] : nullptr; }
 };
 

@@ -695,10 +695,10 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   memset(&a, 0, sizeof a);
   a.cfg = a.dma = -1;
   a.cls_ph = a.cls_pw = -1;
-  a.x = (const bf16_t*)m->T(L.d.src);
+  a.x = (const bf16_t*)m->TI(L.d.src);
   a.w = m->wpack + L.wpack_off;
-  a.y = (bf16_t*)m->T(L.d.dst);
-  a.res = L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr;
+  a.y = (bf16_t*)m->TI(L.d.dst);
+  a.res = L.d.res >= 0 ? (const bf16_t*)m->TI(L.d.res) : nullptr;
   a.res_lo = L.d.res >= 0 ? (const bf16_t*)m->TLo(L.d.res) : nullptr;
   a.y_lo = (bf16_t*)m->TLo(L.d.dst);
   a.scale = m->scale_bias + L.sb_off;
@@ -806,7 +806,7 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       return SPK_OK;
     }
     case SPK_OP_MAXPOOL:
-      if (spk_launch_maxpool((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), nb, in.h, in.w,
+      if (spk_launch_maxpool((const bf16_t*)m->TI(L.d.src), (bf16_t*)m->TI(L.d.dst), nb, in.h, in.w,
                              in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, m->infer_dt, m->stream))
         return fail(SPK_ERR_HIP, "maxpool launch failed");
       return SPK_OK;
@@ -833,12 +833,57 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
 // Measured (ResNet-50, batch 256, round 2): 5.40 ms with the fork against 5.30 ms on one stream - the branches
 // already keep several blocks per CU resident and the two grids only contend - so it is OFF unless
 // SPK_SIDE_STREAM=1 asks for it.
+// Prefix micro-batching: the leading layers whose tensors exceed the 256 MiB Infinity Cache at the full batch (ResNet-50,
+// batch 256: stem, max-pool and the 56^2 stage, 103-411 MB per tensor) run chunk by chunk of `mb` images, so that a
+// chunk's tensors (13-51 MB at 32 images) are still on die when the next layer reads them; the deeper layers, whose
+// tensors fit anyway and whose M is small, keep the full batch (chunking THEM costs tile fill).  Only plain conv /
+// max-pool layers without remainder tensors qualify.  SPK_PREFIX_MB=<images> (0 = off), SPK_PREFIX_BYTES=<bytes>.
+// Measured (round 2, ResNet-50 batch 256): 5.62 ms with 32-image chunks, 5.57 ms with 64, against 5.51 ms without:
+// the stage-1 layers already stream at 4.1-4.5 TB/s and the cache does not serve them faster, so it stays OFF.
+static int prefix_layers(const spk_model* m, int nb, int* mb_out) {
+  static const int mb_env = getenv("SPK_PREFIX_MB") ? atoi(getenv("SPK_PREFIX_MB")) : 0;
+  static const double limit = getenv("SPK_PREFIX_BYTES") ? atof(getenv("SPK_PREFIX_BYTES")) : 128e6;
+  *mb_out = mb_env;
+  if (mb_env <= 0 || nb <= mb_env || m->precise_res || m->fp8) return 0;
+  int p = 0;
+  for (const Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV && L.d.kind != SPK_OP_MAXPOOL) break;
+    if (L.d.kind == SPK_OP_CONV && L.mode == CONV_MODE_STEM3) break;
+    const TDim& o = m->tdims[L.d.dst];
+    if ((double)nb * o.h * o.w * o.c * 2 < limit) break;
+    ++p;
+  }
+  // a chunked layer may only read tensors produced inside the prefix (or the input image)
+  for (int i = 0; i < p; ++i) {
+    const Layer& L = m->layers[i];
+    auto inside = [&](int t) {
+      if (t <= 0) return true;
+      for (int j = 0; j < p; ++j) if (m->layers[j].d.dst == t) return true;
+      return false;
+    };
+    if (!inside(L.d.src) || (L.d.res >= 0 && !inside(L.d.res))) return 0;
+  }
+  return p;
+}
+
 static int run_layers_eval(spk_model* m, int nb) {
   static const bool two = getenv("SPK_SIDE_STREAM") && atoi(getenv("SPK_SIDE_STREAM")) != 0;
   bool any = false;
   for (const Layer& L : m->layers) any |= L.side_branch;
   if (!two || !any) {
-    for (Layer& L : m->layers) SPK_TRY(spk_run_layer_eval(m, L, nb));
+    int mb = 0;
+    const int p = prefix_layers(m, nb, &mb);
+    if (p > 0) {
+      for (int i0 = 0; i0 < nb; i0 += mb) {
+        m->img0 = i0;
+        for (int i = 0; i < p; ++i) {
+          const int r = spk_run_layer_eval(m, m->layers[i], std::min(mb, nb - i0));
+          if (r != SPK_OK) { m->img0 = 0; return r; }
+        }
+      }
+      m->img0 = 0;
+    }
+    for (size_t i = (size_t)p; i < m->layers.size(); ++i) SPK_TRY(spk_run_layer_eval(m, m->layers[i], nb));
     return SPK_OK;
   }
   if (!m->side) {

@@ -166,6 +166,17 @@ struct OptTable {
   int count;
 };
 
+struct PackEntry {
+  unsigned long long src, dst;   // element offsets: master weights in the flat fp32 buffer / image in the bf16 buffer
+  unsigned int cout, taps, cin;
+  int kind;                      // 0 forward image (element-wise), 1 data-gradient image (transposed)
+};
+struct PackTable {
+  PackEntry e[64];
+  int count;
+};
+int spk_launch_pack_multi(const float* pbuf, bf16_t* wpack, const PackTable& t, hipStream_t s);
+
 int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, const float* gamma,
                            const float* beta, float* rmean, float* rvar, float* mean, float* invstd,
                            float* scale, float* shift, float eps, float momentum, float* tmp,

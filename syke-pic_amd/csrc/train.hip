@@ -200,15 +200,33 @@ static int plan_train(spk_model* m, int n, int h, int w) {
 static int repack_weights(spk_model* m) {
   TrainState* t = m->train;
   if (!t->weights_dirty) return SPK_OK;
+  // every conv's forward and data-gradient image through table-driven launches (64 images each); the stem's
+  // forward image has its own layout and kernel
+  PackTable tab;
+  tab.count = 0;
+  auto flush = [&]() -> int {
+    const int r = spk_launch_pack_multi(m->pbuf, t->wpack, tab, m->stream);
+    tab.count = 0;
+    return r;
+  };
   for (size_t i = 0; i < m->layers.size(); ++i) {
     const Layer& L = m->layers[i];
     if (L.d.kind != SPK_OP_CONV) continue;
-    K_TRY(spk_launch_pack_weights(m->P(L.p_w), t->wpack + t->conv[i].wfwd_off, L.d.cout, L.d.k, L.d.k,
-                                  L.d.cin, L.mode, DT_BF16, 0, m->stream), "pack_weights");
-    if (L.mode != CONV_MODE_STEM)
-      K_TRY(spk_launch_pack_dgrad(m->P(L.p_w), t->wpack + t->conv[i].wdg_off, L.d.cout, L.d.k * L.d.k,
-                                  L.d.cin, m->stream), "pack_dgrad");
+    if (L.mode == CONV_MODE_STEM) {
+      K_TRY(spk_launch_pack_weights(m->P(L.p_w), t->wpack + t->conv[i].wfwd_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
+                                    L.mode, DT_BF16, 0, m->stream), "pack_weights");
+      continue;
+    }
+    for (int kind = 0; kind < 2; ++kind) {
+      PackEntry& e = tab.e[tab.count++];
+      e.src = m->params[L.p_w].off;
+      e.dst = kind ? t->conv[i].wdg_off : t->conv[i].wfwd_off;
+      e.cout = (unsigned)L.d.cout; e.taps = (unsigned)(L.d.k * L.d.k); e.cin = (unsigned)L.d.cin;
+      e.kind = kind;
+      if (tab.count == 64) K_TRY(flush(), "pack_multi");
+    }
   }
+  K_TRY(flush(), "pack_multi");
   t->weights_dirty = false;
   return SPK_OK;
 }

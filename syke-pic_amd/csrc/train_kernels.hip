@@ -376,6 +376,25 @@ __global__ void pack_dgrad_kernel(const float* __restrict__ w, bf16_t* __restric
   }
 }
 
+// Both 16-bit weight images of up to 64 conv layers in ONE launch (every training step repacks every conv whose
+// master weights the optimizer moved: 2 x 53 tiny launches for ResNet-50 otherwise).  blockIdx.y selects a table
+// entry; kind 0: forward image [Cout][K] = the master layout, an element-wise conversion; kind 1: data-gradient
+// image [Cin][taps][Cout].
+__global__ void pack_multi_kernel(const float* __restrict__ pbuf, bf16_t* __restrict__ wpack, PackTable t) {
+  const PackEntry e = t.e[blockIdx.y];
+  const float* w = pbuf + e.src;
+  bf16_t* out = wpack + e.dst;
+  const unsigned n = e.cout * e.taps * e.cin;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    if (e.kind == 0) {
+      out[i] = to_h16<DT>(w[i]);
+    } else {
+      const unsigned co = i % e.cout, tt = (i / e.cout) % e.taps, ci = i / (e.cout * e.taps);
+      out[i] = to_h16<DT>(w[((size_t)co * e.taps + tt) * e.cin + ci]);
+    }
+  }
+}
+
 // ---- optimizers over one tensor of the flat buffers ----
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
                            size_t n, float lr, float wd, float momentum, float gscale, int first) {
@@ -672,6 +691,12 @@ int spk_launch_stem_wgrad_unpack(const float* slabs, float* out, int cout, int k
 int spk_launch_pack_dgrad(const float* w, bf16_t* out, int cout, int taps, int cin, hipStream_t s) {
   const size_t n = (size_t)cout * taps * cin;
   hipLaunchKernelGGL(pack_dgrad_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, w, out, cout, taps, cin);
+  return LAUNCH_OK();
+}
+
+int spk_launch_pack_multi(const float* pbuf, bf16_t* wpack, const PackTable& t, hipStream_t s) {
+  if (t.count <= 0) return 0;
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(48, t.count), dim3(256), 0, s, pbuf, wpack, t);
   return LAUNCH_OK();
 }
 
