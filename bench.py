@@ -187,6 +187,8 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)  # noqa: E731
     step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3)}
+    if mode == "train" and sync:
+        sync.close()   # the per-phase profile below runs on rank 0 alone: no collectives from here on
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -199,6 +199,16 @@ int spk_optim_step(spk_model* m, const spk_optim_desc* opt);
  * pointer, element count): what a data-parallel caller all-reduces over RCCL
  * between spk_train_forward_backward and spk_optim_step. */
 int spk_model_grad_buffer(spk_model* m, void** dev_ptr, int64_t* numel);
+/* Data-parallel overlap: the flat gradient buffer is produced back to front (head and layer4 first, the stem
+ * last).  With a callback installed, spk_train_forward_backward reports each contiguous slice [offset, offset +
+ * numel) of the buffer as soon as every kernel that writes it has been ENQUEUED: it records an event on the
+ * model's stream, makes `comm_stream` (a hipStream_t) wait for it, then calls cb(user, bucket, offset, numel)
+ * on the calling host thread.  The callee starts its collective on `comm_stream` (torch: `dist.all_reduce(view,
+ * async_op=True)` under `torch.cuda.stream(comm)`), which then runs beside the rest of the backward pass.
+ * n_buckets 1..3 (slices: head + last stage | the stage before | everything earlier); cb == NULL removes it. */
+typedef void (*spk_grad_ready_fn)(void* user, int bucket, int64_t offset, int64_t numel);
+int spk_model_set_grad_ready_callback(spk_model* m, spk_grad_ready_fn cb, void* user, void* comm_stream,
+                                      int n_buckets);
 /* Gradient of one tensor, copied to host in state_dict layout (tests). */
 int spk_model_read_grad(spk_model* m, const char* key, void* host, int64_t numel);
 

@@ -99,6 +99,13 @@ struct spk_model {
   int cur_gate_stride = 0;
   std::vector<float> t_fp8_scale;    // per tensor: 0 = 16-bit storage, else value = byte * scale
 
+  // data-parallel overlap (spk_model_set_grad_ready_callback)
+  spk_grad_ready_fn grad_cb = nullptr;
+  void* grad_cb_user = nullptr;
+  hipStream_t comm_stream = nullptr;
+  int grad_buckets = 0;
+  hipEvent_t grad_ev[3] = {nullptr, nullptr, nullptr};
+
   uint64_t seed = 0;
   TrainState* train = nullptr;
 

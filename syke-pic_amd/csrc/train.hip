@@ -322,6 +322,9 @@ int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cou
   return SPK_OK;
 }
 
+static int grad_bucket_of(const spk_model* m, const Layer& L);
+static int grad_bucket_done(spk_model* m, int b);
+
 extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, int h, int w, int layout,
                                           int dtype, const int64_t* y, float* stats, float* logits_out) {
   if (!m || !x || !y || !stats || n < 1) return tfail(SPK_ERR_ARG, "train step: bad arguments");
@@ -422,10 +425,15 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   // ------------------------------ backward ------------------------------
   std::vector<char> has_grad(m->n_tensors, 0);
   has_grad[last] = 1;
+  int cur_bucket = 0;
   for (int i = nl - 1; i >= 0; --i) {
     Layer& L = m->layers[i];
     const TDim& in = m->tdims[L.d.src];
     const TDim& o = m->tdims[L.d.dst];
+    if (m->grad_cb && (L.d.kind == SPK_OP_CONV || L.d.kind == SPK_OP_LINEAR)) {
+      const int b = grad_bucket_of(m, L);
+      while (cur_bucket < b) SPK_TRY(grad_bucket_done(m, cur_bucket++));   // backward has left that stage
+    }
     if (!has_grad[L.d.dst]) continue;
     switch (L.d.kind) {
       case SPK_OP_LINEAR: {
@@ -495,6 +503,52 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
       }
     }
   }
+  if (m->grad_cb)
+    while (cur_bucket < m->grad_buckets) SPK_TRY(grad_bucket_done(m, cur_bucket++));
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_grad_ready_callback(spk_model* m, spk_grad_ready_fn cb, void* user, void* comm_stream,
+                                                 int n_buckets) {
+  if (!m || (cb && (n_buckets < 1 || n_buckets > 3))) return tfail(SPK_ERR_ARG, "set_grad_ready_callback: bad arguments");
+  HIP_TRY(hipSetDevice(m->device));
+  m->grad_cb = cb;
+  m->grad_cb_user = user;
+  m->comm_stream = (hipStream_t)comm_stream;
+  m->grad_buckets = cb ? n_buckets : 0;
+  for (int i = 0; i < 3; ++i)
+    if (cb && i < n_buckets && !m->grad_ev[i]) HIP_TRY(hipEventCreateWithFlags(&m->grad_ev[i], hipEventDisableTiming));
+  return SPK_OK;
+}
+
+// Bucket of the flat gradient buffer a layer's parameters belong to (0 = produced first by backward): with B
+// buckets the last B-1 conv stages (by `child` index of the owning module) get one each, front to back.
+static int grad_bucket_of(const spk_model* m, const Layer& L) {
+  if (m->grad_buckets <= 1) return 0;
+  int top = -1;
+  for (const Layer& Q : m->layers) if (Q.d.kind == SPK_OP_CONV) top = std::max(top, Q.d.child);
+  if (L.d.child < 0) return 0;                       // head
+  const int b = top - L.d.child;                     // 0 for the last conv stage
+  return std::min(b, m->grad_buckets - 1);
+}
+
+// every kernel writing bucket `b` is enqueued: fence it for the communication stream and tell the caller
+static int grad_bucket_done(spk_model* m, int b) {
+  // slice of the flat buffer = offsets of the trainable tensors of the bucket's layers (contiguous: parameters are
+  // laid out in state_dict order, stage by stage)
+  size_t lo = (size_t)-1, hi = 0;
+  for (const Param& p : m->params) {
+    if (!p.trainable || p.layer < 0) continue;
+    if (grad_bucket_of(m, m->layers[p.layer]) != b) continue;
+    lo = std::min(lo, p.off);
+    hi = std::max(hi, p.off + (size_t)((p.numel + 63) / 64 * 64));
+  }
+  if (lo == (size_t)-1) return SPK_OK;
+  if (b == m->grad_buckets - 1) lo = 0;              // the last bucket reaches to the front of the buffer
+  if (b == 0) hi = m->n_train;
+  HIP_TRY(hipEventRecord(m->grad_ev[b], m->stream));
+  if (m->comm_stream != m->stream) HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->grad_ev[b], 0));
+  m->grad_cb(m->grad_cb_user, b, (int64_t)lo, (int64_t)(hi - lo));
   return SPK_OK;
 }
 

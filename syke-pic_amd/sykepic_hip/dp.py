@@ -75,9 +75,16 @@ def shard_indices(indices, rank, world, pad=True):
 
 
 class GradSync:
-    """All-reduce of the library's flat gradient buffer."""
+    """All-reduce of the library's flat gradient buffer.
 
-    def __init__(self, net, dist=None, view=None):
+    overlap=True (the default on the GPU with more than one rank): the buffer is reduced in up to three slices
+    that the library reports back to front while the backward pass is still running (head + last stage first, the
+    stem last; `spk_model_set_grad_ready_callback`): each slice's collective is enqueued on a communication
+    stream behind an event, so the 96 MB of ResNet-50 gradients cross xGMI underneath the remaining dgrad / wgrad
+    kernels instead of after them; `all_reduce()` then only waits for the collectives still in flight.  xGMI is a
+    point-to-point mesh: few large messages (3 x 16-64 MB) keep every link busy, many small buckets would not."""
+
+    def __init__(self, net, dist=None, view=None, overlap=None, buckets=3):
         self.net, self.dist = net, dist
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         if view is not None:          # CPU/gloo tests pass a host tensor
@@ -85,10 +92,39 @@ class GradSync:
         else:
             ptr, numel = net.grad_buffer()
             self.flat = torch.as_tensor(_DevicePtr(ptr, numel), device=net.device)
+        self._works, self._cb, self._comm = [], None, None
+        if overlap is None:
+            overlap = self.world > 1 and view is None and os.environ.get("SPK_DP_OVERLAP", "1") != "0"
+        if overlap and view is None and self.world > 1:
+            self._install(buckets)
+
+    def _install(self, buckets):
+        from . import lib
+        self._comm = torch.cuda.Stream(device=self.net.device)
+
+        def ready(_user, bucket, offset, numel):
+            # called by the library inside forward_backward, after it made the communication stream wait for
+            # the kernels that write flat[offset : offset + numel]
+            with torch.cuda.stream(self._comm):
+                self._works.append(self.dist.all_reduce(self.flat[offset:offset + numel], op=self.dist.ReduceOp.SUM,
+                                                        async_op=True))
+
+        self._cb = lib.GRAD_READY_FN(ready)   # keep the ctypes thunk alive as long as the handle may call it
+        self.net.set_grad_ready_callback(self._cb, self._comm.cuda_stream, buckets)
+
+    def close(self):
+        if self._cb is not None:
+            self.net.set_grad_ready_callback(None, 0, 0)
+            self._cb = None
 
     def all_reduce(self, optimizer=None):
         if self.world > 1:
-            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+            if self._cb is not None:
+                for w in self._works:     # makes the current stream wait for each collective
+                    w.wait()
+                self._works = []
+            else:
+                self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
 

@@ -79,6 +79,7 @@ SYMBOLS = {
                                              _P, _P, _P]),
     "spk_optim_step": (C.c_int, [_P, C.POINTER(OptimDesc)]),
     "spk_model_grad_buffer": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "spk_model_set_grad_ready_callback": (C.c_int, [_P, _P, _P, _P, C.c_int]),
     "spk_model_read_grad": (C.c_int, [_P, C.c_char_p, _P, C.c_int64]),
     "spk_model_read_activation": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
     "spk_model_read_activation_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int64]),
@@ -96,6 +97,8 @@ SYMBOLS = {
     "spk_model_profile_train": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
                                           C.c_int, C.POINTER(LayerTime), C.c_int]),
 }
+
+GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int64)
 
 _lib = None
 

@@ -484,6 +484,15 @@ class HipNet:
             lib.check(self._lib.spk_model_set_stream(self._h, self._stream()))
             lib.check(self._lib.spk_optim_step(self._h, C.byref(desc)))
 
+    def set_grad_ready_callback(self, cb, comm_stream, buckets):
+        """Install (cb = a lib.GRAD_READY_FN) or remove (cb = None) the gradient-slice callback of the training
+        step (data-parallel overlap; include/sykepic_hip.h)."""
+        self._ensure_init()
+        with torch.cuda.device(self.device):
+            lib.check(self._lib.spk_model_set_grad_ready_callback(
+                self._h, C.cast(cb, C.c_void_p) if cb is not None else None, None,
+                C.c_void_p(int(comm_stream)) if comm_stream else None, int(buckets)))
+
     def grad_buffer(self):
         """(device pointer, numel) of the flat fp32 gradient buffer."""
         ptr, n = C.c_void_p(), C.c_int64()

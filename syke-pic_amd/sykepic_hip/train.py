@@ -241,12 +241,14 @@ def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epo
                 lr_scheduler.step(val_loss)
     except KeyboardInterrupt:
         print("[INFO] Stopping early")
+        sync.close()
     except Exception as e:  # the reference swallows every error here (quirk Q5)
         print(f"[ERROR] {e}")
         if parallel:
             # ... but one replica leaving the loop would leave the others blocked in the next all-reduce:
             # under data parallelism the error ends the rank (non-zero exit; the launcher stops the job)
             raise
+    sync.close()
     return best_state
 
 

@@ -40,6 +40,52 @@ def test_grad_buffer_view_aliases_library_memory():
     assert torch.allclose(net._read_grad("head.2.bias", (10,)), 2 * before)
 
 
+def test_gradient_slices_are_reported_back_to_front_and_complete():
+    """The overlap hook of the data-parallel step (spk_model_set_grad_ready_callback): the library reports the
+    flat gradient buffer in three contiguous slices, head + last stage first, covering it exactly once, and each
+    slice is final when the communication stream runs the callee's work: doubling every slice on that stream (what
+    a 2-rank sum of equal gradients does) must give exactly 2 x the gradients of a step without the hook."""
+    from sykepic_hip import lib
+    from sykepic_hip.dp import _DevicePtr
+    from sykepic_hip.net import HipNet
+    g = arch.build_graph("resnet18", 10)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=5, logit_gain=2.0)
+    net = HipNet("resnet18", 10, weights=None)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    x = torch.from_numpy(synth.synth_images(8, 3, 64, 64, seed=10)).cuda()
+    y = torch.from_numpy(synth.synth_labels(8, 10, seed=11)).cuda()
+    net.train()
+    net.forward_backward(x, y)
+    ptr, numel = net.grad_buffer()
+    flat = torch.as_tensor(_DevicePtr(ptr, numel), device=net.device)
+    torch.cuda.synchronize()
+    base = flat.clone()
+    comm = torch.cuda.Stream()
+    seen = []
+
+    def ready(_user, bucket, offset, n):
+        seen.append((bucket, offset, n))
+        with torch.cuda.stream(comm):
+            flat[offset:offset + n].mul_(2.0)
+
+    cb = lib.GRAD_READY_FN(ready)
+    net.set_grad_ready_callback(cb, comm.cuda_stream, 3)
+    net.forward_backward(x, y)
+    torch.cuda.current_stream().wait_stream(comm)
+    torch.cuda.synchronize()
+    net.set_grad_ready_callback(None, 0, 0)
+    assert [b for b, _, _ in seen] == [0, 1, 2]
+    spans = sorted((o, o + n) for _, o, n in seen)
+    assert spans[0][0] == 0 and spans[-1][1] == numel and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert seen[0][1] > seen[1][1] > seen[2][1] == 0            # back to front
+    head_off = seen[0][1]
+    assert head_off < numel - 10 * 128 - 128                    # the head lies inside the first slice
+    assert torch.equal(flat, 2 * base)
+    net.forward_backward(x, y)                                   # hook removed: plain gradients again
+    torch.cuda.synchronize()
+    assert torch.equal(flat, base)
+
+
 def test_bench_two_ranks_like_the_driver(tmp_path):
     env = dict(os.environ, SPK_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",

@@ -9,8 +9,19 @@ Takes the conv_igemm_kernel dispatches of ONE steady-state forward pass (the
 dispatches between the last two to_nhwc4_kernel launches), so autotuning
 launches are excluded."""
 import csv
+import hashlib
 import json
 import sys
+from pathlib import Path
+
+
+def kernel_source_sha():
+    """Same digest as bench.py: the figure is only quoted by bench.py for the kernel sources it was taken on."""
+    h = hashlib.sha256()
+    for f in sorted((Path(__file__).resolve().parent.parent / "syke-pic_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def one_pass(path):
@@ -32,6 +43,7 @@ def main():
     all_w = sum(float(r["Counter_Value"]) for r in w)
     res = {
         "kernel": "conv_igemm_kernel",
+        "kernel_src_sha": kernel_source_sha(),
         "launches_per_step": len(conv_f),
         "fetch_bytes_per_step": sum(conv_f) * 1024 * 2,
         "write_bytes_per_step": sum(conv_w) * 1024,
