@@ -256,6 +256,11 @@ int spk_op_conv_wgrad(const void* x_dev, const void* dy_dev, float* dw_dev, int 
 int spk_op_pw_fp8(const void* x_dev, int a_fp8, const float* w_dev, void* y_dev, int out_fp8, const void* res_dev,
                   const float* bn_scale_dev, const float* bn_bias_dev, const float* gate_dev, int hw, int m_rows, int cin,
                   int cout, int act, float a_scale, float y_scale, void* hip_stream);
+/* Depthwise Conv2d(C, C, k, stride, pad (k-1)/2, groups=C) + folded BatchNorm + activation (EfficientNet MBConv):
+ * x [n,h,w,C] fp16 NHWC, w float32 [C][k*k], y [n,ho,wo,C] fp16; pool (optional) float32 [n][C] = per-image sums of
+ * the outputs (squeeze-excitation numerator).  lds != 0: the LDS-staged kernel, else the gather kernel. */
+int spk_op_dwconv(const void* x_dev, const float* w_dev, const float* bn_scale_dev, const float* bn_bias_dev, void* y_dev,
+                  float* pool_dev, int n, int h, int w, int channels, int k, int stride, int act, int lds, void* hip_stream);
 
 /* --- ROI preprocessing straight from the .roi blob ---
  * One ROI of an IFCB sample: byte offset into the .roi blob, width, height

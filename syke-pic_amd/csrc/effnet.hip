@@ -171,12 +171,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
 #pragma unroll
           for (int j = 0; j < 4; ++j) { wrow[q][j] = w0[j]; wrow[q][4 + j] = w1[j]; }
         }
+        // all COLS loads of the row are issued before the first use: unconditional (column clamped into the
+        // image, value zeroed by a select), so no branch separates them and their latencies overlap
+        u32x4_t raw[COLS];
 #pragma unroll
         for (int col = 0; col < COLS; ++col) {
           const int ix = ox0 * S - PAD + col;
-          if ((unsigned)ix >= (unsigned)wid) continue;
+          const int ixc = min(max(ix, 0), wid - 1);
+          raw[col] = *(const u32x4_t*)(xi + ((size_t)iy * wid + ixc) * c_p);
+          if ((unsigned)ix >= (unsigned)wid) raw[col] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int col = 0; col < COLS; ++col) {
           float xv[8];
-          unpack8f<DT>(*(const u32x4_t*)(xi + ((size_t)iy * wid + ix) * c_p), xv);
+          unpack8f<DT>(raw[col], xv);
 #pragma unroll
           for (int u = 0; u < PX; ++u) {
             const int q = col - u * S;  // tap of output u that this column feeds

@@ -95,6 +95,7 @@ struct spk_model {
   bool fp8_packed = false;
   unsigned char* w8pack = nullptr;
   float* s8 = nullptr;
+  int cur_dw_chunks = 0;             // pool-partial rows per image the depthwise layer that ran last wrote
   const float* cur_gate = nullptr;   // gates of the squeeze-excitation op that ran last (consumed by the project conv)
   int cur_gate_stride = 0;
   std::vector<float> t_fp8_scale;    // per tensor: 0 = 16-bit storage, else value = byte * scale

@@ -648,8 +648,9 @@ int spk_plan(spk_model* m, int n, int h, int w) {
     if (L.d.kind != SPK_OP_SE) continue;
     const TDim& d = m->tdims[L.d.src];
     // partials [n][chunks][c] (chunks(1) >= chunks(nb)), scales [n][c], hidden units [n][squeeze]
-    const int ch = std::max(spk_dw_chunks(1, d.h * ((d.w + 3) / 4), d.c), spk_dw_chunks(1, d.h * ((d.w + 1) / 2), d.c));
-    se_floats = std::max(se_floats, (size_t)n * ((ch + 1) * d.c + L.d.k));
+    // pool partials [n][chunks][c] of whichever depthwise kernel runs (chunks <= 64 for all of them), scales [n][c],
+    // hidden units [n][squeeze]
+    se_floats = std::max(se_floats, (size_t)n * ((64 + 1) * d.c + L.d.k));
   }
   m->se_off = total;
   total += align256(se_floats * 4);
@@ -720,6 +721,58 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   return SPK_OK;
 }
 
+// Depthwise layers have two kernels (effnet.hip / pw_fp8.hip: per-thread gather; dwconv_lds.hip: input rows staged
+// through LDS).  Neither wins everywhere (B4, batch 256: the LDS ring is 1.3-1.6x faster on the k5 stride-1 layers at
+// 28^2 / 14^2 and up to 2x slower on the 112^2 / 56^2 layers, whose rows take several passes per iteration), so each
+// distinct problem is timed once per process with both and the winner remembered (both give the same values up to
+// the fp32 summation order of the pool partials).  SPK_DW_LDS=0 / 1 forces one.
+#include <map>
+#include <mutex>
+#include <tuple>
+static int dw_forced() {
+  static const int v = getenv("SPK_DW_LDS") ? atoi(getenv("SPK_DW_LDS")) : -1;
+  return v;
+}
+static std::map<std::tuple<int, int, int, int, int, int, int>, int> g_dw_choice;
+static std::mutex g_dw_mu;
+
+template <class F>
+static int dw_choose(int et, int nb, int h, int w, int c, int k, int s, hipStream_t st, F run, const int* chunks) {
+  // candidates: 0 gather kernel, 1 LDS ring kernel; chunks[v] == 0: cannot run this problem
+  if (dw_forced() >= 0) {
+    const int v = dw_forced();
+    if (v < 2 && chunks[v] > 0) return v;
+    return 0;
+  }
+  const auto key = std::make_tuple(et, nb, h, w, c, k, s);
+  {
+    std::lock_guard<std::mutex> lk(g_dw_mu);
+    auto it = g_dw_choice.find(key);
+    if (it != g_dw_choice.end()) return it->second;
+  }
+  hipEvent_t e0, e1;
+  int best = 0;
+  if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    float t[2] = {1e30f, 1e30f};
+    for (int v = 0; v < 2; ++v) {
+      if (chunks[v] <= 0 || run(v) != 0) continue;   // warm-up
+      (void)hipEventRecord(e0, st);
+      for (int r = 0; r < 3; ++r) (void)run(v);
+      (void)hipEventRecord(e1, st);
+      if (hipEventSynchronize(e1) == hipSuccess) (void)hipEventElapsedTime(&t[v], e0, e1);
+    }
+    if (t[1] < t[0]) best = 1;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("SPK_TUNE_LOG"))
+      fprintf(stderr, "[spk tune] depthwise et %d N%d %dx%d C%d k%d s%d: gather %.1f us, lds %.1f us\n", et, nb, h, w, c, k, s,
+              t[0] * 1000.f / 3.f, t[1] * 1000.f / 3.f);
+  }
+  std::lock_guard<std::mutex> lk(g_dw_mu);
+  g_dw_choice[key] = best;
+  return best;
+}
+
 // fp8 mode: the four layers of an MBConv block with e4m3 tensors between them (pw_fp8.hip)
 static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
@@ -739,17 +792,28 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
     case 2: {   // depthwise on e4m3; pool partials for the squeeze-excitation gate as in the fp16 kernel
       const float ys = fp8_scale_of(L.amax_out);
       m->t_fp8_scale[L.d.dst] = ys;
-      const int chunks = spk_dw_chunks(nb, o.h * ((o.w + 1) / 2), in.c);
-      if (spk_launch_dwconv_fp8((const unsigned char*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                                (unsigned char*)m->T(L.d.dst), (float*)((char*)m->arena + m->se_off), nb, in.h, in.w,
-                                in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu, chunks, fp8_scale_of(L.amax_in), 1.f / ys,
-                                m->stream))
+      float* partial = (float*)((char*)m->arena + m->se_off);
+      const float s_in = fp8_scale_of(L.amax_in);
+      const int chunks[2] = {spk_dw_chunks(nb, o.h * ((o.w + 1) / 2), in.c),
+                             spk_dwconv_lds_chunks(1, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride)};
+      auto run = [&](int v) {
+        if (v)
+          return spk_launch_dwconv_lds(1, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst),
+                                       partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu, s_in, 1.f / ys,
+                                       m->stream);
+        return spk_launch_dwconv_fp8((const unsigned char*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                                     (unsigned char*)m->T(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k,
+                                     L.d.stride, L.d.relu, chunks[0], s_in, 1.f / ys, m->stream);
+      };
+      const int v = dw_choose(1, nb, in.h, in.w, in.c, L.d.k, L.d.stride, m->stream, run, chunks);
+      m->cur_dw_chunks = chunks[v];
+      if (run(v) != 0)
         return fail(SPK_ERR_HIP, std::string("fp8 depthwise launch failed for ") + L.d.name);
       return SPK_OK;
     }
     case 3: {   // squeeze-excitation: the gates only; the project conv multiplies them into its A operand
       float* partial = (float*)((char*)m->arena + m->se_off);
-      const int chunks = spk_dw_chunks(nb, in.h * ((in.w + 1) / 2), in.c);
+      const int chunks = m->cur_dw_chunks;
       float* gate = partial + (size_t)nb * chunks * in.c;
       if (spk_launch_se(nullptr, nullptr, partial, chunks, gate, m->P(L.p_w), m->P(L.p_b), m->dwpack + L.wpack_off,
                         m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k, DT_F16, m->stream))
@@ -784,10 +848,23 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
     case SPK_OP_CONV: return run_conv_eval(m, L, nb);
     case SPK_OP_DWCONV: {
       const float* sc = m->scale_bias + L.sb_off;
+      float* partial = (float*)((char*)m->arena + m->se_off);
       // the pool partial sums of the squeeze-excitation gate that follows are a by-product
-      if (spk_launch_dwconv((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                            (bf16_t*)m->T(L.d.dst), (float*)((char*)m->arena + m->se_off), nb, in.h, in.w, in.c, o.h,
-                            o.w, L.d.k, L.d.stride, L.d.relu, m->infer_dt, m->stream))
+      const bool f16 = m->infer_dt == DT_F16;
+      const int chunks[2] = {spk_dw_chunks(nb, o.h * ((o.w + 3) / 4), in.c),
+                             f16 ? spk_dwconv_lds_chunks(0, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride) : 0};
+      auto run = [&](int v) {
+        if (v)
+          return spk_launch_dwconv_lds(0, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst),
+                                       partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu, 1.f, 1.f,
+                                       m->stream);
+        return spk_launch_dwconv((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                                 (bf16_t*)m->T(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride,
+                                 L.d.relu, m->infer_dt, m->stream);
+      };
+      const int v = dw_choose(0, nb, in.h, in.w, in.c, L.d.k, L.d.stride, m->stream, run, chunks);
+      m->cur_dw_chunks = chunks[v];
+      if (run(v) != 0)
         return fail(SPK_ERR_UNSUPPORTED, std::string("depthwise conv launch failed (fp16 eval only) for ") + L.d.name);
       return SPK_OK;
     }
@@ -797,7 +874,7 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       for (const Layer& Q : m->layers) from_dw |= (Q.d.kind == SPK_OP_DWCONV && Q.d.dst == L.d.src);
       if (!from_dw) return fail(SPK_ERR_UNSUPPORTED, "squeeze-excitation must follow a depthwise conv");
       float* partial = (float*)((char*)m->arena + m->se_off);
-      const int chunks = spk_dw_chunks(nb, in.h * ((in.w + 3) / 4), in.c);  // as the depthwise launch: groups of 4 outputs
+      const int chunks = m->cur_dw_chunks;   // as the depthwise launch that just ran
       float* scale = partial + (size_t)nb * chunks * in.c;
       if (spk_launch_se((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), partial, chunks, scale, m->P(L.p_w),
                         m->P(L.p_b), m->dwpack + L.wpack_off, m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,

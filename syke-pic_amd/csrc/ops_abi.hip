@@ -161,3 +161,38 @@ extern "C" int spk_op_pw_fp8(const void* x, int a_fp8, const float* w, void* y, 
   if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_pw_fp8: kernel failed");
   return SPK_OK;
 }
+
+// Depthwise conv + folded BN + activation through the LDS-staged kernel (dwconv_lds.hip; lds != 0) or the gather
+// kernel (effnet.hip; lds 0), fp16 NHWC tensors, w: float32 [C][k*k].  pool_out (optional): float32 [n][C] sums of the outputs
+// over each image (the squeeze-excitation pool numerator).
+extern "C" int spk_op_dwconv(const void* x, const float* w, const float* bn_scale, const float* bn_bias, void* y,
+                             float* pool_out, int n, int h, int wid, int c, int k, int stride, int act, int lds,
+                             void* stream) {
+  if (!x || !w || !bn_scale || !bn_bias || !y || n < 1 || c % 8) return ofail(SPK_ERR_ARG, "op_dwconv: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int pad = (k - 1) / 2, ho = (h + 2 * pad - k) / stride + 1, wo = (wid + 2 * pad - k) / stride + 1;
+  Scratch sc;
+  float* wt = sc.get<float>((size_t)k * k * c);
+  int chunks = lds ? spk_dwconv_lds_chunks(0, n, h, wid, c, ho, wo, k, stride) : spk_dw_chunks(n, ho * ((wo + 3) / 4), c);
+  if (lds && chunks <= 0) return ofail(SPK_ERR_UNSUPPORTED, "op_dwconv: the LDS kernel cannot run this shape");
+  float* partial = sc.get<float>((size_t)n * chunks * c);
+  if (!wt || !partial) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pack_tapmajor(w, wt, c, k * k, c, s), "pack_tapmajor");
+  int r;
+  if (lds)
+    r = spk_launch_dwconv_lds(0, x, wt, bn_scale, bn_bias, y, partial, n, h, wid, c, ho, wo, k, stride, act, 1.f, 1.f, s);
+  else
+    r = spk_launch_dwconv((const bf16_t*)x, wt, bn_scale, bn_bias, (bf16_t*)y, partial, n, h, wid, c, ho, wo, k, stride, act,
+                          DT_F16, s);
+  if (r) return ofail(SPK_ERR_HIP, "op_dwconv: launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_dwconv: kernel failed");
+  if (pool_out) {
+    std::vector<float> hp((size_t)n * chunks * c), out((size_t)n * c, 0.f);
+    if (hipMemcpy(hp.data(), partial, hp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return ofail(SPK_ERR_HIP, "copy failed");
+    for (int i = 0; i < n; ++i)
+      for (int q = 0; q < chunks; ++q)
+        for (int ch = 0; ch < c; ++ch) out[(size_t)i * c + ch] += hp[((size_t)i * chunks + q) * c + ch];
+    if (hipMemcpy(pool_out, out.data(), out.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return ofail(SPK_ERR_HIP, "copy failed");
+  }
+  return SPK_OK;
+}

@@ -357,14 +357,20 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
       for (int r = 0; r < K; ++r) {
         const int iy = oy * S - PAD + r;
         if ((unsigned)iy >= (unsigned)h) continue;
+        // all COLS loads of the row before the first use: unconditional, clamped column, zeroed by a select
+        u32x4_t raw[COLS];
 #pragma unroll
         for (int col = 0; col < COLS; ++col) {
           const int ix = ox0 * S - PAD + col;
-          if ((unsigned)ix >= (unsigned)wid) continue;
-          const u32x4_t raw = *(const u32x4_t*)(xi + ((size_t)iy * wid + ix) * c_p);
+          const int ixc = min(max(ix, 0), wid - 1);
+          raw[col] = *(const u32x4_t*)(xi + ((size_t)iy * wid + ixc) * c_p);
+          if ((unsigned)ix >= (unsigned)wid) raw[col] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int col = 0; col < COLS; ++col) {
           float xv[CPT];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) cvt4_f32(raw[q], xv + 4 * q);
+          for (int q = 0; q < 4; ++q) cvt4_f32(raw[col][q], xv + 4 * q);
 #pragma unroll
           for (int u = 0; u < PX; ++u) {
             const int q = col - u * S;  // tap of output u that this column feeds

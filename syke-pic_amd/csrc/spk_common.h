@@ -136,6 +136,11 @@ int spk_launch_dwconv_fp8(const unsigned char* x, const float* w, const float* s
                           float* partial, int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act,
                           int chunks, float in_scale, float out_inv_scale, hipStream_t s);
 int spk_launch_mul3(const float* a, const float* b, float c, float* out, int n, hipStream_t s);
+// LDS-staged depthwise conv (dwconv_lds.hip): et 0 fp16 tensors, 1 e4m3 tensors
+int spk_dwconv_lds_chunks(int et, int n, int h, int wid, int c_p, int ho, int wo, int k, int stride);
+int spk_launch_dwconv_lds(int et, const void* x, const float* w, const float* scale, const float* bias, void* y,
+                          float* partial, int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act,
+                          float w_scale, float out_inv_scale, hipStream_t s);
 
 // ---------------------------------------------------------------------------
 // Head (head.hip): fp32 Linear layers, softmax, cross-entropy

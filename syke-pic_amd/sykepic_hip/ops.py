@@ -139,3 +139,21 @@ def pw_fp8(x, weight, bn_scale, bn_bias, act=0, a_scale=1.0, y_scale=1.0, out_fp
                                    _p(gate.float().contiguous()) if gate is not None else None, int(hw), m, cin, cout,
                                    int(act), float(a_scale), float(y_scale), _stream(dev)))
     return y
+
+
+def dwconv(x, weight, bn_scale, bn_bias, k, stride=1, act=2, lds=1):
+    """Depthwise conv + folded BN + activation (spk_op_dwconv).  x [N,C,H,W] float16, weight [C,1,k,k];
+    returns (y [N,C,Ho,Wo] float16, pool [N,C] float32 sums of y before rounding)."""
+    so = lib.load()
+    dev = x.device
+    n, c, h, w = x.shape
+    pad = (k - 1) // 2
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    xh = x.half().permute(0, 2, 3, 1).contiguous()
+    y = torch.full((n, ho, wo, c), float("nan"), dtype=torch.float16, device=dev)
+    pool = torch.empty((n, c), dtype=torch.float32, device=dev)
+    wk = weight.float().reshape(c, k * k).contiguous()
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_dwconv(_p(xh), _p(wk), _p(bn_scale.float().contiguous()), _p(bn_bias.float().contiguous()),
+                                   _p(y), _p(pool), n, h, w, c, k, stride, int(act), int(lds), _stream(dev)))
+    return y.permute(0, 3, 1, 2), pool

@@ -66,6 +66,35 @@ def test_efficientnet_probabilities_match_reference_golden(golden_dir, network):
     assert (pg.argmax(1) == pr.argmax(1)).mean() >= 0.9
 
 
+@pytest.mark.parametrize("case", [(3, 48, 56, 56, 3, 1), (2, 144, 57, 45, 3, 2), (2, 336, 28, 28, 5, 1), (3, 192, 29, 31, 5, 2),
+                                  (2, 672, 14, 14, 3, 1), (4, 1632, 7, 7, 5, 1), (2, 2688, 7, 7, 3, 1), (1, 40, 112, 112, 3, 1),
+                                  (2, 24, 33, 9, 5, 1)],
+                         ids=lambda c: "n%d_c%d_%dx%d_k%ds%d" % c)
+def test_depthwise_kernels_match_torch(case):
+    """Depthwise KxK conv + folded BN + SiLU, both kernels (LDS-staged ring of input rows, dwconv_lds.hip; per-thread
+    gather, effnet.hip), against F.conv2d(groups=C) on the same fp16 input: odd / non-square sizes, stride 2, channel
+    counts that do not fill a channel slab, bands that end mid-image.  fp32 accumulation of <= 25 taps: 2e-3 of the
+    tensor maximum (fp16 output rounding), and the squeeze-excitation pool sums to 1e-4."""
+    import torch.nn.functional as F
+    from sykepic_hip import ops
+    n, c, h, w, k, s = case
+    g = torch.Generator().manual_seed(c + h)
+    x = (torch.randn((n, c, h, w), generator=g)).half()
+    wt = torch.randn((c, 1, k, k), generator=g) * (1.0 / k)
+    sc = torch.rand(c, generator=g) + 0.5
+    bi = torch.randn(c, generator=g) * 0.3
+    v = F.conv2d(x.float(), wt, None, s, (k - 1) // 2, groups=c) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)
+    want = v * torch.sigmoid(v)
+    for lds in (1, 0):
+        y, pool = ops.dwconv(x.cuda(), wt.cuda(), sc.cuda(), bi.cuda(), k, s, act=2, lds=lds)
+        y, pool = y.float().cpu(), pool.cpu()
+        assert torch.isfinite(y).all(), "unwritten outputs"
+        err = float((y - want).abs().max() / want.abs().max())
+        perr = float((pool - want.sum((2, 3))).abs().max() / want.sum((2, 3)).abs().max())
+        print(f"dwconv {case} lds={lds}: max error / max {err:.2e}, pool {perr:.2e}")
+        assert err < 2e-3 and perr < 1e-4
+
+
 def test_efficientnet_odd_size_u8_and_no_training():
     """Ragged image size (odd height/width), uint8 NHWC input, and the training entry points
     refusing a network that has an inference path only."""
