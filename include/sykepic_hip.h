@@ -258,7 +258,7 @@ int spk_op_pw_fp8(const void* x_dev, int a_fp8, const float* w_dev, void* y_dev,
                   int cout, int act, float a_scale, float y_scale, void* hip_stream);
 /* Depthwise Conv2d(C, C, k, stride, pad (k-1)/2, groups=C) + folded BatchNorm + activation (EfficientNet MBConv):
  * x [n,h,w,C] fp16 NHWC, w float32 [C][k*k], y [n,ho,wo,C] fp16; pool (optional) float32 [n][C] = per-image sums of
- * the outputs (squeeze-excitation numerator).  lds != 0: the LDS-staged kernel, else the gather kernel. */
+ * the outputs (squeeze-excitation numerator).  lds != 0: the LDS row-ring kernel, else the gather kernel. */
 int spk_op_dwconv(const void* x_dev, const float* w_dev, const float* bn_scale_dev, const float* bn_bias_dev, void* y_dev,
                   float* pool_dev, int n, int h, int w, int channels, int k, int stride, int act, int lds, void* hip_stream);
 

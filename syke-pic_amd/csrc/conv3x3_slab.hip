@@ -253,7 +253,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64) void conv3x3_slab_kernel(Con
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
         } else if (a.relu == 2) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
+          for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
         }
         u32x4_t ov;
 #pragma unroll

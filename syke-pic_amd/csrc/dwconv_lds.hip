@@ -15,48 +15,13 @@
 //
 // ET = 0: fp16 in / out (the parity path).  ET = 1: e4m3 in / out (fp8 mode, pw_fp8.hip): the caller folds the
 // input scale into the weights; the output is v * out_inv_scale.
-#include "spk_common.h"
+#include "dw_util.h"
 
 #include <algorithm>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-
-template <int ET> struct DwT;
-template <> struct DwT<0> { static constexpr int CPT = 8, PX = 4, ELEM = 2; };
-template <> struct DwT<1> { static constexpr int CPT = 16, PX = 2, ELEM = 1; };
-
-template <int ET>
-__device__ __forceinline__ void unpack16B(const u32x4_t v, float* f) {
-  if (ET == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { f[2 * j] = lo_f32<DT_F16>(v[j]); f[2 * j + 1] = hi_f32<DT_F16>(v[j]); }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[j], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[j], true);
-      f[4 * j] = lo[0]; f[4 * j + 1] = lo[1]; f[4 * j + 2] = hi[0]; f[4 * j + 3] = hi[1];
-    }
-  }
-}
-template <int ET>
-__device__ __forceinline__ u32x4_t pack16B(const float* f, float s) {
-  u32x4_t o;
-  if (ET == 0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = pack2<DT_F16>(f[2 * j], f[2 * j + 1]);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float a = fminf(fmaxf(f[4 * j] * s, -448.f), 448.f), b = fminf(fmaxf(f[4 * j + 1] * s, -448.f), 448.f);
-      float c = fminf(fmaxf(f[4 * j + 2] * s, -448.f), 448.f), d = fminf(fmaxf(f[4 * j + 3] * s, -448.f), 448.f);
-      int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-      o[j] = (unsigned int)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    }
-  }
-  return o;
-}
+using namespace dwu;
 
 struct DwArgs {
   const unsigned char* x;
@@ -203,13 +168,16 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(DwArgs a) {
       for (int u = 0; u < PX; ++u) {
         if (ox0 + u >= a.wo) continue;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-          float t = acc[u][j] * sc[j] + bi[j];
-          if (a.act == 1) t = fmaxf(t, 0.f);
-          else if (a.act == 2) t = t / (1.f + __expf(-t));
-          acc[u][j] = t;
-          pool[j] += t;
+        for (int j = 0; j < CPT; ++j) acc[u][j] = acc[u][j] * sc[j] + bi[j];
+        if (a.act == 2) {   // uniform branch: one activation's instructions, not both + selects
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) acc[u][j] = silu_f(acc[u][j]);
+        } else if (a.act == 1) {
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) acc[u][j] = fmaxf(acc[u][j], 0.f);
         }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) pool[j] += acc[u][j];
         *(u32x4_t*)(yi + ((size_t)oy * a.wo + ox0 + u) * a.c_p * ELEM) = pack16B<ET>(acc[u], a.out_inv_scale);
       }
     }

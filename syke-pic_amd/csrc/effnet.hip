@@ -32,7 +32,7 @@ __device__ __forceinline__ u32x4_t pack8f(const float* f) {
 }
 __device__ __forceinline__ float act_f(float v, int act) {
   if (act == 1) return fmaxf(v, 0.f);
-  if (act == 2) return v / (1.f + __expf(-v));  // SiLU
+  if (act == 2) return silu_f(v);
   return v;
 }
 
@@ -199,10 +199,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
       for (int u = 0; u < PX; ++u) {
         if (ox0 + u >= wo) continue;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          acc[u][j] = act_f(acc[u][j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j], act);
-          pool[j] += acc[u][j];
+        for (int j = 0; j < 8; ++j) acc[u][j] = acc[u][j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j];
+        if (act == 2) {   // uniform branch: one activation's instructions, not both + selects
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[u][j] = silu_f(acc[u][j]);
+        } else if (act == 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[u][j] = fmaxf(acc[u][j], 0.f);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pool[j] += acc[u][j];
         *(u32x4_t*)(yi + ((size_t)oy * wo + ox0 + u) * c_p) = pack8f<DT>(acc[u]);
       }
     }

@@ -725,7 +725,10 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
 // through LDS).  Neither wins everywhere (B4, batch 256: the LDS ring is 1.3-1.6x faster on the k5 stride-1 layers at
 // 28^2 / 14^2 and up to 2x slower on the 112^2 / 56^2 layers, whose rows take several passes per iteration), so each
 // distinct problem is timed once per process with both and the winner remembered (both give the same values up to
-// the fp32 summation order of the pool partials).  SPK_DW_LDS=0 / 1 forces one.
+// the fp32 summation order of the pool partials).  SPK_DW_LDS=0 / 1 forces one.  (A third kernel - whole zero-padded
+// image of a channel slab in LDS, LDS-DMA double-buffered, one block walking over many images - was built for the
+// 14^2 / 7^2 layers and measured no faster than these two on any layer: those layers are VALU-bound, not latency-
+// bound; removed.)
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -765,7 +768,7 @@ static int dw_choose(int et, int nb, int h, int w, int c, int k, int s, hipStrea
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (getenv("SPK_TUNE_LOG"))
-      fprintf(stderr, "[spk tune] depthwise et %d N%d %dx%d C%d k%d s%d: gather %.1f us, lds %.1f us\n", et, nb, h, w, c, k, s,
+      fprintf(stderr, "[spk tune] depthwise et %d N%d %dx%d C%d k%d s%d: gather %.1f us, lds ring %.1f us\n", et, nb, h, w, c, k, s,
               t[0] * 1000.f / 3.f, t[1] * 1000.f / 3.f);
   }
   std::lock_guard<std::mutex> lk(g_dw_mu);
@@ -798,9 +801,9 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
                              spk_dwconv_lds_chunks(1, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride)};
       auto run = [&](int v) {
         if (v)
-          return spk_launch_dwconv_lds(1, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst),
-                                       partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu, s_in, 1.f / ys,
-                                       m->stream);
+          return spk_launch_dwconv_lds(
+              1, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst), partial, nb, in.h, in.w, in.c,
+              o.h, o.w, L.d.k, L.d.stride, L.d.relu, s_in, 1.f / ys, m->stream);
         return spk_launch_dwconv_fp8((const unsigned char*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
                                      (unsigned char*)m->T(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k,
                                      L.d.stride, L.d.relu, chunks[0], s_in, 1.f / ys, m->stream);
@@ -855,9 +858,9 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
                              f16 ? spk_dwconv_lds_chunks(0, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride) : 0};
       auto run = [&](int v) {
         if (v)
-          return spk_launch_dwconv_lds(0, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst),
-                                       partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride, L.d.relu, 1.f, 1.f,
-                                       m->stream);
+          return spk_launch_dwconv_lds(
+              0, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst), partial, nb, in.h, in.w, in.c,
+              o.h, o.w, L.d.k, L.d.stride, L.d.relu, 1.f, 1.f, m->stream);
         return spk_launch_dwconv((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
                                  (bf16_t*)m->T(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride,
                                  L.d.relu, m->infer_dt, m->stream);

@@ -174,7 +174,7 @@ extern "C" int spk_op_dwconv(const void* x, const float* w, const float* bn_scal
   Scratch sc;
   float* wt = sc.get<float>((size_t)k * k * c);
   int chunks = lds ? spk_dwconv_lds_chunks(0, n, h, wid, c, ho, wo, k, stride) : spk_dw_chunks(n, ho * ((wo + 3) / 4), c);
-  if (lds && chunks <= 0) return ofail(SPK_ERR_UNSUPPORTED, "op_dwconv: the LDS kernel cannot run this shape");
+  if (lds && chunks <= 0) return ofail(SPK_ERR_UNSUPPORTED, "op_dwconv: this kernel cannot run this shape");
   float* partial = sc.get<float>((size_t)n * chunks * c);
   if (!wt || !partial) return ofail(SPK_ERR_HIP, "hipMalloc failed");
   O_TRY(spk_launch_pack_tapmajor(w, wt, c, k * k, c, s), "pack_tapmajor");

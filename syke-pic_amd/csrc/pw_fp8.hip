@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       } else if (a.act == 2) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
+        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
       }
       if (OUT_FP8) {
         const float s = a.y_inv_scale;
@@ -385,17 +385,23 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
 #pragma unroll
       for (int u = 0; u < PX; ++u) {
         if (ox0 + u >= wo) continue;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[u][j] = acc[u][j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j];
+        if (act == 2) {   // uniform branch: one activation's instructions, not both + selects
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) acc[u][j] = silu_f(acc[u][j]);
+        } else if (act == 1) {
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) acc[u][j] = fmaxf(acc[u][j], 0.f);
+        }
         u32x4_t o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float t = acc[u][4 * q + j] * wl[K * K * tc + 4 * q + j] + wl[(K * K + 1) * tc + 4 * q + j];
-            if (act == 1) t = fmaxf(t, 0.f);
-            else if (act == 2) t = t / (1.f + __expf(-t));
-            pool[4 * q + j] += t;
-            v[j] = t * out_inv_scale;
+            pool[4 * q + j] += acc[u][4 * q + j];
+            v[j] = acc[u][4 * q + j] * out_inv_scale;
           }
           o[q] = cvt4_fp8(v[0], v[1], v[2], v[3]);
         }

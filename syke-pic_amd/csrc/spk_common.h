@@ -28,6 +28,14 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
 enum { DT_BF16 = 0, DT_F16 = 1 };
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 
+// SiLU x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division: `x / (1 + exp(-x))`
+// compiles to ~12 VALU instructions per element (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas, v_div_fixup), which made
+// the epilogue - not the MFMA / FMA work - the longest part of EfficientNet's expand and depthwise layers.  Every
+// caller rounds the result to fp16 or e4m3 next (>= 2^-11 relative), so the 1-ulp fp32 reciprocal is invisible.
+// x -> -inf: exp overflows to +inf, rcp gives 0, the product is -0 like the division's.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
 template <int DT> __device__ __forceinline__ float lo_f32(unsigned int u) {
   if (DT == DT_BF16) return __builtin_bit_cast(float, u << 16);
   return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));

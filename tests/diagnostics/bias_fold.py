@@ -1,0 +1,72 @@
+"""Does folding the systematic part of the fp16 weight-rounding error into the BatchNorm shift let the plain fp16
+mode (no hi+lo weight split) reach the 1e-3 probability tolerance?  (GPU diagnostic)
+
+fp16(w) = w - dw.  The conv computes sum_k fp16(w)_ok x_k = y_o - sum_k dw_ok x_k; the mean of the lost term over the
+data, c_o = sum_k dw_ok E[x_k], is a per-output-channel constant and can be added back exactly by lowering the
+BatchNorm running mean by c_o.  What is left is sum_k dw_ok (x_k - E[x_k]).  E[x_k] comes from (a) a calibration
+batch run through the fp32 oracle (upper bound of what the trick can do), (b) nothing: the plain mode.
+Prints max / p99 / median |dp| over the images for: plain fp16, plain fp16 + fold, and the library's default rule.
+"""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
+import numpy as np, torch
+from oracle import refnet, graph_eval
+from sykepic_hip import arch, synth
+from sykepic_hip.net import HipNet
+torch.set_num_threads(16)
+network = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+hw = int(sys.argv[2]) if len(sys.argv) > 2 else 224
+n_img = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+g = arch.build_graph(network, 50)
+convs = [op for op in g.ops if op.kind == arch.OP_CONV]
+gold = np.load(ROOT / "tests/golden/net_pass.npz")
+
+
+def folded(sd, means, only=None):
+    out = dict(sd)
+    for op in convs:
+        if only is not None and op.name not in only:
+            continue
+        w = torch.from_numpy(np.asarray(sd[op.name + ".weight"])).float()
+        dw = w - w.half().float()
+        c = (dw.sum((2, 3)) * means[op.src][None, :]).sum(1)          # [cout]
+        out[op.bn + ".running_mean"] = np.asarray(sd[op.bn + ".running_mean"]) - c.numpy()
+    return out
+
+
+for wseed in (-2, 2, 7):
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=abs(wseed))
+    if wseed < 0:
+        last = [k for k in sd if k.startswith("head.") and k.endswith(".bias")][-1]
+        sd[last] = sd[last] + gold[f"{network}_{hw}_bias_adj"]
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    ref = refnet.load_numpy_state(refnet.RefNet(network, 50), sd)
+    xcal = torch.from_numpy(synth.synth_images(16, 3, hw, hw, seed=9000))
+    with torch.no_grad():
+        acts = graph_eval.run(g, tsd, xcal)
+    means = {op.src: acts[op.src].mean((0, 2, 3)) for op in convs}
+    del acts
+    nets = {}
+    for tag, state in (("orig", sd), ("fold", folded(sd, means))):
+        net = HipNet(network, 50, weights=None)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        net.eval()
+        nets[tag] = net
+    names = [n for _, n in nets["orig"].conv_ops()]
+    cases = {"plain fp16": ("orig", set()), "plain fp16 + fold": ("fold", set()), "library default (mode 3)": ("orig", None)}
+    worst = {k: [] for k in cases}
+    for s in range(n_img // 32):
+        x = torch.from_numpy(synth.synth_images(32, 3, hw, hw, seed=(200 if wseed < 0 else 500) + s))
+        pr = refnet.probabilities(ref, x).numpy()
+        for name, (tag, keep) in cases.items():
+            net = nets[tag]
+            net.set_precision(split_weights=3) if keep is None else net.set_split_ops(keep)
+            p = net.probabilities(x.cuda()).cpu().numpy()
+            worst[name].extend(np.abs(p - pr).max(1).tolist())
+    print(f"{network} weights seed {wseed}, {n_img} images")
+    for name in cases:
+        v = np.array(worst[name])
+        print(f"  {name:28s} max|dp| {v.max():.2e}  p99 {np.percentile(v, 99):.2e}  median {np.median(v):.2e}", flush=True)
+    del nets

@@ -68,13 +68,14 @@ def test_efficientnet_probabilities_match_reference_golden(golden_dir, network):
 
 @pytest.mark.parametrize("case", [(3, 48, 56, 56, 3, 1), (2, 144, 57, 45, 3, 2), (2, 336, 28, 28, 5, 1), (3, 192, 29, 31, 5, 2),
                                   (2, 672, 14, 14, 3, 1), (4, 1632, 7, 7, 5, 1), (2, 2688, 7, 7, 3, 1), (1, 40, 112, 112, 3, 1),
-                                  (2, 24, 33, 9, 5, 1)],
+                                  (2, 24, 33, 9, 5, 1), (150, 2688, 7, 7, 3, 1), (90, 960, 14, 14, 5, 2), (5, 272, 13, 9, 3, 2),
+                                  (130, 1632, 7, 7, 5, 1)],
                          ids=lambda c: "n%d_c%d_%dx%d_k%ds%d" % c)
 def test_depthwise_kernels_match_torch(case):
     """Depthwise KxK conv + folded BN + SiLU, both kernels (LDS-staged ring of input rows, dwconv_lds.hip; per-thread
     gather, effnet.hip), against F.conv2d(groups=C) on the same fp16 input: odd / non-square sizes, stride 2, channel
-    counts that do not fill a channel slab, bands that end mid-image.  fp32 accumulation of <= 25 taps: 2e-3 of the
-    tensor maximum (fp16 output rounding), and the squeeze-excitation pool sums to 1e-4."""
+    counts that do not fill a channel slab, bands that end mid-image, many small images.  fp32 accumulation of <= 25
+    taps: 2e-3 of the tensor maximum (fp16 output rounding), and the squeeze-excitation pool sums to 1e-4."""
     import torch.nn.functional as F
     from sykepic_hip import ops
     n, c, h, w, k, s = case
