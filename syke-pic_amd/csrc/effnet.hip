@@ -227,57 +227,87 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// excitation, part 1: hid = silu(W1 avg + b1).  Block (img, 4 hidden units): all 256 threads stride the channels
-// (the pooled mean is summed from the depthwise kernel's chunk partials on the fly), so every thread has
-// 4 x c/256 independent weight loads in flight; fixed-order shuffle + LDS reduction.  hid[img][sq].
+// excitation, part 1: hid = silu(W1 avg + b1).  Block (IPB images, 4 hidden units): all 256 threads stride the channels
+// (the pooled mean is summed from the depthwise kernel's chunk partials on the fly); every weight that is loaded serves
+// IPB images - with one image per block the two excitation kernels re-read the fc weights once per image through L2
+// (c 2688: 2 x 300 MB per layer) and ran 30-100 us; fixed-order shuffle + LDS reduction.  hid[img][sq].
+constexpr int SE_IPB = 8;
 __global__ __launch_bounds__(256) void se_fc1_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
                                                      const float* __restrict__ w1, const float* __restrict__ b1,
-                                                     float* __restrict__ hid, int c, int c_p, int sq) {
-  __shared__ float red[4][4];
-  const int img = blockIdx.x, j0 = blockIdx.y * 4;
-  float t[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = threadIdx.x; i < c; i += 256) {
-    float a = 0.f;
-    for (int k = 0; k < chunks; ++k) a += partial[((size_t)img * chunks + k) * c_p + i];
-    a *= inv_hw;
+                                                     float* __restrict__ hid, int n, int c, int c_p, int sq) {
+  __shared__ float red[4][SE_IPB][4];
+  const int img0 = blockIdx.x * SE_IPB, j0 = blockIdx.y * 4;
+  const int nim = min(SE_IPB, n - img0);
+  float t[SE_IPB][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (j0 + q < sq) t[q] += w1[(size_t)(j0 + q) * c + i] * a;
+  for (int im = 0; im < SE_IPB; ++im)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[im][q] = 0.f;
+  for (int i = threadIdx.x; i < c; i += 256) {
+    float wv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wv[q] = j0 + q < sq ? w1[(size_t)(j0 + q) * c + i] : 0.f;
+#pragma unroll
+    for (int im = 0; im < SE_IPB; ++im) {
+      float a = 0.f;
+      if (im < nim)
+        for (int k = 0; k < chunks; ++k) a += partial[((size_t)(img0 + im) * chunks + k) * c_p + i];
+      a *= inv_hw;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[im][q] += wv[q] * a;
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int im = 0; im < SE_IPB; ++im)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t[q] += __shfl_xor(t[q], o, 64);
-    if (lane == 0) red[wave][q] = t[q];
-  }
+    for (int q = 0; q < 4; ++q) {
+      float v = t[im][q];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) red[wave][im][q] = v;
+    }
   __syncthreads();
-  if (threadIdx.x < 4 && j0 + threadIdx.x < sq) {
-    const int q = threadIdx.x;
-    const float v = red[0][q] + red[1][q] + red[2][q] + red[3][q] + b1[j0 + q];
-    hid[(size_t)img * sq + j0 + q] = v / (1.f + __expf(-v));
+  if (threadIdx.x < SE_IPB * 4) {
+    const int im = threadIdx.x >> 2, q = threadIdx.x & 3;
+    if (im < nim && j0 + q < sq) {
+      const float v = red[0][im][q] + red[1][im][q] + red[2][im][q] + red[3][im][q] + b1[j0 + q];
+      hid[(size_t)(img0 + im) * sq + j0 + q] = silu_f(v);
+    }
   }
 }
 
-// excitation, part 2: s = sigmoid(W2 hid + b2); thread = channel, fc2 weights transposed ([sq][c_p]: coalesced);
-// scale[img][c_p] (0 on padding)
+// excitation, part 2: s = sigmoid(W2 hid + b2); thread = channel, fc2 weights transposed ([sq][c_p]: coalesced), each
+// weight serves the block's IPB images; scale[img][c_p] (0 on padding)
 __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ hid, const float* __restrict__ w2t,
-                                                     const float* __restrict__ b2, float* __restrict__ scale, int c,
-                                                     int c_p, int sq) {
-  extern __shared__ float sh[];  // hid[sq]
-  const int img = blockIdx.x;
-  for (int j = threadIdx.x; j < sq; j += 256) sh[j] = hid[(size_t)img * sq + j];
+                                                     const float* __restrict__ b2, float* __restrict__ scale, int n,
+                                                     int c, int c_p, int sq) {
+  extern __shared__ float sh[];  // hid[sq][IPB]
+  const int img0 = blockIdx.x * SE_IPB;
+  const int nim = min(SE_IPB, n - img0);
+  for (int k = threadIdx.x; k < sq * SE_IPB; k += 256) {
+    const int j = k / SE_IPB, im = k - j * SE_IPB;
+    sh[k] = im < nim ? hid[(size_t)(img0 + im) * sq + j] : 0.f;
+  }
   __syncthreads();
   const int i = blockIdx.y * 256 + threadIdx.x;
   if (i >= c_p) return;
-  float s = 0.f;
+  float t[SE_IPB];
+  const float b = i < c ? b2[i] : 0.f;
+#pragma unroll
+  for (int im = 0; im < SE_IPB; ++im) t[im] = b;
   if (i < c) {
-    float t = b2[i];
-#pragma unroll 8
-    for (int j = 0; j < sq; ++j) t += w2t[(size_t)j * c_p + i] * sh[j];
-    s = 1.f / (1.f + __expf(-t));
+#pragma unroll 4
+    for (int j = 0; j < sq; ++j) {
+      const float w = w2t[(size_t)j * c_p + i];
+      const f32x4_t h0 = *(const f32x4_t*)(sh + j * SE_IPB), h1 = *(const f32x4_t*)(sh + j * SE_IPB + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { t[q] += w * h0[q]; t[4 + q] += w * h1[q]; }
+    }
   }
-  scale[(size_t)img * c_p + i] = s;
+#pragma unroll
+  for (int im = 0; im < SE_IPB; ++im)
+    if (im < nim) scale[(size_t)(img0 + im) * c_p + i] = i < c ? sigmoid_f(t[im]) : 0.f;
 }
 
 template <int DT>
@@ -367,10 +397,11 @@ int spk_launch_se(const bf16_t* x, bf16_t* y, const float* partial, int chunks, 
                   hipStream_t s) {
   if (dt != DT_F16) return -2;
   float* hid = scale + (size_t)n * c_p;  // scratch behind the scales: [n][sq]
-  hipLaunchKernelGGL(se_fc1_kernel, dim3(n, (sq + 3) / 4), dim3(256), 0, s, partial, chunks, 1.0f / (float)hw, w1, b1, hid,
-                     c, c_p, sq);
-  hipLaunchKernelGGL(se_fc2_kernel, dim3(n, (c_p + 255) / 256), dim3(256), (size_t)sq * 4, s, hid, w2t, b2, scale, c, c_p,
-                     sq);
+  const int ig = (n + SE_IPB - 1) / SE_IPB;
+  hipLaunchKernelGGL(se_fc1_kernel, dim3(ig, (sq + 3) / 4), dim3(256), 0, s, partial, chunks, 1.0f / (float)hw, w1, b1, hid,
+                     n, c, c_p, sq);
+  hipLaunchKernelGGL(se_fc2_kernel, dim3(ig, (c_p + 255) / 256), dim3(256), (size_t)sq * SE_IPB * 4, s, hid, w2t, b2, scale,
+                     n, c, c_p, sq);
   if (!y) return hipGetLastError() == hipSuccess ? 0 : -1;   // gates only
   const size_t per_img = (size_t)hw * (c_p / 8);
   if (per_img >= ((size_t)1 << 31)) return -2;

@@ -17,7 +17,10 @@
 // measured 5-9 % slower), two LDS stages, register staging (the loader
 // converts / gates, which LDS-DMA cannot).  LDS granule (8 B) index XORed with 2*((row>>2)&3): the ds_read_b64
 // fragment reads of 16 rows x 2 k-groups then touch 32 distinct 8-B slots (conflict-free), and a 16-B store
-// stays one aligned 16-B store.  These layers are HBM-bound (K = 24 ... 2688): the point of fp8 here is the
+// stays one aligned 16-B store.  (A persistent variant - 3 resident blocks per CU walking the tiles, the loads of the
+// next (tile, K step) issued before the MFMAs and the epilogue of the current one - measured 10-35 % SLOWER on every
+// expand layer: many small independent blocks, 5-6 per CU, hide the load-convert-MFMA-store latency chain better than
+// one-deep prefetch in fewer, fatter blocks.)  These layers are HBM-bound (K = 24 ... 2688): the point of fp8 here is the
 // halved bytes of the expanded tensors, not the MFMA rate.
 #include "spk_common.h"
 
@@ -85,6 +88,7 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
   const int a_chunk = tid % A_CPR, a_row = tid / A_CPR;
   int a_img[A_IT];
   u32x4_t ra[A_IT];
+  f32x4_t rg[GATED ? A_IT : 1][4];
   u32x4_t rb;
   const int b_chunk = tid & 3, b_row = tid >> 2;
 #pragma unroll
@@ -101,10 +105,18 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
       const bool ok = m < a.M && kc < a.cin_s;
       const unsigned off = ok ? (unsigned)(((size_t)m * a.cin_s + kc) * (A_FP8 ? 1 : 2)) : 0x80000000u;
       ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+      if (GATED) {
+        // the 16 gates of this chunk travel with it (one K step ahead of their use): loaded in stash() they cost a
+        // full L2 round trip per K step on the critical path of the long-K project convs
+        const float* g = a.gate + (size_t)a_img[i] * a.gate_stride + kc;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          rg[i][q] = kc + q * 4 < a.gate_stride ? *(const f32x4_t*)(g + q * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
     }
     rb = *(const u32x4_t*)(a.w + (size_t)(n0 + b_row) * a.Kpad + k0 + b_chunk * 16);
   };
-  auto stash = [&](int buf, int kt) {
+  auto stash = [&](int buf) {
     unsigned char* dA = sA + buf * A_BYTES;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -113,13 +125,11 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
         u32x4_t v = ra[i];
         if (GATED) {
           // x * gate[image][channel], re-rounded to e4m3 (one rounding, as a separate scale pass would make)
-          const int kc = kt * BK + a_chunk * 16;
-          const float* g = a.gate + (size_t)a_img[i] * a.gate_stride + kc;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             float f[4];
             cvt4_f32(v[q], f);
-            const f32x4_t gq = kc + q * 4 < a.gate_stride ? *(const f32x4_t*)(g + q * 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const f32x4_t gq = rg[i][q];
             v[q] = cvt4_fp8(f[0] * gq[0], f[1] * gq[1], f[2] * gq[2], f[3] * gq[3]);
           }
         }
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   issue(0);
-  stash(0, 0);
+  stash(0);
   __syncthreads();
   for (int kt = 0; kt < KT; ++kt) {
     const int buf = kt & 1;
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < KT) stash(buf ^ 1, kt + 1);
+    if (kt + 1 < KT) stash(buf ^ 1);
     __syncthreads();
   }
 

@@ -40,6 +40,10 @@ CASES = [
     (129, 2688, 448, True, False, True, True, 0),
     (200, 192, 32, True, False, False, False, 0),
     (64, 64, 64, False, False, False, False, 1),
+    # more tiles than resident blocks: the persistent blocks walk several tiles, loads run ahead across tile borders
+    (40000, 24, 144, False, True, False, False, 2),
+    (100000, 192, 32, True, False, True, True, 0),
+    (33000, 160, 960, False, True, False, False, 2),
 ]
 
 
