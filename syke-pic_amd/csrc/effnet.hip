@@ -62,10 +62,13 @@ __global__ void pack_tapmajor_kernel(const float* __restrict__ w, float* __restr
 }
 
 // 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 8 output channels of
-// one output pixel; the 27 x C weights, scales and shifts sit in LDS; 9 8-byte image loads, 216 FMAs and one
-// 16-B store per thread.  C (32..48 for B0-B4, a multiple of 8) is the stored channel count.  A real (not
-// unrolled) tap loop: unrolled, hipcc 7.2 front-loads every LDS read and spills hundreds of VGPRs.
-// Exact fp32 products of the 16-bit image.
+// one output pixel; the 27 x C weights, scales and shifts sit in LDS, staged once per block for STEM_ITEMS x 256
+// (pixel, channel group) items.  Per item: the 9 8-byte image loads are issued together and unconditionally
+// (coordinates clamped into the image, the value zeroed by a select) - with a bounds branch per tap every load
+// waited for the one before it -, then 216 FMAs tap by tap (the LDS offset is made opaque per tap: otherwise hipcc 7.2
+// front-loads every LDS read - 216 VGPRs of weights) and one 16-B store.  C (32..48 for B0-B4, a multiple of
+// 8) is the stored channel count.  Exact fp32 products of the 16-bit image.
+constexpr int STEM_ITEMS = 4;
 template <int DT>
 __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ scale,
@@ -84,37 +87,56 @@ __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__
   __syncthreads();
   const unsigned G = (unsigned)c >> 3;                 // threads per pixel
   const unsigned total = (unsigned)n * ho * wo * G;    // < 2^31 (checked by the launcher): 32-bit index math
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int c0 = (int)(i % G) * 8;
-  unsigned p = i / G;
-  const size_t pix = p;
-  const int ox = (int)(p % (unsigned)wo);
-  p /= (unsigned)wo;
-  const int oy = (int)(p % (unsigned)ho), img = (int)(p / (unsigned)ho);
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
-  for (int t = 0; t < 9; ++t) {
-    const int r = t / 3, q = t - 3 * r;
-    const int iy = 2 * oy - 1 + r, ix = 2 * ox - 1 + q;
-    uint2 px = {0u, 0u};
-    if ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)wid)
-      px = *(const uint2*)(x + (((size_t)img * h + iy) * wstride + ix) * 4);
-    const float xin[3] = {lo_f32<DT>(px.x), hi_f32<DT>(px.x), lo_f32<DT>(px.y)};
+  for (int it = 0; it < STEM_ITEMS; ++it) {
+    const unsigned i = (blockIdx.x * STEM_ITEMS + it) * 256u + threadIdx.x;
+    if (i >= total) return;
+    const int c0 = (int)(i % G) * 8;
+    unsigned p = i / G;
+    const size_t pix = p;
+    const int ox = (int)(p % (unsigned)wo);
+    p /= (unsigned)wo;
+    const int oy = (int)(p % (unsigned)ho), img = (int)(p / (unsigned)ho);
+    uint2 px[9];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-      const float* wp = sw + (t * 3 + ch) * c + c0;
-      const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[j] += xin[ch] * w0[j];
-        acc[4 + j] += xin[ch] * w1[j];
-      }
+    for (int t = 0; t < 9; ++t) {
+      const int iy = 2 * oy - 1 + t / 3, ix = 2 * ox - 1 + t % 3;
+      const int iyc = min(max(iy, 0), h - 1), ixc = min(max(ix, 0), wid - 1);
+      px[t] = *(const uint2*)(x + (((size_t)img * h + iyc) * wstride + ixc) * 4);
+      if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)wid) px[t] = uint2{0u, 0u};
     }
-  }
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int woff = c0;                                     // LDS float offset of this tap's weights
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = act_f(acc[j] * sw[27 * c + c0 + j] + sw[28 * c + c0 + j], act);
-  *(u32x4_t*)(y + pix * c + c0) = pack8f<DT>(acc);
+    for (int t = 0; t < 9; ++t) {
+      const float xin[3] = {lo_f32<DT>(px[t].x), hi_f32<DT>(px[t].x), lo_f32<DT>(px[t].y)};
+      // ties the offset to the last tap's results: this tap's LDS reads cannot move above the last tap's FMAs, nor those
+      // FMAs below this point
+      asm volatile("" : "+v"(woff), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                   "+v"(acc[7]));
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float* wp = sw + woff + (t * 3 + ch) * c;
+        const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] += xin[ch] * w0[j];
+          acc[4 + j] += xin[ch] * w1[j];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * sw[27 * c + c0 + j] + sw[28 * c + c0 + j];
+    if (act == 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = silu_f(acc[j]);
+    } else if (act == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+    }
+    *(u32x4_t*)(y + pix * c + c0) = pack8f<DT>(acc);
+  }
 }
 
 // depthwise KxK conv + folded BN + activation.  One block = one chunk of output pixels of ONE image x one tile
@@ -160,7 +182,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
       for (int u = 0; u < PX; ++u)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
-#pragma unroll
+      // k3: rows unrolled (all 18 loads in flight, 120-141 VGPRs); k5: a real loop (unrolled, 40 loads = 160 VGPRs of
+      // raw pixels are live at once and only two waves fit a SIMD)
+#pragma unroll(K == 3 ? 3 : 1)
       for (int r = 0; r < K; ++r) {
         const int iy = oy * S - PAD + r;
         if ((unsigned)iy >= (unsigned)h) continue;
@@ -357,7 +381,8 @@ int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, cons
                        int wid, int wstride, int ho, int wo, int c, int c_p, int act, int dt, hipStream_t s) {
   const size_t total = (size_t)n * ho * wo * (c / 8);
   if (c % 8 || c > 256 || dt != DT_F16 || total >= ((size_t)1 << 31)) return -2;
-  hipLaunchKernelGGL(stem3x3_kernel<DT_F16>, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)29 * c * 4, s, x, w,
+  const size_t per_block = (size_t)256 * STEM_ITEMS;
+  hipLaunchKernelGGL(stem3x3_kernel<DT_F16>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), (size_t)29 * c * 4, s, x, w,
                      scale, bias, y, n, h, wid, wstride, ho, wo, c, c_p, act);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
