@@ -15,6 +15,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
 template <int DT>
 __device__ __forceinline__ void unpack8f(const u32x4_t v, float* f) {
 #pragma unroll
@@ -62,14 +64,14 @@ __global__ void pack_tapmajor_kernel(const float* __restrict__ w, float* __restr
 }
 
 // 3x3 stride-2 pad-1 stem on the NHWC4 input image (RGB + zero channel): one thread = 8 output channels of
-// one output pixel; the 27 x C weights, scales and shifts sit in LDS, staged once per block for STEM_ITEMS x 256
-// (pixel, channel group) items.  Per item: the 9 8-byte image loads are issued together and unconditionally
-// (coordinates clamped into the image, the value zeroed by a select) - with a bounds branch per tap every load
-// waited for the one before it -, then 216 FMAs tap by tap (the LDS offset is made opaque per tap: otherwise hipcc 7.2
-// front-loads every LDS read - 216 VGPRs of weights) and one 16-B store.  C (32..48 for B0-B4, a multiple of
-// 8) is the stored channel count.  Exact fp32 products of the 16-bit image.
-constexpr int STEM_ITEMS = 4;
-template <int DT>
+// STEM_PX adjacent output pixels; the 27 x C weights, scales and shifts sit in LDS, staged once per block (STEM_ROWS
+// output rows).  Per item: the 3 x 9 8-byte image loads are issued together and unconditionally (coordinates clamped
+// into the image, the value zeroed by a select) - with a bounds branch per tap every load waited for the one before
+// it -, then 4 x 216 FMAs tap by tap (packed, v_pk_fma_f32) and four 16-B stores.  C (32..48 for B0-B4, a multiple
+// of 8) is the stored channel count.  Exact fp32 products of the 16-bit image.
+constexpr int STEM_ROWS = 2;                            // output rows per block
+constexpr int STEM_PX = 4;                              // adjacent outputs per thread
+template <int DT, int GT>                               // GT = C / 8 (4..6: B0-B4) or 0: any C, run-time divisions
 __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ bias, bf16_t* __restrict__ y, int n,
@@ -85,57 +87,86 @@ __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__
     sw[28 * c + i] = bias[i];
   }
   __syncthreads();
-  const unsigned G = (unsigned)c >> 3;                 // threads per pixel
-  const unsigned total = (unsigned)n * ho * wo * G;    // < 2^31 (checked by the launcher): 32-bit index math
+  // a block owns STEM_ROWS output rows of one image: image and row come from the block index (scalar), the only
+  // per-item division is by the compile-time group count - with a flat item index the three run-time divisions per
+  // item cost more VALU instructions than the 108 packed FMAs
+  const int G = GT ? GT : (c >> 3);
+  const int row_blocks = (ho + STEM_ROWS - 1) / STEM_ROWS;
+  const int img = blockIdx.x / row_blocks, oy0 = (blockIdx.x - img * row_blocks) * STEM_ROWS;
+  // an item = STEM_PX horizontally adjacent outputs x 8 channels: every weight vector read from LDS serves STEM_PX
+  // pixels (one pixel per item, the 864 B of weights per item made the kernel LDS-bandwidth-bound at 1.7 TB/s)
+  const int gpr = (wo + STEM_PX - 1) / STEM_PX;
+  const int row_items = gpr * G, items = min(STEM_ROWS, ho - oy0) * row_items;
 #pragma unroll 1
-  for (int it = 0; it < STEM_ITEMS; ++it) {
-    const unsigned i = (blockIdx.x * STEM_ITEMS + it) * 256u + threadIdx.x;
-    if (i >= total) return;
-    const int c0 = (int)(i % G) * 8;
-    unsigned p = i / G;
-    const size_t pix = p;
-    const int ox = (int)(p % (unsigned)wo);
-    p /= (unsigned)wo;
-    const int oy = (int)(p % (unsigned)ho), img = (int)(p / (unsigned)ho);
-    uint2 px[9];
+  for (int item = threadIdx.x; item < items; item += 256) {
+    const int rsel = item >= row_items ? 1 : 0;          // STEM_ROWS == 2
+    const int in_row = item - rsel * row_items;
+    const int og = in_row / G, c0 = (in_row - og * G) * 8;
+    const int oy = oy0 + rsel, ox0 = og * STEM_PX;
+    constexpr int NCOL = 2 * STEM_PX + 1;                // input columns 2*ox0 - 1 ... 2*ox0 + 2*STEM_PX - 1
+    uint2 px[3][NCOL];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int iy = 2 * oy - 1 + t / 3, ix = 2 * ox - 1 + t % 3;
-      const int iyc = min(max(iy, 0), h - 1), ixc = min(max(ix, 0), wid - 1);
-      px[t] = *(const uint2*)(x + (((size_t)img * h + iyc) * wstride + ixc) * 4);
-      if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)wid) px[t] = uint2{0u, 0u};
+    for (int r = 0; r < 3; ++r) {
+      const int iy = 2 * oy - 1 + r;
+      const int iyc = min(max(iy, 0), h - 1);
+      const bf16_t* rowp = x + ((size_t)img * h + iyc) * wstride * 4;
+#pragma unroll
+      for (int q = 0; q < NCOL; ++q) {
+        const int ix = 2 * ox0 - 1 + q;
+        const int ixc = min(max(ix, 0), wid - 1);
+        px[r][q] = *(const uint2*)(rowp + (size_t)ixc * 4);
+        if ((unsigned)iy >= (unsigned)h || (unsigned)ix >= (unsigned)wid) px[r][q] = uint2{0u, 0u};
+      }
     }
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x2_t acc2[STEM_PX][4];                            // packed pairs: v_pk_fma_f32, 2 FMAs per lane and instruction
+#pragma unroll
+    for (int u = 0; u < STEM_PX; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[u][j] = f32x2_t{0.f, 0.f};
     int woff = c0;                                     // LDS float offset of this tap's weights
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const float xin[3] = {lo_f32<DT>(px[t].x), hi_f32<DT>(px[t].x), lo_f32<DT>(px[t].y)};
       // ties the offset to the last tap's results: this tap's LDS reads cannot move above the last tap's FMAs, nor those
-      // FMAs below this point
-      asm volatile("" : "+v"(woff), "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                   "+v"(acc[7]));
+      // FMAs below this point (unfenced, hipcc 7.2 front-loads all 54 LDS reads: 216 VGPRs of weights)
+      static_assert(STEM_PX == 4, "the fence lists the accumulators");
+      asm volatile("" : "+v"(woff), "+v"(acc2[0][0]), "+v"(acc2[0][1]), "+v"(acc2[0][2]), "+v"(acc2[0][3]), "+v"(acc2[1][0]),
+                   "+v"(acc2[1][1]), "+v"(acc2[1][2]), "+v"(acc2[1][3]), "+v"(acc2[2][0]), "+v"(acc2[2][1]), "+v"(acc2[2][2]),
+                   "+v"(acc2[2][3]), "+v"(acc2[3][0]), "+v"(acc2[3][1]), "+v"(acc2[3][2]), "+v"(acc2[3][3]));
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float* wp = sw + woff + (t * 3 + ch) * c;
         const f32x4_t w0 = *(const f32x4_t*)wp, w1 = *(const f32x4_t*)(wp + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[j] += xin[ch] * w0[j];
-          acc[4 + j] += xin[ch] * w1[j];
+        for (int u = 0; u < STEM_PX; ++u) {
+          const uint2 p = px[t / 3][2 * u + t % 3];
+          const float xv = ch == 0 ? lo_f32<DT>(p.x) : (ch == 1 ? hi_f32<DT>(p.x) : lo_f32<DT>(p.y));
+          const f32x2_t xx = {xv, xv};
+          acc2[u][0] = __builtin_elementwise_fma(xx, f32x2_t{w0[0], w0[1]}, acc2[u][0]);
+          acc2[u][1] = __builtin_elementwise_fma(xx, f32x2_t{w0[2], w0[3]}, acc2[u][1]);
+          acc2[u][2] = __builtin_elementwise_fma(xx, f32x2_t{w1[0], w1[1]}, acc2[u][2]);
+          acc2[u][3] = __builtin_elementwise_fma(xx, f32x2_t{w1[2], w1[3]}, acc2[u][3]);
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
+    const f32x4_t s0 = *(const f32x4_t*)(sw + 27 * c + c0), s1 = *(const f32x4_t*)(sw + 27 * c + c0 + 4);
+    const f32x4_t b0 = *(const f32x4_t*)(sw + 28 * c + c0), b1 = *(const f32x4_t*)(sw + 28 * c + c0 + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * sw[27 * c + c0 + j] + sw[28 * c + c0 + j];
-    if (act == 2) {
+    for (int u = 0; u < STEM_PX; ++u) {
+      if (ox0 + u >= wo) continue;
+      float acc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = silu_f(acc[j]);
-    } else if (act == 1) {
+      for (int j = 0; j < 4; ++j) { acc[2 * j] = acc2[u][j][0]; acc[2 * j + 1] = acc2[u][j][1]; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      for (int j = 0; j < 4; ++j) { acc[j] = acc[j] * s0[j] + b0[j]; acc[4 + j] = acc[4 + j] * s1[j] + b1[j]; }
+      if (act == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = silu_f(acc[j]);
+      } else if (act == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+      }
+      *(u32x4_t*)(y + (((size_t)img * ho + oy) * wo + ox0 + u) * c + c0) = pack8f<DT>(acc);
     }
-    *(u32x4_t*)(y + pix * c + c0) = pack8f<DT>(acc);
   }
 }
 
@@ -381,9 +412,17 @@ int spk_launch_stem3x3(const bf16_t* x, const float* w, const float* scale, cons
                        int wid, int wstride, int ho, int wo, int c, int c_p, int act, int dt, hipStream_t s) {
   const size_t total = (size_t)n * ho * wo * (c / 8);
   if (c % 8 || c > 256 || dt != DT_F16 || total >= ((size_t)1 << 31)) return -2;
-  const size_t per_block = (size_t)256 * STEM_ITEMS;
-  hipLaunchKernelGGL(stem3x3_kernel<DT_F16>, dim3((unsigned)((total + per_block - 1) / per_block)), dim3(256), (size_t)29 * c * 4, s, x, w,
-                     scale, bias, y, n, h, wid, wstride, ho, wo, c, c_p, act);
+  const dim3 grid((unsigned)n * ((ho + STEM_ROWS - 1) / STEM_ROWS));
+#define SPK_STEM(GT) \
+  hipLaunchKernelGGL((stem3x3_kernel<DT_F16, GT>), grid, dim3(256), (size_t)29 * c * 4, s, x, w, scale, bias, y, n, h, wid, \
+                     wstride, ho, wo, c, c_p, act)
+  switch (c / 8) {
+    case 4: SPK_STEM(4); break;
+    case 5: SPK_STEM(5); break;
+    case 6: SPK_STEM(6); break;
+    default: SPK_STEM(0);
+  }
+#undef SPK_STEM
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
