@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(DwArgs a) {
       const int gc = cg0 * CPT + c;
       v = r < K * K ? a.w[(size_t)r * a.c_p + gc] * a.w_scale : (r == K * K ? a.scale[gc] : a.bias[gc]);
     }
-    sw[i] = v;
+    // LDS layout [row][4-channel part][channel group][4]: the lanes of a wave read consecutive 16-B slots (the plain
+    // [row][channel] layout put a lane's 8 / 16 floats 32 / 64 B from its neighbour's: 2- / 4-way bank conflicts)
+    sw[(((r * (CPT / 4) + ((c % CPT) >> 2)) * tcg + c / CPT) << 2) + (c & 3)] = v;
   }
 
   const int R = a.R;
@@ -134,10 +136,10 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(DwArgs a) {
         float wrow[K][CPT];
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-          const float* wp = sw + (r * K + q) * tcs + cg * CPT;
+          const float* wp = sw + ((r * K + q) * (CPT / 4) * tcg + cg) * 4;
 #pragma unroll
           for (int j4 = 0; j4 < CPT / 4; ++j4) {
-            const f32x4_t t = *(const f32x4_t*)(wp + 4 * j4);
+            const f32x4_t t = *(const f32x4_t*)(wp + j4 * tcg * 4);
             wrow[q][4 * j4] = t[0]; wrow[q][4 * j4 + 1] = t[1]; wrow[q][4 * j4 + 2] = t[2]; wrow[q][4 * j4 + 3] = t[3];
           }
         }
@@ -162,13 +164,18 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(DwArgs a) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      const float* sc = sw + (K * K) * tcs + cg * CPT;
-      const float* bi = sc + tcs;
+#pragma unroll
+      for (int j4 = 0; j4 < CPT / 4; ++j4) {   // folded BN: 4 channels' scale and shift at a time (8 live registers)
+        const f32x4_t t0 = *(const f32x4_t*)(sw + (((K * K) * (CPT / 4) + j4) * tcg + cg) * 4);
+        const f32x4_t t1 = *(const f32x4_t*)(sw + (((K * K + 1) * (CPT / 4) + j4) * tcg + cg) * 4);
+#pragma unroll
+        for (int u = 0; u < PX; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[u][4 * j4 + j] = acc[u][4 * j4 + j] * t0[j] + t1[j];
+      }
 #pragma unroll
       for (int u = 0; u < PX; ++u) {
         if (ox0 + u >= a.wo) continue;
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) acc[u][j] = acc[u][j] * sc[j] + bi[j];
         if (a.act == 2) {   // uniform branch: one activation's instructions, not both + selects
 #pragma unroll
           for (int j = 0; j < CPT; ++j) acc[u][j] = silu_f(acc[u][j]);

@@ -192,8 +192,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
   const int ncg = min(32, c8 - cg0), tc = ncg * 8;
   for (int i = threadIdx.x; i < (K * K + 2) * tc; i += 256) {
     const int r = i / tc, c = i - r * tc;
-    sm[i] = r < K * K ? w[(size_t)r * c_p + cg0 * 8 + c]
-                      : (r == K * K ? scale[cg0 * 8 + c] : bias[cg0 * 8 + c]);
+    // LDS layout [row][half (4 channels)][channel group][4]: the lanes of a wave read consecutive 16-B slots (with the
+    // plain [row][channel] layout a lane's 8 floats sit 32 B from its neighbour's: 2-way bank conflicts on every read)
+    sm[(((r * 2 + ((c >> 2) & 1)) * ncg + (c >> 3)) << 2) + (c & 3)] =
+        r < K * K ? w[(size_t)r * c_p + cg0 * 8 + c] : (r == K * K ? scale[cg0 * 8 + c] : bias[cg0 * 8 + c]);
   }
   __syncthreads();
   const int rows = 256 / ncg;  // pixel-group lanes
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
   const int g0 = chunk * per, g1 = min(ngroups, g0 + per);
   float pool[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (prow < rows) {
-    const float* wl = sm + cg * 8;
+    const float* wl = sm + cg * 4;   // + (row * 2 + half) * ncg * 4
     const bf16_t* xi = x + (size_t)img * h * wid * c_p + (cg0 + cg) * 8;
     bf16_t* yi = y + (size_t)img * ho * wo * c_p + (cg0 + cg) * 8;
     for (int g = g0 + prow; g < g1; g += rows) {
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
         float wrow[K][8];
 #pragma unroll
         for (int q = 0; q < K; ++q) {
-          const f32x4_t w0 = *(const f32x4_t*)(wl + (r * K + q) * tc), w1 = *(const f32x4_t*)(wl + (r * K + q) * tc + 4);
+          const f32x4_t w0 = *(const f32x4_t*)(wl + ((r * K + q) * 2) * ncg * 4), w1 = *(const f32x4_t*)(wl + ((r * K + q) * 2 + 1) * ncg * 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { wrow[q][j] = w0[j]; wrow[q][4 + j] = w1[j]; }
         }
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
       for (int u = 0; u < PX; ++u) {
         if (ox0 + u >= wo) continue;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[u][j] = acc[u][j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j];
+        for (int j = 0; j < 8; ++j)
+          acc[u][j] = acc[u][j] * wl[((K * K) * 2 + (j >> 2)) * ncg * 4 + (j & 3)] + wl[((K * K + 1) * 2 + (j >> 2)) * ncg * 4 + (j & 3)];
         if (act == 2) {   // uniform branch: one activation's instructions, not both + selects
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[u][j] = silu_f(acc[u][j]);

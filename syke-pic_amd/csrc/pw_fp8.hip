@@ -340,8 +340,11 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
   const int ncg = min(16, c16 - cg0), tc = ncg * CPT;
   for (int i = threadIdx.x; i < (K * K + 2) * tc; i += 256) {
     const int r = i / tc, c = i - r * tc;
-    sm[i] = r < K * K ? w[(size_t)r * c_p + cg0 * CPT + c] * in_scale
-                      : (r == K * K ? scale[cg0 * CPT + c] : bias[cg0 * CPT + c]);
+    // LDS layout [row][quarter (4 channels)][channel group][4]: the lanes of a wave read consecutive 16-B slots (with
+    // the plain [row][channel] layout a lane's 16 floats sit 64 B from its neighbour's: 4-way bank conflicts on every
+    // weight read - measured 13-15 conflict cycles per LDS instruction)
+    sm[(((r * 4 + ((c >> 2) & 3)) * ncg + (c >> 4)) << 2) + (c & 3)] =
+        r < K * K ? w[(size_t)r * c_p + cg0 * CPT + c] * in_scale : (r == K * K ? scale[cg0 * CPT + c] : bias[cg0 * CPT + c]);
   }
   __syncthreads();
   const int rows = 256 / ncg;
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
 #pragma unroll
   for (int j = 0; j < CPT; ++j) pool[j] = 0.f;
   if (prow < rows) {
-    const float* wl = sm + cg * CPT;
+    const float* wl = sm + cg * 4;   // + (row * 4 + quarter) * ncg * 4
     const unsigned char* xi = x + (size_t)img * h * wid * c_p + (cg0 + cg) * CPT;
     unsigned char* yi = y + (size_t)img * ho * wo * c_p + (cg0 + cg) * CPT;
     for (int g = g0 + prow; g < g1; g += rows) {
@@ -385,9 +388,12 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
           for (int u = 0; u < PX; ++u) {
             const int q = col - u * S;  // tap of output u that this column feeds
             if (q >= 0 && q < K) {
-              const float* wt = wl + (r * K + q) * tc;
 #pragma unroll
-              for (int j = 0; j < CPT; ++j) acc[u][j] += xv[j] * wt[j];
+              for (int j4 = 0; j4 < 4; ++j4) {
+                const f32x4_t wt = *(const f32x4_t*)(wl + ((r * K + q) * 4 + j4) * ncg * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[u][4 * j4 + j] += xv[4 * j4 + j] * wt[j];
+              }
             }
           }
         }
@@ -396,7 +402,8 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
       for (int u = 0; u < PX; ++u) {
         if (ox0 + u >= wo) continue;
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) acc[u][j] = acc[u][j] * wl[K * K * tc + j] + wl[(K * K + 1) * tc + j];
+        for (int j = 0; j < CPT; ++j)
+          acc[u][j] = acc[u][j] * wl[((K * K) * 4 + (j >> 2)) * ncg * 4 + (j & 3)] + wl[((K * K + 1) * 4 + (j >> 2)) * ncg * 4 + (j & 3)];
         if (act == 2) {   // uniform branch: one activation's instructions, not both + selects
 #pragma unroll
           for (int j = 0; j < CPT; ++j) acc[u][j] = silu_f(acc[u][j]);
