@@ -11,6 +11,8 @@ from sykepic_hip import synth
 
 pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
+# fresh images at the reference's base 1.3 (measured r2: median 2.0-2.6e-4, p90 1.6-2.1e-3, max 2.0-3.1e-3, top-1 32/32)
+BASE13_MEDIAN, BASE13_P90, BASE13_MAX = 5e-4, 4e-3, 1e-2
 
 
 def _hipnet(network, sd):
@@ -64,6 +66,17 @@ def test_efficientnet_probabilities_match_reference_golden(golden_dir, network):
     assert np.median(per_img) < 3e-3 and per_img.max() < 6e-2
     assert np.percentile(dp, 90) <= PROB_TOL and np.median(dp) <= PROB_TOL / 3
     assert (pg.argmax(1) == pr.argmax(1)).mean() >= 0.9
+    # ... and at the reference's real base 1.3 (sykepic/compute/probability.py:194), where this synthetic net's logits
+    # of std 10-20 make the softmax 4x steeper than above: the median image is inside the 1e-3 tolerance (2-3e-4), the
+    # worst tenth is not (2e-3: the 40-fold amplification above), so the bounds are the MEASURED ones with 2x head-room -
+    # a regression of the fp16 path shows up at the reference's own setting too
+    pr13 = torch.softmax(torch.from_numpy(z) * float(np.log(1.3)), 1).numpy()
+    pg13 = net.probabilities(x2.cuda()).cpu().numpy()
+    dp13 = np.abs(pg13 - pr13).max(1)
+    print(f"{tag}: max|dp| at base 1.3 on fresh images: median {np.median(dp13):.2e} p90 {np.percentile(dp13, 90):.2e} "
+          f"max {dp13.max():.2e}; top-1 agreement {(pg13.argmax(1) == pr13.argmax(1)).mean():.2f}")
+    assert np.median(dp13) <= BASE13_MEDIAN and np.percentile(dp13, 90) <= BASE13_P90 and dp13.max() <= BASE13_MAX
+    assert (pg13.argmax(1) == pr13.argmax(1)).mean() >= 0.95
 
 
 @pytest.mark.parametrize("case", [(3, 48, 56, 56, 3, 1), (2, 144, 57, 45, 3, 2), (2, 336, 28, 28, 5, 1), (3, 192, 29, 31, 5, 2),

@@ -196,3 +196,21 @@ def test_backbone_checkpoint_key_mapping():
         assert [m for m in mapped if m is not None] == want
         dropped = [k for k, m in zip(tv, mapped) if m is None]
         assert dropped and all(k.startswith(("fc.", "classifier.")) for k in dropped)
+
+
+def test_traffic_provenance_digest_is_shared():
+    """bench.py quotes profiles/r*_pmc_traffic_*.json only when the digest stored by tools/pmc_traffic.py equals its own
+    digest of the conv kernel sources: both must hash the same files the same way."""
+    import importlib.util
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    mods = []
+    for name, rel in (("bench_mod", "bench.py"), ("pmc_traffic_mod", "tools/pmc_traffic.py")):
+        spec = importlib.util.spec_from_file_location(name, root / rel)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mods.append(mod)
+    assert mods[0].TRAFFIC_SOURCES == mods[1].TRAFFIC_SOURCES
+    assert mods[0].kernel_source_sha() == mods[1].kernel_source_sha()
+    for f in mods[0].TRAFFIC_SOURCES:
+        assert (root / "syke-pic_amd" / "csrc" / f).is_file()

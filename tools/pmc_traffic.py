@@ -15,11 +15,15 @@ import sys
 from pathlib import Path
 
 
+TRAFFIC_SOURCES = ("conv_igemm.hip", "conv3x3_slab.hip", "spk_common.h", "model.hip", "model.h")   # as bench.py
+
+
 def kernel_source_sha():
     """Same digest as bench.py: the figure is only quoted by bench.py for the kernel sources it was taken on."""
     h = hashlib.sha256()
-    for f in sorted((Path(__file__).resolve().parent.parent / "syke-pic_amd" / "csrc").glob("*.h*")):
-        h.update(f.name.encode())
+    for name in TRAFFIC_SOURCES:
+        f = Path(__file__).resolve().parent.parent / "syke-pic_amd" / "csrc" / name
+        h.update(name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
 
