@@ -19,6 +19,14 @@
 //     XOR-swizzled with the cout so 16 couts hit 16 slots).
 // Epilogue as in conv_igemm.hip: per-wave LDS staging, BN scale/shift (eval) or
 // raw + per-channel sum / sum-of-squares partials (train), ReLU, 16-bit rows.
+//
+// POOL variant (eval): the 3x3 stride-2 pad-1 max-pool that follows the stem (`base.3`) is applied to the tile in
+// LDS and only the pooled tensor is written: the 411 MB stem output of a batch of 256 neither goes to HBM nor comes
+// back (the separate pass cost 127-132 us, the stem 210).  A 16x16 stem tile whose origin sits one row and column
+// before a multiple of 14 holds every input of 7x7 pooled outputs, so the tiles advance by 14 stem pixels (8x8
+// tiles per 112^2 image instead of 7x7: 31 % more MFMA work on the cheapest layer of the network).  The rounded
+// 16-bit values are pooled, exactly what the separate kernel reads, so the result is bit-identical to the
+// two-kernel path (max commutes with the monotonic rounding anyway).
 #include "spk_common.h"
 
 namespace {
@@ -29,15 +37,21 @@ constexpr int PWP = TILE + 4;            // 20 pixel pairs per patch row (40 pix
 constexpr int PATCH_BYTES = PH * PWP * 16;
 constexpr int W_ROW_BYTES = 512;         // 256 k-elements per cout
 
-template <int DT, int SPLITW>
+constexpr int POOL_STEP = 14;            // POOL: stem pixels a tile advances by (7 pooled outputs)
+constexpr int POOL_OUT = 7;
+
+template <int DT, int SPLITW, int POOL>
 __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
   constexpr int NW = SPLITW ? 2 : 1;
   constexpr int W_BYTES = 64 * W_ROW_BYTES;
   constexpr int EPI_LD = 68;
+  constexpr int TSTEP = POOL ? POOL_STEP : TILE;           // stem pixels between tile origins
+  constexpr int TORG = POOL ? 1 : 0;                       // ... and the origin's offset before the multiple
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sW = smem;                          // [NW][64][512 B]
   unsigned char* const sP = smem + NW * W_BYTES;           // [2][PATCH_BYTES]
   float* const sE = (float*)(sP + 2 * PATCH_BYTES);        // [4 waves][16][EPI_LD]
+  unsigned char* const sT = (unsigned char*)(sE + 4 * 16 * EPI_LD);   // POOL: [16][16] stem pixels x 128 B
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
     const int img = tile / (tiles_x * tiles_y);
     const int rem = tile - img * tiles_x * tiles_y;
     const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int iy0 = ty * TILE * 2 - 3, ix0 = tx * TILE * 2 - 4;
+    const int iy0 = (ty * TSTEP - TORG) * 2 - 3, ix0 = (tx * TSTEP - TORG) * 2 - 4;
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const int c = tid + i * 256;
@@ -142,15 +156,27 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) epi[(fq * 4 + rr) * EPI_LD + j * 16 + frow] = acc[i][j][rr];
       __builtin_amdgcn_wave_barrier();
-      const int oy = ty * TILE + wave * 4 + i;
+      const int oy = ty * TSTEP - TORG + wave * 4 + i;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int px = erow + p * 8;
-        const int ox = tx * TILE + px;
+        const int ox = tx * TSTEP - TORG + px;
         const f32x4_t v0 = *(const f32x4_t*)(epi + px * EPI_LD + ecol);
         const f32x4_t v1 = *(const f32x4_t*)(epi + px * EPI_LD + ecol + 4);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-        if (oy < a.Ho && ox < a.Wo) {
+        const bool inside = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+        if (POOL) {
+          // the rounded tile goes to LDS; positions outside the stem output are the pool's padding: every real value
+          // is >= +0 after the ReLU, so zeros never win against the window's real maximum
+          u32x4_t ov = {0u, 0u, 0u, 0u};
+          if (inside) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + bi[j], 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = pack2<DT>(v[2 * j], v[2 * j + 1]) & 0x7fff7fffu;   // -0 -> +0
+          }
+          *(u32x4_t*)(sT + ((wave * 4 + i) * TILE + px) * 128 + ecol * 2) = ov;
+        } else if (inside) {
           if (a.stats) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
@@ -171,6 +197,31 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
 
     if (next < n_tiles) store_patch(buf ^ 1);
     __syncthreads();
+    if (POOL) {
+      // 7 x 7 pooled pixels x 8 channel chunks of 16 B: the window of pooled (py, px) is the tile's rows 2py .. 2py+2 and
+      // columns 2px .. 2px+2.  Non-negative 16-bit floats order like unsigned integers (fp16 and bf16 alike).
+      for (int it = tid; it < POOL_OUT * POOL_OUT * 8; it += 256) {
+        const int chunk = it & 7, pp = it >> 3;
+        const int ppy = pp / POOL_OUT, ppx = pp - ppy * POOL_OUT;
+        const int py = ty * POOL_OUT + ppy, pxg = tx * POOL_OUT + ppx;
+        if (py >= a.pool_ho || pxg >= a.pool_wo) continue;
+        u32x4_t mx = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const u32x4_t t = *(const u32x4_t*)(sT + ((2 * ppy + r) * TILE + 2 * ppx + q) * 128 + chunk * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned int av = mx[j], bv = t[j];
+              const unsigned int lo = max(av & 0xffffu, bv & 0xffffu), hi = max(av >> 16, bv >> 16);
+              mx[j] = lo | (hi << 16);
+            }
+          }
+        *(u32x4_t*)(a.pool_y + (((size_t)img * a.pool_ho + py) * a.pool_wo + pxg) * 64 + chunk * 8) = mx;
+      }
+      __syncthreads();   // the next tile's epilogue overwrites sT
+    }
     buf ^= 1;
   }
 
@@ -200,15 +251,16 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
   }
 }
 
-template <int DT, int SPLITW>
+template <int DT, int SPLITW, int POOL>
 int launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
-  const int tiles_x = (a.Wo + TILE - 1) / TILE, tiles_y = (a.Ho + TILE - 1) / TILE;
+  const int tiles_x = POOL ? (a.pool_wo + POOL_OUT - 1) / POOL_OUT : (a.Wo + TILE - 1) / TILE;
+  const int tiles_y = POOL ? (a.pool_ho + POOL_OUT - 1) / POOL_OUT : (a.Ho + TILE - 1) / TILE;
   const int n_tiles = a.N * tiles_x * tiles_y;
-  const size_t lds = (SPLITW ? 2 : 1) * 64 * W_ROW_BYTES + 2 * PATCH_BYTES + 4 * 16 * 68 * 4;
+  const size_t lds = (SPLITW ? 2 : 1) * 64 * W_ROW_BYTES + 2 * PATCH_BYTES + 4 * 16 * 68 * 4 + (POOL ? TILE * TILE * 128 : 0);
   int grid = 256 * 2;  // 2 blocks per CU fit (74 / 107 KB of LDS)
-  if (SPLITW) grid = 256;
+  if (SPLITW || POOL) grid = 256;   // 106 / 139 KB with the pooled tile: one block per CU
   if (grid > n_tiles) grid = n_tiles;
-  auto k = conv_stem_kernel<DT, SPLITW>;
+  auto k = conv_stem_kernel<DT, SPLITW, POOL>;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -225,6 +277,11 @@ int launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
 // problem is not this shape (the caller then uses the generic kernel).
 int spk_conv_stem_launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
   if (a.Cout != 64 || a.kh != 7 || a.stride != 2 || a.pad != 3 || a.res) return -2;
-  if (a.dt == DT_F16) return a.splitw ? launch<DT_F16, 1>(a, s, m_tiles_out) : launch<DT_F16, 0>(a, s, m_tiles_out);
-  return launch<DT_BF16, 0>(a, s, m_tiles_out);
+  if (a.pool_y) {   // fused max-pool (eval): the pooled dims must be those of a 3x3 / 2 pad-1 pool of this stem output
+    if (!a.relu || a.stats || a.pool_ho != (a.Ho - 1) / 2 + 1 || a.pool_wo != (a.Wo - 1) / 2 + 1) return -2;
+    if (a.dt == DT_F16) return a.splitw ? launch<DT_F16, 1, 1>(a, s, m_tiles_out) : launch<DT_F16, 0, 1>(a, s, m_tiles_out);
+    return launch<DT_BF16, 0, 1>(a, s, m_tiles_out);
+  }
+  if (a.dt == DT_F16) return a.splitw ? launch<DT_F16, 1, 0>(a, s, m_tiles_out) : launch<DT_F16, 0, 0>(a, s, m_tiles_out);
+  return launch<DT_BF16, 0, 0>(a, s, m_tiles_out);
 }

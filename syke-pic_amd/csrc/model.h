@@ -46,6 +46,8 @@ struct Layer {
   float amax_in = 0.f, amax_out = 0.f;   // max |x| of the input / output tensor on the calibration batch
   size_t w8_off = 0, s8_off = 0;         // e4m3 weights / [ws, epilogue scale] floats of this layer
   bool side_branch = false;   // output is only ever a shortcut operand (downsample conv): may run beside the main branch
+  int fuse_pool = -1;         // stem conv: index of the 3x3/2 max-pool layer its eval kernel can absorb (conv_stem.hip), or -1
+  bool pooled_by_stem = false;  // that max-pool layer
   hipEvent_t join = nullptr;  // side branches: recorded on the side stream after the layer
 };
 
@@ -111,6 +113,10 @@ struct spk_model {
   TrainState* train = nullptr;
 
   int img0 = 0;                 // first image of the chunk the eval executor is working on (prefix micro-batching)
+  bool fuse_stem_pool = true;   // eval: stem conv + max-pool in one kernel (SPK_FUSE_STEM_POOL=0 turns it off)
+  int stale_stem_t = -1;        // tensor id of the stem output the last eval forward did NOT write (fused), or -1
+  bool force_unfused = false;   // read_activation is recomputing the stem output
+  int last_eval_nb = 0;         // images of the last eval micro-batch (read_activation recomputes a stale tensor)
   float* P(int pi) const { return pbuf + params[pi].off; }
   void* T(int t) const { return (char*)arena + toff[t]; }
   // tensor t from image img0 on

@@ -159,6 +159,21 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     for (const Layer& Q : m->layers)
       if (Q.d.kind == SPK_OP_CONV && Q.d.dst == L.d.src && Q.d.k == 1 && !Q.trunk_writer) L.inner3x3 = true;
   }
+  // the ResNet stem (7x7/2 conv + BN + ReLU) followed by the 3x3/2 pad-1 max-pool that alone reads its output: one
+  // kernel in the eval path (conv_stem.hip, POOL variant)
+  for (size_t i = 0; i + 1 < m->layers.size(); ++i) {
+    Layer& L = m->layers[i];
+    Layer& P = m->layers[i + 1];
+    if (L.d.kind != SPK_OP_CONV || L.mode != CONV_MODE_STEM || L.d.relu != 1 || L.d.res >= 0) continue;
+    if (P.d.kind != SPK_OP_MAXPOOL || P.d.src != L.d.dst || P.d.k != 3 || P.d.stride != 2 || P.d.pad != 1) continue;
+    bool other = false;
+    for (size_t j = 0; j < m->layers.size(); ++j)
+      if (j != i + 1 && (m->layers[j].d.src == L.d.dst || m->layers[j].d.res == L.d.dst)) other = true;
+    if (other || L.d.dst == m->layers.back().d.dst) continue;
+    L.fuse_pool = (int)(i + 1);
+    P.pooled_by_stem = true;
+  }
+  if (const char* e = getenv("SPK_FUSE_STEM_POOL")) m->fuse_stem_pool = atoi(e) != 0;
   for (int oi : order) {
     Layer& L = m->layers[oi];
     const std::string nm = L.d.name, bn = L.d.bn;
@@ -681,6 +696,12 @@ static int micro_batch(spk_model* m, int n) {
 // ---------------------------------------------------------------------------
 // eval-mode forward of images [i0, i0+nb) into logits rows [i0, i0+nb)
 // ---------------------------------------------------------------------------
+// eval: does the stem kernel also compute the max-pool that follows it?  (not with the rounding-remainder tensors of
+// the precise-residual mode, whose pool works on value + remainder)
+static bool stem_pool_fused(const spk_model* m, const Layer& L) {
+  return L.fuse_pool >= 0 && m->fuse_stem_pool && !m->precise_res && !m->force_unfused;
+}
+
 static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
@@ -716,6 +737,16 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   a.splitw = layer_split(m, L);
   a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
   a.w_bytes = (unsigned)((size_t)L.cout_p * L.kpad * 2 * (a.splitw ? 2 : 1));
+  if (stem_pool_fused(m, L)) {   // the max-pool layer that follows is computed here and skipped below
+    const Layer& P = m->layers[L.fuse_pool];
+    const TDim& po = m->tdims[P.d.dst];
+    a.pool_y = (bf16_t*)m->TI(P.d.dst);
+    a.pool_ho = po.h;
+    a.pool_wo = po.w;
+    m->stale_stem_t = L.d.dst;
+  } else if (L.fuse_pool >= 0) {
+    m->stale_stem_t = -1;
+  }
   if (spk_conv_launch(a, L.mode, m->stream, nullptr))
     return fail(SPK_ERR_HIP, std::string("conv launch failed for ") + L.d.name);
   return SPK_OK;
@@ -886,6 +917,7 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       return SPK_OK;
     }
     case SPK_OP_MAXPOOL:
+      if (L.pooled_by_stem && m->stale_stem_t == L.d.src) return SPK_OK;   // the stem kernel wrote this layer's output
       if (spk_launch_maxpool((const bf16_t*)m->TI(L.d.src), (bf16_t*)m->TI(L.d.dst), nb, in.h, in.w,
                              in.c, L.d.k, L.d.stride, L.d.pad, o.h, o.w, m->infer_dt, m->stream))
         return fail(SPK_ERR_HIP, "maxpool launch failed");
@@ -948,6 +980,7 @@ static int prefix_layers(const spk_model* m, int nb, int* mb_out) {
 
 static int run_layers_eval(spk_model* m, int nb) {
   static const bool two = getenv("SPK_SIDE_STREAM") && atoi(getenv("SPK_SIDE_STREAM")) != 0;
+  m->last_eval_nb = nb;
   bool any = false;
   for (const Layer& L : m->layers) any |= L.side_branch;
   if (!two || !any) {
@@ -1057,6 +1090,17 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
   const size_t cnt = (size_t)n * d.h * d.w * d.c;
   if ((int64_t)((size_t)n * d.h * d.w * cl) != numel) return fail(SPK_ERR_ARG, "read_activation: size mismatch");
   HIP_TRY(hipSetDevice(m->device));
+  if (t == m->stale_stem_t && m->last_eval_nb > 0) {
+    // the last forward computed stem + max-pool in one kernel and never wrote this tensor: run the stem layer alone
+    // (its input is still in the arena)
+    for (Layer& L : m->layers)
+      if (L.d.kind == SPK_OP_CONV && L.d.dst == t) {
+        m->force_unfused = true;
+        const int r = run_conv_eval(m, L, m->last_eval_nb);
+        m->force_unfused = false;
+        if (r != SPK_OK) return r;
+      }
+  }
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (!d.bf16) {
     HIP_TRY(hipMemcpy(host, m->T(t), cnt * 4, hipMemcpyDeviceToHost));
@@ -1157,6 +1201,11 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
       const double real_in = L.mode == CONV_MODE_STEM ? (double)nb * in.h * in.w * 8 : in_b;
       by = real_in + out_b + (L.d.res >= 0 ? out_b : 0) + (double)L.d.cout * L.kpad * 2;
       snprintf(nm, sizeof nm, "%s", L.d.name);
+      if (stem_pool_fused(m, L)) {   // the kernel writes the pooled tensor only
+        const TDim& po = m->tdims[m->layers[L.fuse_pool].d.dst];
+        by = real_in + (double)nb * po.h * po.w * po.c * 2 + (double)L.d.cout * L.kpad * 2;
+        snprintf(nm, sizeof nm, "%s+maxpool", L.d.name);
+      }
     } else if (L.d.kind == SPK_OP_LINEAR) {
       fl = 2.0 * nb * L.d.cin * L.d.cout;
       by = in_b + out_b + (double)L.d.cin * L.d.cout * 4;
@@ -1171,6 +1220,7 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
       snprintf(nm, sizeof nm, "%s@base.%d",
                L.d.kind == SPK_OP_MAXPOOL ? "maxpool" : (L.d.kind == SPK_OP_GAVGPOOL ? "avgpool" : "dropout"),
                L.d.child);
+      if (L.pooled_by_stem && m->stale_stem_t == L.d.src) by = 0;   // computed inside the stem kernel
     }
     put(nm, ms[i + 1], fl, by);
   }

@@ -92,6 +92,11 @@ struct ConvArgs {
   // channels per pixel as stored in HBM when they differ from the GEMM's 64-padded Cin / Cout (EfficientNet widths
   // are multiples of 8 only): 0 = same.  K chunks past cin_s read as zeros, output columns past cout_s are not stored.
   int cin_s, cout_s;
+  // stem only (conv_stem.hip): when set, the kernel applies the 3x3 stride-2 pad-1 max-pool that follows the stem in
+  // every torchvision ResNet to its own output tile and writes ONLY the pooled tensor [N,pool_ho,pool_wo,64] here
+  // (y is not written).  Needs relu, no stats.
+  bf16_t* pool_y;
+  int pool_ho, pool_wo;
 };
 
 // returns 0 on success; fills *m_tiles with the number of row tiles used

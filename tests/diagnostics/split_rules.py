@@ -29,6 +29,12 @@ for wseed in (-2, 2, 7):   # -2: seed 2 with the calibrated head bias of the gol
     last_stage = {n for n in convs if n.startswith("base.7.")}
     rules = {"all": set(convs), "all-but-inner3x3": set(convs) - k3, "all-but-inner3x3(stages1-3)": set(convs) - (k3 - last_stage),
              "trunk": trunk, "none": set()}
+    early = {n for n in convs if n == "base.0" or n.startswith(("base.4.", "base.5."))}
+    mid = {n for n in convs if n.startswith("base.6.")}
+    rules["stages1-2 (minus inner3x3)"] = early - k3
+    rules["stages1-3 (minus inner3x3)"] = (early | mid) - k3
+    rules["stages1-2 + trunk writers"] = (early - k3) | trunk
+    rules["stages3-4 (minus inner3x3)"] = set(convs) - early - k3
     rules["mode3"] = None   # the library's own rule (spk_model_set_precision(3)): must equal all-but-inner3x3
     worst = {k: [] for k in rules}; rms = {k: [] for k in rules}
     for s in range(n_img // 32):

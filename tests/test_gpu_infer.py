@@ -263,3 +263,29 @@ def test_every_main_loop_flavour_gives_the_same_network_output():
     assert np.abs(ref).max() > 0.1
     for key, z in outs.items():
         assert np.array_equal(z, ref), f"cfg {key[0]} flavour {key[1]}: max diff {np.abs(z - ref).max()}"
+
+
+@pytest.mark.parametrize("shape", [(5, 224, 224), (3, 180, 180), (2, 75, 101), (4, 64, 64), (1, 37, 53)])
+def test_stem_kernel_with_fused_maxpool_equals_stem_then_pool(shape):
+    """The eval path computes the ResNet stem (7x7/2 conv + BN + ReLU) and the 3x3/2 max-pool behind it in one kernel
+    (conv_stem.hip, POOL variant: only the pooled tensor is written).  After a forward the pooled tensor comes from the
+    fused kernel; reading the stem output makes the library run the stem layer alone (un-fused kernel).  Max-pooling
+    that with torch must give the fused kernel's tensor exactly - same roundings, same values - for tile-aligned,
+    odd and non-square sizes (tiles that end mid-image, pooled rows whose window hangs over the border)."""
+    import torch.nn.functional as F
+    n, h, w = shape
+    g = arch.build_graph("resnet18", 5)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=6)
+    net = _hipnet("resnet18", sd, classes=5)
+    x = torch.from_numpy(synth.synth_images(n, 3, h, w, seed=h))
+    net.forward(x.cuda())
+    stem = [op for op in g.ops if op.kind == arch.OP_CONV][0]
+    pool = [op for op in g.ops if op.kind == arch.OP_MAXPOOL][0]
+    assert pool.src == stem.dst
+    ho, wo = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    hp, wp = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    pooled = net.read_activation(pool.dst, n, (n, 64, hp, wp))       # written by the fused kernel
+    stem_out = net.read_activation(stem.dst, n, (n, 64, ho, wo))     # recomputed by the un-fused kernel
+    assert float(stem_out.abs().max()) > 0.1 and float(stem_out.min()) >= 0.0
+    want = F.max_pool2d(stem_out, 3, 2, 1)
+    assert torch.equal(pooled, want), float((pooled - want).abs().max())
