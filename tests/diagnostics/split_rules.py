@@ -35,6 +35,7 @@ for wseed in (-2, 2, 7):   # -2: seed 2 with the calibrated head bias of the gol
     rules["stages1-3 (minus inner3x3)"] = (early | mid) - k3
     rules["stages1-2 + trunk writers"] = (early - k3) | trunk
     rules["stages3-4 (minus inner3x3)"] = set(convs) - early - k3
+    rules["all-but-inner3x3, stem unsplit"] = set(convs) - k3 - {"base.0"}
     rules["mode3"] = None   # the library's own rule (spk_model_set_precision(3)): must equal all-but-inner3x3
     worst = {k: [] for k in rules}; rms = {k: [] for k in rules}
     for s in range(n_img // 32):

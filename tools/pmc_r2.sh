@@ -17,4 +17,4 @@ rm -rf gpurun_out/pmc_${TAG}_sq
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_${TAG}_sq -- python3 bench.py --mode infer --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_${TAG}_sq.err
 S=$(find gpurun_out/pmc_${TAG}_sq -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_mfma.py "$S" gpurun_out/${TAG}_pmc_mfma_util_infer_mixed.json > gpurun_out/${TAG}_pmc_mfma.log
-tail -5 gpurun_out/${TAG}_pmc_traffic.log gpurun_out/${TAG}_pmc_mfma.log
+tail -n 5 gpurun_out/${TAG}_pmc_traffic.log; tail -n 5 gpurun_out/${TAG}_pmc_mfma.log
