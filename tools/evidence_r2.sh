@@ -23,4 +23,7 @@ bash tools/pmc_sq.sh ${T}_r50 --mode both > gpurun_out/${T}_pmc_sq_r50.log 2>&1 
 bash tools/pmc_sq.sh ${T}_b4 --network efficientnet_b4 --batch 256 --precision fp8 --mode infer > gpurun_out/${T}_pmc_sq_b4.log 2>&1 && python3 tools/pmc_sq_table.py ${T}_b4 gpurun_out/${T}_sq_counters_efficientnet_b4_fp8.txt > /dev/null; echo "sq b4 rc=$?"
 timeout -k 10 300 python3 tools/e2e_prob.py 20000 resnet18 > gpurun_out/${T}_e2e_prob.log 2>&1; echo "e2e prob rc=$?"
 timeout -k 10 300 python3 tools/e2e_train.py > gpurun_out/${T}_e2e_train.log 2>&1; echo "e2e train rc=$?"
-tail -3 gpurun_out/${T}_e2e_prob.log gpurun_out/${T}_e2e_train.log
+tail -n 3 gpurun_out/${T}_e2e_prob.log; tail -n 3 gpurun_out/${T}_e2e_train.log
+# gpurun merges at most 64 MiB back: drop the raw traces, keep the summaries
+rm -rf gpurun_out/pmc_* gpurun_out/prof_* gpurun_out/*_pmc_sq_set*.csv
+du -sh gpurun_out
