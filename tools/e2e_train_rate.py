@@ -1,0 +1,70 @@
+"""End-to-end `sykepic train` rate: PNG files on disk -> threaded decode -> GPU resize / augmentation -> ResNet training
+step (all layers unfrozen from epoch 0) -> validation.  Prints images/s of whole epochs (wall clock between the
+"----- Epoch" banners of train.main, validation included) next to the kernel-only rate bench.py reports.
+Usage: python3 tools/e2e_train_rate.py [n_images=12288] [network=resnet50] [size=224] [batch=256]"""
+import contextlib
+import io
+import sys
+import time
+from collections import namedtuple
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT / "syke-pic_amd"), str(ROOT / "tests")]
+import numpy as np
+from PIL import Image
+
+from test_gpu_workflows import INI
+
+n_img = int(sys.argv[1]) if len(sys.argv) > 1 else 12288
+network = sys.argv[2] if len(sys.argv) > 2 else "resnet50"
+size = int(sys.argv[3]) if len(sys.argv) > 3 else 224
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else 256
+tmp = Path("/tmp/e2e_train_rate")
+import shutil
+shutil.rmtree(tmp, ignore_errors=True)
+rng = np.random.RandomState(0)
+classes = 8
+t0 = time.time()
+for ci in range(classes):
+    d = tmp / "ds" / f"class_{ci}"
+    d.mkdir(parents=True)
+    for i in range(n_img // classes):
+        h, w = int(rng.randint(40, 160)), int(rng.randint(60, 300))     # IFCB-like ROI sizes
+        img = np.clip(rng.normal(170 + 6 * ci, 12, (h, w)), 0, 255).astype(np.uint8)
+        Image.fromarray(img).save(d / f"D20200101T000000_IFCB114_{i:05d}.png")
+print(f"{n_img} PNGs written in {time.time() - t0:.1f} s", flush=True)
+ini = INI.format(ds=tmp / "ds", models=tmp / "models")
+ini = ini.replace("network = resnet18", f"network = {network}").replace("shape = 3, 64, 64", f"shape = 3, {size}, {size}")
+ini = ini.replace("batch_size = 16", f"batch_size = {batch}").replace("max_epochs = 8", "max_epochs = 4")
+ini = ini.replace("split = 0.6, 0.2, 0.2", "split = 0.9, 0.05, 0.05").replace("oversample_until = 12", "oversample_until =")
+ini = ini.replace("head = 32, 16", "head = 256, 128").replace("num_workers = 0", "num_workers = 8")
+ini = ini.replace("[lr_warmup]\nuse = yes", "[lr_warmup]\nuse = no")      # every layer trains from the first epoch
+(tmp / "train.ini").write_text(ini)
+
+
+class Stamp(io.TextIOBase):
+    """stdout tee that records the wall-clock time of every epoch banner"""
+
+    def __init__(self, out):
+        self.out, self.marks = out, []
+
+    def write(self, s):
+        if "----- Epoch" in s or "Model Evaluation" in s:
+            self.marks.append((time.time(), s.strip()))
+        return self.out.write(s)
+
+    def flush(self):
+        self.out.flush()
+
+
+from sykepic_hip import train
+Args = namedtuple("Args", "config dist collage")
+tee = Stamp(sys.stdout)
+with contextlib.redirect_stdout(tee):
+    train.main(Args(str(tmp / "train.ini"), False, None))
+marks = tee.marks
+n_train = int(n_img * 0.9)
+for (ta, a), (tb, _) in zip(marks[:-1], marks[1:]):
+    if "Epoch" in a:
+        print(f"{a}: {tb - ta:.2f} s -> {n_train / (tb - ta):.0f} training images/s (epoch wall clock incl. validation)")
