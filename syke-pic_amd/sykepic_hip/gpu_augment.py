@@ -80,8 +80,9 @@ class GpuTransform:
         self.transform, self.device = transform, torch.device(device)
         self.so = lib.load()
 
-    def __call__(self, images):
-        """images: HxWx3 / HxW uint8 arrays whose channels are identical (IFCB PNGs are greyscale)."""
+    def __call__(self, images, modes=None):
+        """images: HxWx3 / HxW uint8 arrays whose channels are identical (IFCB PNGs are greyscale).
+        modes: their most common pixel values when the caller has them already (the decode workers do)."""
         t = self.transform
         th, tw = t.target_dims
         n = len(images)
@@ -94,7 +95,9 @@ class GpuTransform:
             off += g.size
         blob = np.concatenate([np.ascontiguousarray(g).reshape(-1) for g in grey]) if n else np.zeros(1, np.uint8)
         if t.border == "mode":
-            border = np.array([[P.mode_pixel_value(g)] * 4 for g in grey], dtype=np.uint8)
+            if modes is None:
+                modes = [P.mode_pixel_value(g) for g in grey]
+            border = np.repeat(np.asarray(modes, dtype=np.uint8)[:, None], 4, axis=1)
             code = -1
         else:
             border = np.full((n, 4), t.border[0], dtype=np.uint8)
@@ -122,18 +125,78 @@ class GpuTransform:
         return out
 
 
+class _PngDataset:
+    """Map-style dataset for the loader's worker processes: index -> pngio.decode_png."""
+
+    def __init__(self, paths, need_mode):
+        self.paths, self.need_mode = [str(p) for p in paths], need_mode
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        return pngio.decode_png(self.paths[i], self.need_mode)
+
+
+class _IndexedPng(_PngDataset):
+    """... returning (index, decoded image): the consumer needs the labels of exactly these indices."""
+
+    def __getitem__(self, i):
+        return i, pngio.decode_png(self.paths[i], self.need_mode)
+
+
+def _identity(batch):
+    return batch
+
+
+class _EpochBatches:
+    """Batch sampler: a fresh order per epoch - the sampler's, a torch.randperm, or file order - cut into batches."""
+
+    def __init__(self, n, batch_size, shuffle, sampler):
+        self.n, self.batch_size, self.shuffle, self.sampler = n, batch_size, shuffle, sampler
+
+    def order(self):
+        if self.sampler is not None:
+            return list(iter(self.sampler))
+        if self.shuffle:
+            return torch.randperm(self.n).tolist()
+        return list(range(self.n))
+
+    def prepare(self):
+        """Draw the next epoch's order.  The loader calls this once per epoch BEFORE it creates the DataLoader iterator:
+        that constructor asks the batch sampler twice (persistent workers) and takes a seed from torch's global
+        generator in between, which would shift the permutation relative to the single-threaded loader."""
+        order = self.order()
+        self.pending = [order[b:b + self.batch_size] for b in range(0, len(order), self.batch_size)]
+
+    def __iter__(self):
+        if getattr(self, "pending", None) is None:
+            self.prepare()
+        return iter(self.pending)
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None and hasattr(self.sampler, "__len__") else self.n
+        return (n + self.batch_size - 1) // self.batch_size
+
+
 class GpuLoader:
     """Drop-in for the train/val `DataLoader` of `ModelData.set_data_loaders`: PNG decode on the host, the whole
     transform on the GPU; yields (uint8 [B, H, W, 3] cuda tensor, int64 labels) — `HipNet` takes that layout.
 
     Decoding is the only per-image host work left, so it is what has to keep up with the training step
-    (ResNet-50: ~9.4 k img/s per GPU): PNGs are decoded by a pool of `workers` threads (zlib inflate runs outside
-    the GIL) and `prefetch` batches are kept in flight ahead of the consumer, so the GPU step of batch k overlaps
-    the decode of batches k+1 ... k+prefetch.  The random draws of the augmentations stay in the consuming thread,
-    in batch order (`draw_ops`), so a seeded run is reproducible whatever the worker count."""
+    (ResNet-50: ~9.4 k img/s per GPU).  Round 2, measured with `tools/e2e_train_rate.py` (PNG files -> ResNet-50 step,
+    batch 256, a 16-core share of the host): decoding on the training thread fed 3.5 k img/s; a pool of decode THREADS
+    with prefetch 4.6-5.1 k (PIL and the per-image Python around it serialise on the GIL).  So, like the reference's
+    `DataLoader(num_workers=...)` (sykepic/train/data.py:151-160), the images are decoded by `workers` PROCESSES
+    (torch's DataLoader machinery: fork, persistent, two batches prefetched per worker), which also take the border
+    value (pixel histogram) and the colour check of each image; one thread assembles the batches - concatenation,
+    the augmentation draws, the host-to-device copies and the preprocessing / augmentation kernels - up to two
+    batches ahead of the training loop, so that work overlaps the training step as well.  The random draws stay in
+    ONE thread, in batch order (`draw_ops`), so a seeded run is reproducible whatever the worker count; the workers
+    draw nothing."""
 
     def __init__(self, paths, labels, transform, batch_size, device, shuffle=False, sampler=None, workers=None,
-                 prefetch=3):
+                 prefetch=2):
         import os
         self.paths, self.labels = list(paths), list(labels)
         self.batch_size, self.shuffle, self.sampler = int(batch_size), shuffle, sampler
@@ -146,47 +209,76 @@ class GpuLoader:
                 workers = os.cpu_count() or 1
             workers = max(1, min(16, workers))
         self.workers, self.prefetch = int(workers), max(1, int(prefetch))
+        self._need_mode = transform.border == "mode"
+        self._batches_of = _EpochBatches(len(self.paths), self.batch_size, shuffle, sampler)
+        self._dl = None
 
     def __len__(self):
-        n = len(self.sampler) if self.sampler is not None and hasattr(self.sampler, "__len__") else len(self.paths)
-        return (n + self.batch_size - 1) // self.batch_size
+        return len(self._batches_of)
 
-    def _to_batch(self, idx, imgs):
-        if any(im.ndim == 3 and not (np.array_equal(im[..., 0], im[..., 1]) and np.array_equal(im[..., 0], im[..., 2]))
-               for im in imgs):
-            # a colour PNG: the host pipeline handles it
-            x = torch.stack([self.pipe.transform(im) for im in imgs])
+    def _to_batch(self, idx, decoded):
+        imgs = [d[0] for d in decoded]
+        if any(d[1] is None for d in decoded):
+            # a colour PNG in the batch: the host pipeline handles it
+            rgb = [im if im.ndim == 3 else np.repeat(im[:, :, None], 3, axis=2) for im in imgs]
+            x = torch.stack([self.pipe.transform(im) for im in rgb])
         else:
-            x = self.pipe(imgs)
+            x = self.pipe(imgs, [d[1] for d in decoded])
         return x, torch.tensor([int(self.labels[i]) for i in idx], dtype=torch.int64)
 
-    def __iter__(self):
-        from collections import deque
-        from concurrent.futures import ThreadPoolExecutor
-        if self.sampler is not None:
-            order = list(iter(self.sampler))
-        elif self.shuffle:
-            order = torch.randperm(len(self.paths)).tolist()
-        else:
-            order = list(range(len(self.paths)))
-        batches = [order[b:b + self.batch_size] for b in range(0, len(order), self.batch_size)]
+    def _batches(self):
         if self.workers <= 1:
-            for idx in batches:
-                yield self._to_batch(idx, [pngio.read_image(self.paths[i], 3) for i in idx])
+            self._batches_of.prepare()
+            for idx in self._batches_of:
+                yield self._to_batch(idx, [pngio.decode_png(self.paths[i], self._need_mode) for i in idx])
             return
-        pool = ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="sykepic-png")
+        if self._dl is None:
+            from torch.utils.data import DataLoader
+            # batch_sampler yields index lists; the "batch" a worker returns is [(index, decoded image)]
+            self._dl = DataLoader(_IndexedPng(self.paths, self._need_mode), batch_sampler=self._batches_of,
+                                  num_workers=self.workers, collate_fn=_identity, persistent_workers=True,
+                                  prefetch_factor=self.prefetch)
+        self._batches_of.prepare()
+        rng_state = torch.get_rng_state()
+        it = iter(self._dl)                 # draws a worker seed nobody uses: the decode workers are deterministic
+        torch.set_rng_state(rng_state)      # ... so the global generator stays where the single-threaded loader leaves it
+        for items in it:
+            yield self._to_batch([i for i, _ in items], [d for _, d in items])
+
+    def __iter__(self):
+        """Batches assembled by a background thread, at most two ahead of the consumer."""
+        import queue
+        import threading
+        if self.workers <= 1:
+            yield from self._batches()
+            return
+        q = queue.Queue(maxsize=2)
+        end, stop = object(), threading.Event()
+
+        def produce():
+            try:
+                for item in self._batches():
+                    while not stop.is_set():
+                        try:
+                            q.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                    if stop.is_set():
+                        return
+                q.put(end)
+            except BaseException as e:   # surfaces in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=produce, name="sykepic-batch", daemon=True)
+        t.start()
         try:
-            inflight = deque()
-            nxt = 0
-            while nxt < len(batches) and len(inflight) < self.prefetch:
-                inflight.append((batches[nxt], [pool.submit(pngio.read_image, self.paths[i], 3) for i in batches[nxt]]))
-                nxt += 1
-            while inflight:
-                idx, futs = inflight.popleft()
-                imgs = [f.result() for f in futs]
-                if nxt < len(batches):
-                    inflight.append((batches[nxt], [pool.submit(pngio.read_image, self.paths[i], 3) for i in batches[nxt]]))
-                    nxt += 1
-                yield self._to_batch(idx, imgs)
+            while True:
+                item = q.get()
+                if item is end:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
         finally:
-            pool.shutdown(wait=False, cancel_futures=True)
+            stop.set()

@@ -12,3 +12,20 @@ def read_image(path, num_chans=3):
         if num_chans == 3:
             return np.asarray(im.convert("RGB"), dtype=np.uint8)
         return np.asarray(im.convert("L"), dtype=np.uint8)[:, :, None]
+
+
+def decode_png(path, need_mode):
+    """One training image for the GPU input pipeline (gpu_augment.GpuLoader), run in a loader worker process:
+    (grey HxW uint8, border value) for the greyscale PNGs IFCB writes - also when they are stored as RGB with equal
+    channels - or (HxWx3 RGB, None) for a real colour image (the host pipeline takes those).  The grey array equals
+    channel 0 of `read_image(path, 3)`; the border value is `preprocess.mode_pixel_value` of it (most common value,
+    ties: the lowest).  Only numpy and PIL here: the workers never touch torch or the GPU."""
+    with Image.open(path) as im:
+        if im.mode == "L":
+            g = np.asarray(im, dtype=np.uint8)
+        else:
+            rgb = np.asarray(im.convert("RGB"), dtype=np.uint8)
+            if not (np.array_equal(rgb[..., 0], rgb[..., 1]) and np.array_equal(rgb[..., 0], rgb[..., 2])):
+                return rgb, None
+            g = np.ascontiguousarray(rgb[..., 0])
+    return g, (int(np.argmax(np.bincount(g.reshape(-1), minlength=256))) if need_mode else 0)

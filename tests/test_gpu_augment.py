@@ -82,3 +82,47 @@ def test_loader_feeds_the_training_step(tmp_path):
         net.forward_backward(x, y)
         seen += len(y)
     assert seen == 10
+
+
+def test_loader_threads_do_not_change_the_batches(tmp_path):
+    """The decode workers and the batch-assembly thread only move work off the training thread: under the same seeds
+    the batches (augmentations included) are byte-identical to the single-threaded loader, in the same order, and
+    equal to the host pipeline applied image by image.  A grey image stored as RGB takes the GPU path too."""
+    import random
+    from PIL import Image
+    rng = np.random.RandomState(7)
+    paths, labels = [], []
+    for i, im in enumerate(_images(rng, 23)):
+        p = tmp_path / f"img_{i:02d}.png"
+        (Image.fromarray(im) if i == 5 else Image.fromarray(im[..., 0])).save(p)    # i == 5: RGB file, equal channels
+        paths.append(p)
+        labels.append(i % 4)
+    t = P.Compose(PIPELINES["reference default (flip, translate, zoom, brightness)"](), (64, 64), "mode")
+
+    def run(workers):
+        random.seed(11)
+        torch.manual_seed(11)
+        loader = gpu_augment.GpuLoader(paths, labels, t, 6, "cuda:0", shuffle=True, workers=workers)
+        out = [(x.cpu(), y.clone()) for _ in range(2) for x, y in loader]      # two epochs: fresh order each
+        return out, float(torch.rand(1)), random.random()
+
+    (one, t1, r1), (many, t2, r2) = run(1), run(4)
+    assert (t1, r1) == (t2, r2)                      # both generators end where the single-threaded loader leaves them
+    assert len(one) == len(many) == 8
+    assert not torch.equal(one[0][1], one[4][1])     # the second epoch is shuffled anew
+    many_first = many[:4]
+    for (xa, ya), (xb, yb) in zip(one, many):
+        assert torch.equal(ya, yb) and torch.equal(xa, xb)
+    # the host pipeline, image by image, in the loader's order and with the same draws
+    random.seed(11)
+    torch.manual_seed(11)
+    order = torch.randperm(len(paths)).tolist()
+    from sykepic_hip import pngio
+    k = 0
+    for xb, _ in many_first:
+        for j in range(xb.shape[0]):
+            want = t(pngio.read_image(paths[order[k]], 3))              # float CHW in [0, 1]
+            want_u8 = (want * 255.0).round().to(torch.uint8).permute(1, 2, 0)
+            assert torch.equal(xb[j], want_u8), (k, order[k])
+            k += 1
+    assert k == len(paths)

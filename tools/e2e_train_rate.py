@@ -50,13 +50,28 @@ class Stamp(io.TextIOBase):
         self.out, self.marks = out, []
 
     def write(self, s):
-        if "----- Epoch" in s or "Model Evaluation" in s:
+        if "----- Epoch" in s or "Model Evaluation" in s or "[STAT] Train Acc" in s:
             self.marks.append((time.time(), s.strip()))
         return self.out.write(s)
 
     def flush(self):
         self.out.flush()
 
+
+# the input pipeline alone (decode workers -> batch thread -> GPU preprocessing), no training step behind it
+import torch
+from sykepic_hip import gpu_augment, preprocess as P
+paths = sorted((tmp / "ds").rglob("*.png"))
+tf = P.Compose([P.Resize(), P.FlipHorizontal(), P.FlipVertical(), P.Translate(), P.Zoom((0.8, 1.2)),
+                P.ChangeBrightness((0.95, 1.1)), P.ToTensor()], (size, size), "mode")
+for workers in (8, 16):
+    loader = gpu_augment.GpuLoader(paths, [0] * len(paths), tf, batch, "cuda:0", shuffle=True, workers=workers)
+    t0 = time.time()
+    n = 0
+    for x, y in loader:
+        n += len(y)
+    torch.cuda.synchronize()
+    print(f"input pipeline alone, {workers} decode workers: {n / (time.time() - t0):.0f} images/s", flush=True)
 
 from sykepic_hip import train
 Args = namedtuple("Args", "config dist collage")
@@ -65,6 +80,12 @@ with contextlib.redirect_stdout(tee):
     train.main(Args(str(tmp / "train.ini"), False, None))
 marks = tee.marks
 n_train = int(n_img * 0.9)
-for (ta, a), (tb, _) in zip(marks[:-1], marks[1:]):
-    if "Epoch" in a:
-        print(f"{a}: {tb - ta:.2f} s -> {n_train / (tb - ta):.0f} training images/s (epoch wall clock incl. validation)")
+for i, (ta, a) in enumerate(marks):
+    if "Epoch" not in a:
+        continue
+    t_loop = next((tb for tb, b in marks[i + 1:] if "Train Acc" in b), None)
+    t_next = next((tb for tb, b in marks[i + 1:] if "Epoch" in b or "Evaluation" in b), None)
+    if t_loop is None or t_next is None:
+        continue
+    print(f"{a}: training loop {t_loop - ta:.2f} s -> {n_train / (t_loop - ta):.0f} images/s; whole epoch (validation, "
+          f"plots, checkpoint) {t_next - ta:.2f} s -> {n_train / (t_next - ta):.0f} images/s")
