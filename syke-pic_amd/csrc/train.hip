@@ -425,6 +425,18 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   // ------------------------------ backward ------------------------------
   std::vector<char> has_grad(m->n_tensors, 0);
   has_grad[last] = 1;
+  // needs[t]: some parameter with requires_grad sits at or upstream of the layer that produces tensor t, i.e. autograd
+  // would compute dL/dt (sykepic/train/network.py:133-172 freezes the base; with a frozen base `loss.backward()` stops
+  // at the head).  Gradients nobody needs are not computed: during the head-only epochs of the reference's unfreeze
+  // schedule the BatchNorm backward and data-gradient passes through the whole base cost 14 of 23 ms per step.
+  std::vector<char> needs(m->n_tensors, 0);
+  auto trainable = [&](const Layer& Q) {
+    for (int pi : {Q.p_w, Q.p_g, Q.p_b})
+      if (pi >= 0 && m->params[pi].requires_grad) return true;
+    return false;
+  };
+  for (const Layer& Q : m->layers)
+    needs[Q.d.dst] = trainable(Q) || needs[Q.d.src] || (Q.d.kind == SPK_OP_CONV && Q.d.res >= 0 && needs[Q.d.res]);
   int cur_bucket = 0;
   for (int i = nl - 1; i >= 0; --i) {
     Layer& L = m->layers[i];
@@ -434,7 +446,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
       const int b = grad_bucket_of(m, L);
       while (cur_bucket < b) SPK_TRY(grad_bucket_done(m, cur_bucket++));   // backward has left that stage
     }
-    if (!has_grad[L.d.dst]) continue;
+    if (!has_grad[L.d.dst] || !needs[L.d.dst]) continue;
     switch (L.d.kind) {
       case SPK_OP_LINEAR: {
         const float* gy = (const float*)t->G(L.d.dst);
@@ -445,11 +457,12 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                  fout, fin, n, 1.f, 0, s), "linear wgrad");
         if (m->params[L.p_b].requires_grad)
           K_TRY(spk_launch_colsum(gy, t->gbuf + m->params[L.p_b].off, n, fout, s), "bias grad");
-        // dX[n][i] = sum_o gy[n][o] * W[o][i]
-        K_TRY(spk_launch_sgemm(gy, fout, 1, m->P(L.p_w), 1, fin, nullptr, (float*)t->G(L.d.src), fin, 1, n,
-                               fin, fout, 1.f, 0, s), "linear dgrad");
+        if (needs[L.d.src]) {   // dX[n][i] = sum_o gy[n][o] * W[o][i]
+          K_TRY(spk_launch_sgemm(gy, fout, 1, m->P(L.p_w), 1, fin, nullptr, (float*)t->G(L.d.src), fin, 1, n,
+                                 fin, fout, 1.f, 0, s), "linear dgrad");
+          has_grad[L.d.src] = 1;
+        }
         mark(m, PH_HEAD_BWD);
-        has_grad[L.d.src] = 1;
         break;
       }
       case SPK_OP_DROPOUT:
@@ -475,15 +488,15 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* st = t->stats + t->conv[i].stat_off;
         const Param& pg = m->params[L.p_g];
         const Param& pb = m->params[L.p_b];
-        bf16_t* g_res = L.d.res >= 0 ? (bf16_t*)t->G(L.d.res) : nullptr;
+        bf16_t* g_res = L.d.res >= 0 && needs[L.d.res] ? (bf16_t*)t->G(L.d.res) : nullptr;
         K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st,
                                 st + C, m->P(L.p_g), part, coef,
                                 pg.requires_grad ? t->gbuf + pg.off : nullptr,
                                 pb.requires_grad ? t->gbuf + pb.off : nullptr, dy, g_res,
-                                L.d.res >= 0 ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
+                                g_res ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
         mark(m, PH_BN_BWD);
-        if (L.d.res >= 0) has_grad[L.d.res] = 1;
-        if (L.d.src != 0) {
+        if (g_res) has_grad[L.d.res] = 1;
+        if (L.d.src != 0 && needs[L.d.src]) {
           // data gradient: implicit GEMM over the dgrad weight image (stride 2: one launch per parity class)
           SPK_TRY(spk_conv_dgrad_all(dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n,
                                      o.h, o.w, C, in.h, in.w, L.d.cin, L.d.k, L.d.stride, L.d.pad, s));

@@ -1,5 +1,5 @@
 """End-to-end `sykepic train` rate: PNG files on disk -> threaded decode -> GPU resize / augmentation -> ResNet training
-step (all layers unfrozen from epoch 0) -> validation.  Prints images/s of whole epochs (wall clock between the
+step (the reference's unfreeze schedule, compressed: the head alone, then the last stage, then every layer) -> validation.  Prints images/s of whole epochs (wall clock between the
 "----- Epoch" banners of train.main, validation included) next to the kernel-only rate bench.py reports.
 Usage: python3 tools/e2e_train_rate.py [n_images=12288] [network=resnet50] [size=224] [batch=256]"""
 import contextlib
@@ -36,10 +36,11 @@ for ci in range(classes):
 print(f"{n_img} PNGs written in {time.time() - t0:.1f} s", flush=True)
 ini = INI.format(ds=tmp / "ds", models=tmp / "models")
 ini = ini.replace("network = resnet18", f"network = {network}").replace("shape = 3, 64, 64", f"shape = 3, {size}, {size}")
-ini = ini.replace("batch_size = 16", f"batch_size = {batch}").replace("max_epochs = 8", "max_epochs = 4")
+ini = ini.replace("batch_size = 16", f"batch_size = {batch}").replace("max_epochs = 8", "max_epochs = 6")
 ini = ini.replace("split = 0.6, 0.2, 0.2", "split = 0.9, 0.05, 0.05").replace("oversample_until = 12", "oversample_until =")
 ini = ini.replace("head = 32, 16", "head = 256, 128").replace("num_workers = 0", "num_workers = 8")
-ini = ini.replace("[lr_warmup]\nuse = yes", "[lr_warmup]\nuse = no")      # every layer trains from the first epoch
+# the reference's unfreeze schedule, compressed: epochs 1-2 head only, 3 = head + the last two base modules, 4.. = all
+ini = ini.replace("step_1 = 3", "step_1 = 2").replace("step_2 = 5", "step_2 = 3").replace("step_3 = 7", "step_3 = 4")
 (tmp / "train.ini").write_text(ini)
 
 
