@@ -425,14 +425,20 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   // ------------------------------ backward ------------------------------
   std::vector<char> has_grad(m->n_tensors, 0);
   has_grad[last] = 1;
-  // needs[t]: some parameter with requires_grad sits at or upstream of the layer that produces tensor t, i.e. autograd
-  // would compute dL/dt (sykepic/train/network.py:133-172 freezes the base; with a frozen base `loss.backward()` stops
-  // at the head).  Gradients nobody needs are not computed: during the head-only epochs of the reference's unfreeze
-  // schedule the BatchNorm backward and data-gradient passes through the whole base cost 14 of 23 ms per step.
+  // needs[t]: some parameter that the optimizer updates sits at or upstream of the layer that produces tensor t, i.e.
+  // dL/dt changes something.  Gradients nobody needs are not computed, as with autograd.  NOTE the reference's own
+  // schedule never gets there: its freeze() (sykepic/train/network.py:149-172) leaves every BatchNorm of the "frozen"
+  // base trainable and train.py:131 puts them into param group 0, so the data-gradient chain runs down to the stem's
+  // BatchNorm from the first epoch on (head-only epochs: 20.3 ms per ResNet-50 step at batch 256 against 26.9 with
+  // every conv trainable - only the weight-gradient kernels drop out).  The cut applies when a caller freezes the
+  // BatchNorm layers as well, or keeps them out of the optimizer.  A parameter counts when it requires grad AND an
+  // optimizer group holds it (without any optimizer every trainable tensor is in group 0).
   std::vector<char> needs(m->n_tensors, 0);
+  bool any_group = false;
+  for (const Param& p : m->params) any_group |= p.trainable && p.group >= 0;
   auto trainable = [&](const Layer& Q) {
     for (int pi : {Q.p_w, Q.p_g, Q.p_b})
-      if (pi >= 0 && m->params[pi].requires_grad) return true;
+      if (pi >= 0 && m->params[pi].requires_grad && (!any_group || m->params[pi].group >= 0)) return true;
     return false;
   };
   for (const Layer& Q : m->layers)
