@@ -214,3 +214,18 @@ def test_traffic_provenance_digest_is_shared():
     assert mods[0].kernel_source_sha() == mods[1].kernel_source_sha()
     for f in mods[0].TRAFFIC_SOURCES:
         assert (root / "syke-pic_amd" / "csrc" / f).is_file()
+
+
+def test_roi_number_equals_the_reference_expression():
+    """`prob.roi_number` parses without pathlib; same value (or the same ValueError) as the reference's
+    ``int(Path(path).stem.split("_")[-1])`` (sykepic/compute/probability.py:190)."""
+    from pathlib import Path
+    good = ["/x/D20180712T065600_IFCB114_00002.png", "D2018_IFCB114_12345.png", "a/b.c/D_7.png",
+            Path("/x/y/S_00042.png"), "S_00003", ".hidden_5", "x/.h_6.png", "a_b/c_1.d_2.png"]
+    for p in good:
+        assert prob.roi_number(p) == int(Path(p).stem.split("_")[-1]), p
+    for p in ["dir/S_9.tar.gz", "nounderscore.png"]:
+        with pytest.raises(ValueError):
+            int(Path(p).stem.split("_")[-1])
+        with pytest.raises(ValueError):
+            prob.roi_number(p)
