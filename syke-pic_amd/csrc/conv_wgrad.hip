@@ -105,6 +105,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
 
   u32x4_t rdv[DY_IT], rxv[X_IT];
 
+  // (image, output row, output column) of the X_IT pixels this thread fetches, advanced by BK pixels per step with adds
+  // and compares: the two run-time divisions per load (m / HoWo, rem / Wo: ~30 VALU instructions each) used to cost
+  // more issue slots per step than the step's 32 MFMAs (SQ counters: 30 % of the wave cycles issuing VALU, 22.8 M VALU
+  // against 3.1 M LDS instructions per launch)
+  int c_img[X_IT], c_ho[X_IT], c_wo[X_IT];
+#pragma unroll
+  for (int i = 0; i < X_IT; ++i) {
+    const int m = p_begin + x_row + i * X_RPP;
+    c_img[i] = m / HoWo;
+    const int rem = m - c_img[i] * HoWo;
+    c_ho[i] = rem / a.Wo;
+    c_wo[i] = rem - c_ho[i] * a.Wo;
+  }
+  const int adv_rows = BK / a.Wo, adv_cols = BK - adv_rows * a.Wo;   // BK pixels = adv_rows rows + adv_cols columns
+
   auto issue = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < DY_IT; ++i) {
@@ -115,10 +130,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
       const int m = p0 + x_row + i * X_RPP;
-      const int img = m / HoWo;
-      const int rem = m - img * HoWo;
-      const int ho = rem / a.Wo;
-      const int wo = rem - ho * a.Wo;
+      const int img = c_img[i], ho = c_ho[i], wo = c_wo[i];
+      {   // the next step's pixel: m + BK
+        int nw = wo + adv_cols, nh = ho + adv_rows;
+        if (nw >= a.Wo) { nw -= a.Wo; nh += 1; }
+        int ni = img;
+        while (nh >= a.Ho) { nh -= a.Ho; ni += 1; }
+        c_img[i] = ni; c_ho[i] = nh; c_wo[i] = nw;
+      }
       unsigned off = 0x80000000u;
       if (STEM) {
         // column chunk -> (filter row, pixel pair) of the [8 rows][8 taps][4 ch] image
