@@ -208,11 +208,12 @@ class ModelData:
             from . import gpu_augment
             if gpu_augment.supported(train_transform, num_chans) and gpu_augment.supported(eval_transform, num_chans):
                 G = gpu_augment.GpuLoader
+                kw = {"num_chans": num_chans, "workers": num_workers if num_workers and num_workers > 0 else None}
                 self.train_loader = G(train_x, train_y, train_transform, batch_size, device, shuffle=sampler is None,
-                                      sampler=sampler)
-                self.val_loader = G(val_x, val_y, eval_transform, batch_size, device)
+                                      sampler=sampler, **kw)
+                self.val_loader = G(val_x, val_y, eval_transform, batch_size, device, **kw)
                 if self.test_x:
-                    self.test_loader = G(self.test_x, self.test_y, eval_transform, batch_size, device)
+                    self.test_loader = G(self.test_x, self.test_y, eval_transform, batch_size, device, **kw)
                 return
         self.train_loader = DataLoader(train_data, batch_size, shuffle=sampler is None, sampler=sampler,
                                        num_workers=num_workers)

@@ -20,10 +20,16 @@ _KINDS = (P.Resize, P.FlipHorizontal, P.FlipVertical, P.Translate, P.Zoom, P.Rot
 
 
 def supported(transform, num_chans):
-    """Square 3-channel targets, the reference's augmentation set, constant / modal border, no Normalize."""
-    if num_chans != 3 or not isinstance(transform, P.Compose):
+    """Square targets for Zoom / Rotate, the reference's augmentation set, constant / modal border; 3-channel
+    pipelines may end in the ImageNet `Normalize` the reference appends to its TRAIN transform
+    (sykepic/train/config.py:55-56), 1-channel pipelines may not (the host pipeline decides what that means)."""
+    if num_chans not in (1, 3) or not isinstance(transform, P.Compose):
         return False
-    ts = transform.transforms
+    ts = list(transform.transforms)
+    if ts and isinstance(ts[-1], P.Normalize):
+        if num_chans != 3:
+            return False
+        ts = ts[:-1]
     if not ts or not isinstance(ts[0], P.Resize) or not isinstance(ts[-1], P.ToTensor):
         return False
     if any(not isinstance(t, _KINDS) for t in ts) or sum(isinstance(t, P.Resize) for t in ts) != 1:
@@ -37,7 +43,7 @@ def supported(transform, num_chans):
 def draw_ops(transform, dims):
     """Per-sample parameters of every augmentation, drawn exactly as `Compose.__call__` would while processing
     the images one after the other.  dims: [(h, w)] of the decoded images.  -> AugOp array [n_ops][n]."""
-    ts = [t for t in transform.transforms if not isinstance(t, (P.Resize, P.ToTensor))]
+    ts = [t for t in transform.transforms if not isinstance(t, (P.Resize, P.ToTensor, P.Normalize))]
     n = len(dims)
     ops = (lib.AugOp * (len(ts) * n))()
     th, tw = transform.target_dims
@@ -74,11 +80,30 @@ def draw_ops(transform, dims):
 
 
 class GpuTransform:
-    """`Compose` for a list of decoded grey images at once: -> uint8 [n, H, W, 3] on the GPU."""
+    """`Compose` for a list of decoded grey images at once: -> uint8 [n, H, W, num_chans] on the GPU, or - when the
+    pipeline ends in `Normalize` - the float32 [n, 3, H, W] tensor `ToTensor` + `Normalize` give (same float32
+    operations as the host pipeline, through a 3 x 256 table computed on the host)."""
 
-    def __init__(self, transform, device):
-        self.transform, self.device = transform, torch.device(device)
+    def __init__(self, transform, device, num_chans=3):
+        self.transform, self.device, self.num_chans = transform, torch.device(device), int(num_chans)
         self.so = lib.load()
+        last = transform.transforms[-1]
+        self.lut = None
+        if isinstance(last, P.Normalize):
+            # a uint8 pixel has 256 possible values: the 3 x 256 results of ToTensor + Normalize are computed HERE, on
+            # the host, with the host pipeline's own float32 operations, and the GPU only looks them up - bit-equal to
+            # the host pipeline (torch's GPU float division is not correctly rounded: a few ulp off)
+            v = torch.arange(256, dtype=torch.float32).div_(255.0).view(1, 256)
+            self.lut = ((v - last.mean.view(-1, 1)) / last.std.view(-1, 1)).to(self.device)
+
+    def _finish(self, x):
+        """uint8 [n, H, W, 3] -> what the pipeline's tail (channel count, ToTensor, Normalize) makes of it."""
+        if self.num_chans == 1:
+            x = x[..., :1].contiguous()
+        if self.lut is None:
+            return x
+        idx = x.permute(0, 3, 1, 2).long()
+        return torch.stack([self.lut[c][idx[:, c]] for c in range(idx.shape[1])], dim=1)
 
     def __call__(self, images, modes=None):
         """images: HxWx3 / HxW uint8 arrays whose channels are identical (IFCB PNGs are greyscale).
@@ -113,7 +138,7 @@ class GpuTransform:
                                                   C.c_void_p(rois_d.data_ptr()), n, th, tw, code,
                                                   C.c_void_p(x.data_ptr()), stream))
             if n_ops == 0:
-                return x
+                return self._finish(x)
             ops_d = torch.frombuffer(bytearray(bytes(ops)), dtype=torch.uint8).to(dev)
             border_d = torch.from_numpy(border).to(dev)
             out = torch.empty_like(x)
@@ -122,7 +147,7 @@ class GpuTransform:
                                                 C.c_void_p(tmp.data_ptr()), n, th, tw, 3,
                                                 C.c_void_p(ops_d.data_ptr()), n_ops,
                                                 C.c_void_p(border_d.data_ptr()), stream))
-        return out
+        return self._finish(out)
 
 
 class _PngDataset:
@@ -196,11 +221,11 @@ class GpuLoader:
     draw nothing."""
 
     def __init__(self, paths, labels, transform, batch_size, device, shuffle=False, sampler=None, workers=None,
-                 prefetch=2):
+                 prefetch=2, num_chans=3):
         import os
         self.paths, self.labels = list(paths), list(labels)
         self.batch_size, self.shuffle, self.sampler = int(batch_size), shuffle, sampler
-        self.pipe = GpuTransform(transform, device)
+        self.pipe = GpuTransform(transform, device, num_chans)
         self.dataset = self.paths  # len(loader.dataset) is used for the [STAT] lines
         if workers is None:
             try:

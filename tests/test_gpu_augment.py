@@ -54,9 +54,12 @@ def test_gpu_transform_is_byte_identical_to_the_host_pipeline(name, border):
 
 def test_unsupported_pipelines_fall_back():
     t = P.Compose([P.Resize(), P.ToTensor(), P.Normalize(P.IMAGENET_MEAN, P.IMAGENET_STD)], (180, 180), "mode")
-    assert not gpu_augment.supported(t, 3)
+    assert gpu_augment.supported(t, 3) and not gpu_augment.supported(t, 1)      # Normalize: 3-channel pipelines only
     assert not gpu_augment.supported(P.Compose([P.Resize(), P.Zoom((0.8, 1.2)), P.ToTensor()], (120, 180), "mode"), 3)
-    assert not gpu_augment.supported(P.Compose([P.Resize(), P.ToTensor()], (180, 180), "mode"), 1)
+    assert not gpu_augment.supported(P.Compose([P.Resize(), P.Normalize(P.IMAGENET_MEAN, P.IMAGENET_STD), P.ToTensor()],
+                                               (180, 180), "mode"), 3)          # Normalize anywhere but last
+    assert not gpu_augment.supported(P.Compose([P.Resize(), P.ToTensor()], (180, 180), "mode"), 4)
+    assert not gpu_augment.supported(P.Compose([P.Resize(), P.ToTensor()], (180, 180), (10, 20, 30)), 3)
 
 
 def test_loader_feeds_the_training_step(tmp_path):
@@ -126,3 +129,28 @@ def test_loader_threads_do_not_change_the_batches(tmp_path):
             assert torch.equal(xb[j], want_u8), (k, order[k])
             k += 1
     assert k == len(paths)
+
+
+def test_gpu_transform_with_imagenet_normalization_and_one_channel():
+    """The two pipeline tails that used to fall back to host workers: the ImageNet `Normalize` the reference appends to
+    its TRAIN transform (sykepic/train/config.py:55-56) - float32 [n, 3, H, W], bit-equal to ToTensor + Normalize on
+    the host - and 1-channel models ([n, H, W, 1] uint8 = the host pipeline's single channel)."""
+    rng = np.random.RandomState(3)
+    imgs = _images(rng, 10)
+    aug = [P.Resize(), P.FlipHorizontal(), P.FlipVertical(), P.Translate(), P.Zoom((0.7, 1.3)), P.ChangeBrightness((0.9, 1.1))]
+    t = P.Compose(aug + [P.ToTensor(), P.Normalize(P.IMAGENET_MEAN, P.IMAGENET_STD)], (96, 96), "mode")
+    assert gpu_augment.supported(t, 3) and not gpu_augment.supported(t, 1)
+    random.seed(5)
+    want = torch.stack([t(im) for im in imgs])
+    random.seed(5)
+    got = gpu_augment.GpuTransform(t, "cuda:0")(imgs)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (10, 3, 96, 96)
+    assert torch.equal(got.cpu(), want), float((got.cpu() - want).abs().max())
+    t1 = P.Compose(aug + [P.ToTensor()], (96, 96), "mode")
+    assert gpu_augment.supported(t1, 1)
+    random.seed(6)
+    want1 = torch.stack([t1(im[..., :1]) for im in imgs])                       # [n, 1, H, W] float in [0, 1]
+    random.seed(6)
+    got1 = gpu_augment.GpuTransform(t1, "cuda:0", num_chans=1)(imgs)
+    assert got1.dtype == torch.uint8 and tuple(got1.shape) == (10, 96, 96, 1)
+    assert torch.equal(got1.cpu().permute(0, 3, 1, 2), (want1 * 255.0).round().to(torch.uint8))
