@@ -61,7 +61,7 @@ def parse():
 
 # the sources the ResNet inference conv kernels (the roofline's dominant kernel) are built from, and the model code that
 # chooses their precision mode and tiles: the PMC traffic figure is re-taken when any of these changes
-TRAFFIC_SOURCES = ("conv_igemm.hip", "conv3x3_slab.hip", "spk_common.h", "model.hip", "model.h")
+TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_stem.hip", "spk_common.h", "model.hip", "model.h")
 
 
 def kernel_source_sha():

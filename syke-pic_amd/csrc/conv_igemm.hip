@@ -741,13 +741,6 @@ int spk_conv_m_tiles(int M, int Cout, int mode) {
 }
 
 static int launch_with(const ConvArgs& a, int mode, int cfg, hipStream_t s, int* m_tiles_out) {
-  if (cfg >= 100) {  // halo-slab 3x3 kernel (conv3x3_slab.hip)
-    if (spk_conv3x3_slab_eligible(a, mode)) {
-      const int r = spk_conv3x3_slab_launch(a, cfg - 100, s, m_tiles_out);
-      if (r != -3) return r;  // -3: this tile does not exist for the problem
-    }
-    cfg = pick_cfg(a.M, a.Cout);
-  }
   if (cfg == 5 && (a.Cout % 256 || a.splitw)) cfg = 4;
   if ((cfg == 0 || cfg == 4) && a.Cout % 128) cfg = 3;
   switch (cfg) {
@@ -918,24 +911,6 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
           fprintf(stderr, "[spk cand] %dx%d C%d->%d k%d s%d sw%d: cfg %d dma %d %.1f us\n", a.H, a.W, a.Cin, a.Cout,
                   a.kh, a.stride, a.splitw, cfg, dma, ms * 1000.f / 3.f);
         if (ms < best) { best = ms; win = {cfg, dma}; }
-      }
-    }
-    // the halo-slab 3x3 kernel loses to the best implicit-GEMM tile on every ResNet layer measured so far
-    // (DESIGN.md section 5): it joins the tuning only on request
-    static const bool tune_slab = getenv("SPK_TUNE_SLAB") && atoi(getenv("SPK_TUNE_SLAB"));
-    if (tune_slab && spk_conv3x3_slab_eligible(a, mode)) {
-      for (int sc = 0; sc < 4; ++sc) {
-        if (spk_conv3x3_slab_launch(a, sc, s, nullptr)) continue;  // warm-up
-        (void)hipEventRecord(e0, s);
-        for (int r = 0; r < 3; ++r) spk_conv3x3_slab_launch(a, sc, s, nullptr);
-        (void)hipEventRecord(e1, s);
-        if (hipEventSynchronize(e1) != hipSuccess) continue;
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (getenv("SPK_TUNE_LOG") && atoi(getenv("SPK_TUNE_LOG")) > 1)
-          fprintf(stderr, "[spk cand] %dx%d C%d->%d k%d s%d sw%d: slab %d %.1f us\n", a.H, a.W, a.Cin, a.Cout, a.kh,
-                  a.stride, a.splitw, sc, ms * 1000.f / 3.f);
-        if (ms < best) { best = ms; win = {100 + sc, 0}; }
       }
     }
     (void)hipEventDestroy(e0);

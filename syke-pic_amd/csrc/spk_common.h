@@ -103,9 +103,6 @@ struct ConvArgs {
 // (needed to size/finalize the stats partials)
 int spk_conv_launch(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out);
 int spk_conv_m_tiles(int M, int Cout, int mode);
-// 3x3 stride-1 halo-slab forward kernel (conv3x3_slab.hip); cfg 0..3 = 128x64, 256x64, 128x128, 64x64 tiles
-bool spk_conv3x3_slab_eligible(const ConvArgs& a, int mode);
-int spk_conv3x3_slab_launch(const ConvArgs& a, int cfg, hipStream_t s, int* m_tiles_out);
 int spk_conv_stem_launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out);  // conv_stem.hip
 const char* spk_conv_last_config();
 

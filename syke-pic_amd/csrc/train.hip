@@ -174,7 +174,7 @@ static int plan_train(spk_model* m, int n, int h, int w) {
       max_slab = std::max(max_slab, (size_t)sp * L.d.cout * ktot);
       int rpb;
       const int nb = spk_bn_bwd_blocks(M, L.d.cout, &rpb);
-      const size_t fwd_part = (size_t)((M + 60) / 61) * 2 * L.d.cout;  // smallest M tile: 61 rows (64-row halo-slab tile)
+      const size_t fwd_part = (size_t)((M + 60) / 61) * 2 * L.d.cout;  // sized for M tiles of 61 rows (the smallest tile any forward kernel has used; today 64)
       max_part = std::max(max_part, std::max((size_t)nb * 2 * L.d.cout, fwd_part));
       max_c = std::max(max_c, (size_t)L.d.cout);
     } else if (L.d.kind == SPK_OP_MAXPOOL) {

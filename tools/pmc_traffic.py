@@ -15,7 +15,7 @@ import sys
 from pathlib import Path
 
 
-TRAFFIC_SOURCES = ("conv_igemm.hip", "conv3x3_slab.hip", "spk_common.h", "model.hip", "model.h")   # as bench.py
+TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_stem.hip", "spk_common.h", "model.hip", "model.h")   # as bench.py
 
 
 def kernel_source_sha():
