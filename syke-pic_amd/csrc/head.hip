@@ -139,16 +139,17 @@ __global__ void softmax_kernel(const float* __restrict__ z, float* __restrict__ 
 
 // Mean cross-entropy + arg-max accuracy + dlogits in ONE block so that the
 // loss sum has a fixed summation order (bitwise reproducible).
-__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ z,
+__global__ __launch_bounds__(1024) void ce_kernel(const float* __restrict__ z,
                                                  const int64_t* __restrict__ y, int n, int c,
                                                  float* __restrict__ stats,
                                                  float* __restrict__ dz) {
-  __shared__ float s_loss[4];
-  __shared__ float s_corr[4];
+  constexpr int WAVES = 16;   // a row per wave at a time: 4 waves walked 64 rows each, one latency chain per row (92 us)
+  __shared__ float s_loss[WAVES];
+  __shared__ float s_corr[WAVES];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float loss = 0.f, corr = 0.f;
   const float invn = 1.0f / (float)n;
-  for (int row = wave; row < n; row += 4) {
+  for (int row = wave; row < n; row += WAVES) {
     const float* zr = z + (size_t)row * c;
     const int label = (int)y[row];
     float mx = -INFINITY;
@@ -179,9 +180,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ z,
   }
   if (lane == 0) { s_loss[wave] = loss; s_corr[wave] = corr; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    stats[0] += (s_loss[0] + s_loss[1]) + (s_loss[2] + s_loss[3]);
-    stats[1] += (s_corr[0] + s_corr[1]) + (s_corr[2] + s_corr[3]);
+  if (threadIdx.x == 0) {   // fixed order
+    float tl = 0.f, tc = 0.f;
+    for (int q = 0; q < WAVES; ++q) { tl += s_loss[q]; tc += s_corr[q]; }
+    stats[0] += tl;
+    stats[1] += tc;
   }
 }
 
@@ -254,6 +257,6 @@ int spk_launch_softmax(const float* z, float* p, int n, int c, float scale, hipS
 
 int spk_launch_ce(const float* z, const int64_t* y, int n, int c, float* stats, float* dlogits,
                   hipStream_t s) {
-  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, s, z, y, n, c, stats, dlogits);
+  hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(1024), 0, s, z, y, n, c, stats, dlogits);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
