@@ -265,7 +265,7 @@ __global__ void maxpool_idx_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
 }
 
 // gather form: every input pixel sums the gradients of the windows whose
-// saved arg-max points at it (deterministic, no atomics).  blockIdx.y = (image, input row): the thread only splits its
+// saved arg-max points at it (deterministic, no atomics).  blockIdx.x = (image, input row): the thread only splits its
 // index into (column, channel group) - the flat-index version did three 64-bit divisions per element and a run-time
 // `% stride` and `/ stride` per tap, 180 M VALU instructions per ResNet-50 launch (306 us for 565 MB).
 template <int K, int S, int P>   // K == 0: run-time k / stride / pad
@@ -275,11 +275,11 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ gy, const unsigned
   const int k = K ? K : k_rt, stride = K ? S : stride_rt, pad = K ? P : pad_rt;
   const unsigned c8 = (unsigned)c >> 3;
   const unsigned row_items = (unsigned)w * c8;
-  const int img = blockIdx.y / h, iy = blockIdx.y - img * h;
+  const int img = blockIdx.x / h, iy = blockIdx.x - img * h;   // x: up to 2^31-1 blocks (y is limited to 65535)
   const bf16_t* gyi = gy + (size_t)img * ho * wo * c;
   const unsigned char* idxi = idx + (size_t)img * ho * wo * c;
   bf16_t* gxr = gx + ((size_t)img * h + iy) * w * c;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < row_items; i += gridDim.x * blockDim.x) {
+  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < row_items; i += gridDim.y * blockDim.x) {
     const unsigned ix = i / c8, cc = i - ix * c8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -660,7 +660,7 @@ int spk_launch_maxpool_idx(const bf16_t* x, bf16_t* y, unsigned char* idx, int n
 int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* gx, int n, int h, int w,
                            int c, int k, int stride, int pad, int ho, int wo, hipStream_t s) {
   const unsigned row_items = (unsigned)w * (c / 8);
-  const dim3 grid((row_items + 255) / 256, (unsigned)n * h);
+  const dim3 grid((unsigned)n * h, std::min(65535u, (row_items + 255) / 256));
   if (k == 3 && stride == 2 && pad == 1)
     hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, s, gy, idx, gx, n, h, w, c, k, stride, pad, ho, wo);
   else
