@@ -104,6 +104,31 @@ GRAD_READY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_int64, C.c_int64)
 _lib = None
 
 
+def _default_tune_cache():
+    """The kernel tuner's winners persist per machine and per build of the library unless the caller says otherwise:
+    `SPK_TUNE_CACHE=<file>` names the file, `SPK_TUNE_CACHE=off` (or 0 / empty) keeps the choices in the process only.
+    Default: $XDG_CACHE_HOME (or ~/.cache)/sykepic_hip/tune-<size>-<mtime of the .so>.txt - a rebuilt library starts
+    a new file.  Without it every `sykepic prob` process re-times ~40 candidates for each convolution shape before its
+    first batch (0.3 s of a 0.6 s single-sample run, tools/e2e_prob.py)."""
+    import os
+    v = os.environ.get("SPK_TUNE_CACHE")
+    if v is not None:
+        if v.strip().lower() in ("", "0", "off", "none"):
+            del os.environ["SPK_TUNE_CACHE"]
+        return
+    if not os.path.exists("/dev/kfd"):
+        return         # no AMD GPU on this host (build / CPU-test containers): nothing will be tuned, touch nothing
+    try:
+        st = LIB_PATH.stat()
+        base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+        d = os.path.join(base, "sykepic_hip")
+        os.makedirs(d, exist_ok=True)
+        if os.access(d, os.W_OK):
+            os.environ["SPK_TUNE_CACHE"] = os.path.join(d, f"tune-{st.st_size:x}-{int(st.st_mtime):x}.txt")
+    except OSError:
+        pass   # no writable cache directory: tune per process
+
+
 def load():
     """Load the HIP library (once). Raises if it is not built."""
     global _lib
@@ -114,6 +139,7 @@ def load():
             f"{LIB_PATH} not found: the HIP library is not built "
             "(run syke-pic_amd/csrc/build.sh or __graft_entry__.build()); "
             "there is no CPU fallback on the product path")
+    _default_tune_cache()
     lib = C.CDLL(str(LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing

@@ -229,3 +229,25 @@ def test_roi_number_equals_the_reference_expression():
             int(Path(p).stem.split("_")[-1])
         with pytest.raises(ValueError):
             prob.roi_number(p)
+
+
+def test_tune_cache_environment_rules(monkeypatch):
+    """lib._default_tune_cache: an explicit file is kept, `off` / `0` / empty mean "this process only" (the variable is
+    removed before the library reads it), and a host without an AMD GPU gets no cache directory."""
+    import os
+    from sykepic_hip import lib
+    monkeypatch.setenv("SPK_TUNE_CACHE", "/tmp/some/where.txt")
+    lib._default_tune_cache()
+    assert os.environ["SPK_TUNE_CACHE"] == "/tmp/some/where.txt"
+    for off in ("off", "0", "", "None"):
+        monkeypatch.setenv("SPK_TUNE_CACHE", off)
+        lib._default_tune_cache()
+        assert "SPK_TUNE_CACHE" not in os.environ
+    monkeypatch.delenv("SPK_TUNE_CACHE", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", "/tmp/spk_test_cache_home")
+    lib._default_tune_cache()
+    if os.path.exists("/dev/kfd"):
+        assert os.environ["SPK_TUNE_CACHE"].startswith("/tmp/spk_test_cache_home/sykepic_hip/tune-")
+    else:
+        assert "SPK_TUNE_CACHE" not in os.environ and not os.path.exists("/tmp/spk_test_cache_home")
+    monkeypatch.delenv("SPK_TUNE_CACHE", raising=False)
