@@ -42,4 +42,39 @@ __device__ __forceinline__ u32x4_t pack16B(const float* f, float s) {
   return o;
 }
 
+// Tap weights, folded-BN scales and shifts of one channel tile -> LDS, for every depthwise kernel.
+// LDS layout [row][4-channel part][channel group][4] (row = tap, then scale, then shift): the lanes of a wave read
+// consecutive 16-byte slots (the plain [row][channel] layout put a lane's 8 / 16 floats 32 / 64 B from its
+// neighbour's: 2- / 4-way bank conflicts on every weight read, 13-15 conflict cycles per LDS instruction in the e4m3
+// gather kernel).  All of a thread's 16-byte loads are issued before its first LDS store: as a plain
+// `for (i = tid; ...; i += 256) lds[f(i)] = global[g(i)]` loop the (K*K + 2) * 256 / 256 = 11 ... 27 iterations were a
+// chain of dependent L2 round trips at the start of EVERY block (~13 us for k5; a 7x7 or 14x14 layer has ~1800 blocks
+// of ~1 us of work each).
+// groups: channel groups of the tile that exist (ncg); gstride: group stride of the LDS layout (ncg, or the plan's
+// tile width when the kernel addresses with that); channels of groups >= `groups` are stored as zeros.
+template <int K, int CPT>
+__device__ __forceinline__ void stage_dw_weights(float* __restrict__ lds, const float* __restrict__ w,
+                                                 const float* __restrict__ scale, const float* __restrict__ bias, int c_p,
+                                                 int ch0, int groups, int gstride, float w_scale, int tid) {
+  constexpr int ROWS = K * K + 2;
+  constexpr int WV = (ROWS * 256 / 4 + 255) / 256;    // float4 per thread for a full 256-channel tile
+  const int tcs = gstride * CPT;                      // channels the layout holds per row
+  const int total4 = ROWS * tcs / 4;
+  f32x4_t v[WV];
+  int slot[WV];
+#pragma unroll
+  for (int i = 0; i < WV; ++i) {
+    const int j = min(tid + i * 256, total4 - 1) * 4;
+    const int r = j / tcs, c = j - r * tcs;
+    const bool ok = c < groups * CPT;
+    const float* src = r < K * K ? w + (size_t)r * c_p : (r == K * K ? scale : bias);
+    v[i] = *(const f32x4_t*)(src + ch0 + (ok ? c : 0));
+    v[i] *= ok ? (r < K * K ? w_scale : 1.f) : 0.f;
+    slot[i] = ((r * (CPT / 4) + ((c % CPT) >> 2)) * gstride + c / CPT) << 2;
+  }
+#pragma unroll
+  for (int i = 0; i < WV; ++i)
+    if (tid + i * 256 < total4) *(f32x4_t*)(lds + slot[i]) = v[i];
+}
+
 }  // namespace dwu

@@ -52,17 +52,7 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(DwArgs a) {
   const int cg = tid % tcg, lane = tid / tcg;
   const bool ch_ok = cg < ncg;
 
-  for (int i = tid; i < (K * K + 2) * tcs; i += 256) {
-    const int r = i / tcs, c = i - r * tcs;
-    float v = 0.f;
-    if (c < ncg * CPT) {
-      const int gc = cg0 * CPT + c;
-      v = r < K * K ? a.w[(size_t)r * a.c_p + gc] * a.w_scale : (r == K * K ? a.scale[gc] : a.bias[gc]);
-    }
-    // LDS layout [row][4-channel part][channel group][4]: the lanes of a wave read consecutive 16-B slots (the plain
-    // [row][channel] layout put a lane's 8 / 16 floats 32 / 64 B from its neighbour's: 2- / 4-way bank conflicts)
-    sw[(((r * (CPT / 4) + ((c % CPT) >> 2)) * tcg + c / CPT) << 2) + (c & 3)] = v;
-  }
+  stage_dw_weights<K, CPT>(sw, a.w, a.scale, a.bias, a.c_p, cg0 * CPT, ncg, tcg, a.w_scale, tid);   // layout: dw_util.h
 
   const int R = a.R;
   const int NR = (R - 1) * S + K;             // input rows an iteration needs

@@ -9,7 +9,7 @@
 // of 64; padded channels are exactly zero everywhere (zero weights, zero BN scale/shift,
 // SiLU(0) = 0, SE scale 0), so they never contribute.
 // All of these are HBM-bound passes: 16-B per-lane accesses, channels innermost.
-#include "spk_common.h"
+#include "dw_util.h"
 
 #include <algorithm>
 
@@ -190,13 +190,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const bf16_t* __restrict__ 
   const int c8 = c_p >> 3;
   const int cg0 = blockIdx.x * 32;
   const int ncg = min(32, c8 - cg0), tc = ncg * 8;
-  for (int i = threadIdx.x; i < (K * K + 2) * tc; i += 256) {
-    const int r = i / tc, c = i - r * tc;
-    // LDS layout [row][half (4 channels)][channel group][4]: the lanes of a wave read consecutive 16-B slots (with the
-    // plain [row][channel] layout a lane's 8 floats sit 32 B from its neighbour's: 2-way bank conflicts on every read)
-    sm[(((r * 2 + ((c >> 2) & 1)) * ncg + (c >> 3)) << 2) + (c & 3)] =
-        r < K * K ? w[(size_t)r * c_p + cg0 * 8 + c] : (r == K * K ? scale[cg0 * 8 + c] : bias[cg0 * 8 + c]);
-  }
+  dwu::stage_dw_weights<K, 8>(sm, w, scale, bias, c_p, cg0 * 8, ncg, ncg, 1.f, threadIdx.x);   // layout: dw_util.h
   __syncthreads();
   const int rows = 256 / ncg;  // pixel-group lanes
   const int cg = threadIdx.x % ncg, prow = threadIdx.x / ncg;

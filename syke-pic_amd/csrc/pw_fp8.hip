@@ -22,7 +22,7 @@
 // expand layer: many small independent blocks, 5-6 per CU, hide the load-convert-MFMA-store latency chain better than
 // one-deep prefetch in fewer, fatter blocks.)  These layers are HBM-bound (K = 24 ... 2688): the point of fp8 here is the
 // halved bytes of the expanded tensors, not the MFMA rate.
-#include "spk_common.h"
+#include "dw_util.h"
 
 namespace {
 
@@ -338,14 +338,7 @@ __global__ __launch_bounds__(256) void dwconv_fp8_kernel(const unsigned char* __
   const int c16 = c_p / CPT;
   const int cg0 = blockIdx.x * 16;
   const int ncg = min(16, c16 - cg0), tc = ncg * CPT;
-  for (int i = threadIdx.x; i < (K * K + 2) * tc; i += 256) {
-    const int r = i / tc, c = i - r * tc;
-    // LDS layout [row][quarter (4 channels)][channel group][4]: the lanes of a wave read consecutive 16-B slots (with
-    // the plain [row][channel] layout a lane's 16 floats sit 64 B from its neighbour's: 4-way bank conflicts on every
-    // weight read - measured 13-15 conflict cycles per LDS instruction)
-    sm[(((r * 4 + ((c >> 2) & 3)) * ncg + (c >> 4)) << 2) + (c & 3)] =
-        r < K * K ? w[(size_t)r * c_p + cg0 * CPT + c] * in_scale : (r == K * K ? scale[cg0 * CPT + c] : bias[cg0 * CPT + c]);
-  }
+  dwu::stage_dw_weights<K, CPT>(sm, w, scale, bias, c_p, cg0 * CPT, ncg, ncg, in_scale, threadIdx.x);   // layout: dw_util.h
   __syncthreads();
   const int rows = 256 / ncg;
   const int cg = threadIdx.x % ncg, prow = threadIdx.x / ncg;
