@@ -78,13 +78,22 @@ __global__ __launch_bounds__(256) void stem3x3_kernel(const bf16_t* __restrict__
                                                       int h, int wid, int wstride, int ho, int wo, int c, int c_p,
                                                       int act) {
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [27 (tap, channel)][c], scale[c], bias[c]
-  for (int i = threadIdx.x; i < 27 * c; i += 256) {
-    const int k = i / c, col = i - k * c;                    // k = tap*3 + channel
-    sw[i] = w[(size_t)((k / 3) * 4 + k % 3) * c_p + col];    // source rows are [tap][4 channels] x c_p
-  }
-  for (int i = threadIdx.x; i < c; i += 256) {
-    sw[27 * c + i] = scale[i];
-    sw[28 * c + i] = bias[i];
+  {
+    // 29 rows of c floats as 16-byte loads, all issued before the first LDS store (c <= 256: at most 8 per thread); as a
+    // load-store loop this was a chain of L2 round trips at the start of each of the 14 k blocks of a batch of 256
+    constexpr int WV = (29 * 256 / 4 + 255) / 256;
+    const int total4 = 29 * c / 4;
+    f32x4_t v[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int j = min((int)threadIdx.x + i * 256, total4 - 1) * 4;
+      const int k = j / c, col = j - k * c;                  // k = tap*3 + channel, then scale, then shift
+      const float* src = k < 27 ? w + (size_t)((k / 3) * 4 + k % 3) * c_p : (k == 27 ? scale : bias);   // [tap][4 ch] x c_p
+      v[i] = *(const f32x4_t*)(src + col);
+    }
+#pragma unroll
+    for (int i = 0; i < WV; ++i)
+      if ((int)threadIdx.x + i * 256 < total4) *(f32x4_t*)(sw + ((int)threadIdx.x + i * 256) * 4) = v[i];
   }
   __syncthreads();
   // a block owns STEM_ROWS output rows of one image: image and row come from the block index (scalar), the only
@@ -364,9 +373,20 @@ __global__ __launch_bounds__(256) void se_fc2_kernel(const float* __restrict__ h
   extern __shared__ float sh[];  // hid[sq][IPB]
   const int img0 = blockIdx.x * SE_IPB;
   const int nim = min(SE_IPB, n - img0);
-  for (int k = threadIdx.x; k < sq * SE_IPB; k += 256) {
-    const int j = k / SE_IPB, im = k - j * SE_IPB;
-    sh[k] = im < nim ? hid[(size_t)(img0 + im) * sq + j] : 0.f;
+  for (int k0 = 0; k0 < sq * SE_IPB; k0 += 4 * 256) {   // four loads in flight per thread, then the stores
+    float hv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = min(k0 + u * 256 + (int)threadIdx.x, sq * SE_IPB - 1);
+      const int j = k / SE_IPB, im = k - j * SE_IPB;
+      hv[u] = hid[(size_t)(img0 + min(im, nim - 1)) * sq + j];
+      if (im >= nim) hv[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * 256 + (int)threadIdx.x;
+      if (k < sq * SE_IPB) sh[k] = hv[u];
+    }
   }
   __syncthreads();
   const int i = blockIdx.y * 256 + threadIdx.x;
