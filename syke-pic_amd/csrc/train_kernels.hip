@@ -188,40 +188,56 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
 
 // stage 3: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); the
 // shortcut branch receives dz itself (g_res = dz or += dz).
-__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ g, const unsigned char* __restrict__ mask,
-                                    const bf16_t* __restrict__ y, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ coef,
-                                    bf16_t* __restrict__ dy, bf16_t* __restrict__ g_res,
-                                    int res_accumulate, size_t n8, int C, int relu) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ g, const unsigned char* __restrict__ mask, const bf16_t* __restrict__ y,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+    bf16_t* __restrict__ dy, bf16_t* __restrict__ g_res, int res_accumulate, int M, int C, int relu, int rows_per_block) {
+  // A thread owns ONE 8-channel chunk (the five per-channel constants live in registers) and walks rows: the flat-index
+  // version paid a 64-bit `i % c8` and 40 per-channel loads for every 16 bytes of dy (bn_bwd 7.5 -> 6.8 ms per ResNet-50
+  // step).  The same rewrite of bn_apply_kernel (two constants per channel) measured 3 % slower than its flat form, and
+  // unrolling the row loop by four made both slower: neither is kept.
   const int c8 = C >> 3;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8;
-       i += (size_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(i % c8) * 8;
-    float gv[8], yv[8], o[8];
-    unpack8(*(const u32x4_t*)(g + i * 8), gv);
-    unpack8(*(const u32x4_t*)(y + i * 8), yv);
-    if (relu) {
-      const unsigned bits = mask[i];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gv[j] = (bits >> j) & 1u ? gv[j] : 0.f;
-    }
-    if (g_res) {
-      if (res_accumulate) {
-        float rv[8];
-        unpack8(*(const u32x4_t*)(g_res + i * 8), rv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) rv[j] += gv[j];
-        *(u32x4_t*)(g_res + i * 8) = pack8(rv);
-      } else {
-        *(u32x4_t*)(g_res + i * 8) = pack8(gv);
-      }
-    }
+  const int tpr = c8 < 256 ? c8 : 256;
+  const int rif = 256 / tpr;
+  const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
+  const int row0 = blockIdx.x * rows_per_block, row1 = min(M, row0 + rows_per_block);
+  if (lane_r >= rif) return;
+  for (int cc8 = lane_c; cc8 < c8; cc8 += tpr) {
+    const int cc = cc8 * 8;
+    float mu[8], is[8], k0[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xh = (yv[j] - mean[cc + j]) * invstd[cc + j];
-      o[j] = coef[2 * C + cc + j] * (gv[j] - coef[cc + j] - xh * coef[C + cc + j]);
+      mu[j] = mean[cc + j]; is[j] = invstd[cc + j];
+      k0[j] = coef[cc + j]; k1[j] = coef[C + cc + j]; k2[j] = coef[2 * C + cc + j];
     }
-    *(u32x4_t*)(dy + i * 8) = pack8(o);
+    for (int r = row0 + lane_r; r < row1; r += rif) {
+      const size_t i = (size_t)r * c8 + cc8;
+      float gv[8], yv[8], o[8];
+      unpack8(*(const u32x4_t*)(g + i * 8), gv);
+      unpack8(*(const u32x4_t*)(y + i * 8), yv);
+      if (relu) {
+        const unsigned bits = mask[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[j] = (bits >> j) & 1u ? gv[j] : 0.f;
+      }
+      if (g_res) {
+        if (res_accumulate) {
+          float rv[8];
+          unpack8(*(const u32x4_t*)(g_res + i * 8), rv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) rv[j] += gv[j];
+          *(u32x4_t*)(g_res + i * 8) = pack8(rv);
+        } else {
+          *(u32x4_t*)(g_res + i * 8) = pack8(gv);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (yv[j] - mu[j]) * is[j];
+        o[j] = k2[j] * (gv[j] - k0[j] - xh * k1[j]);
+      }
+      *(u32x4_t*)(dy + i * 8) = pack8(o);
+    }
   }
 }
 
@@ -583,6 +599,16 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ gy, const unsigned 
     gx[i] = mask[i] ? gy[i] * scale : 0.f;
 }
 
+// rows per block of the row-walking BatchNorm backward apply kernel: each thread takes >= 8 rows (its per-channel
+// constants are loaded once), about 16 blocks per CU over the tensor
+inline int pointwise_rows(int M, int C, int* rows_per_block) {
+  const int c8 = C >> 3, tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
+  int rpb = rif * 8;
+  while ((M + rpb - 1) / rpb > 256 * 16) rpb *= 2;
+  *rows_per_block = rpb;
+  return (M + rpb - 1) / rpb;
+}
+
 inline int grid_for(size_t total, int block) {
   size_t g = (total + block - 1) / block;
   if (g > 256 * 8 * 4) g = 256 * 8 * 4;
@@ -643,9 +669,10 @@ int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* a, const bf16_t* y, 
   const float* fin = presum(partials, &nb, C, tmp, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, fin, nb, C,
                      (double)M, gamma, invstd, dgamma, dbeta, coef);
-  const size_t n8 = (size_t)M * C / 8;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, s, g, a, y, mean,
-                     invstd, coef, dy, g_res, res_accumulate, n8, C, relu);
+  int arpb = 0;
+  const int anb = pointwise_rows(M, C, &arpb);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(anb), dim3(256), 0, s, g, a, y, mean, invstd, coef, dy, g_res,
+                     res_accumulate, M, C, relu, arpb);
   return LAUNCH_OK();
 }
 
