@@ -88,19 +88,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
   const int p_begin = split * a.pix_per_split;
   const int p_end = min(a.M, p_begin + a.pix_per_split);
 
-  int tap_r = 0, tap_s = 0, ci0 = 0;
-  if (!STEM) {
-    const int tap = kcol0 / a.Cin;
-    ci0 = kcol0 - tap * a.Cin;
-    tap_r = tap / a.kw;
-    tap_s = tap - tap_r * a.kw;
-  }
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, a.dy_bytes, 0x00020000);
 
   const int d_ch = tid % DY_CPR, d_row = tid / DY_CPR;
   const int x_ch = tid % X_CPR, x_row = tid / X_CPR;
+  // filter tap and input channel of THIS thread's 8-channel column chunk: a column tile may span several taps (Cin = 64
+  // with 128-column tiles: half the dy re-reads of the 64-column tiles, whose 16 KB of loads per 8 MFMAs were bound by
+  // the L2 -> LDS rate) and may hang over Ktot (those columns load zeros and are not stored)
+  int tap_r = 0, tap_s = 0, ci0 = 0;
+  bool col_ok = true;
+  if (!STEM) {
+    const int kc = kcol0 + x_ch * 8;
+    col_ok = kc < a.Ktot;
+    const int tap = kc / a.Cin;
+    ci0 = kc - tap * a.Cin;
+    tap_r = tap / a.kw;
+    tap_s = tap - tap_r * a.kw;
+  }
   const int HoWo = a.Ho * a.Wo;
 
   u32x4_t rdv[DY_IT], rxv[X_IT];
@@ -147,8 +153,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
           off = (unsigned)((((img * a.H + hi) * a.W + px) * 4) * 2);
       } else {
         const int hi = ho * a.stride - a.pad + tap_r, wi = wo * a.stride - a.pad + tap_s;
-        if (m < p_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
-          off = (unsigned)((((img * a.H + hi) * a.W + wi) * a.Cin + ci0 + x_ch * 8) * 2);
+        if (col_ok && m < p_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W)
+          off = (unsigned)((((img * a.H + hi) * a.W + wi) * a.Cin + ci0) * 2);
       }
       rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
     }
@@ -207,14 +213,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wr * WCO + i * 16 + fq * 4 + r;
         const int kc = kcol0 + wc * WCI + j * 16 + fr;
-        slab[(size_t)co * a.Ktot + kc] = acc[i][j][r];
+        if (kc < a.Ktot) slab[(size_t)co * a.Ktot + kc] = acc[i][j][r];
       }
 }
 
 template <int BCO, int BCI, bool STEM, int NBUF>
 int launch_nb(const WgradArgs& a, int splits, hipStream_t s) {
   const int co_tiles = a.Cout / BCO;
-  const int k_tiles = a.Ktot / BCI;
+  const int k_tiles = (a.Ktot + BCI - 1) / BCI;
   const size_t lds = NBUF * (size_t)64 * (BCO + BCI) * 2;
   auto k = conv_wgrad_kernel<BCO, BCI, STEM, NBUF>;
   static bool attr = false;
@@ -339,6 +345,10 @@ int spk_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* slabs, int N, int
     return launch<64, 128, true>(a, splits, s);
   }
   if (Cin % 128 == 0) {
+    if (Cout % 128 == 0) return launch<128, 128, false>(a, splits, s);
+    return launch<64, 128, false>(a, splits, s);
+  }
+  if (a.Ktot >= 256) {   // several taps per 128-column tile (the last tile may hang over Ktot)
     if (Cout % 128 == 0) return launch<128, 128, false>(a, splits, s);
     return launch<64, 128, false>(a, splits, s);
   }
