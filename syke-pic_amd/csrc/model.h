@@ -97,6 +97,9 @@ struct spk_model {
   bool fp8_packed = false;
   unsigned char* w8pack = nullptr;
   float* s8 = nullptr;
+  unsigned char* fp8_shadow = nullptr;  // fp8 mode: e4m3 copy of the trunk tensor the last project conv wrote (pw_fp8.hip)
+  size_t fp8_shadow_bytes = 0;
+  int shadow_t = -1, shadow_stride = 0;  // ... its tensor id (-1: none valid) and row stride in bytes
   int cur_dw_chunks = 0;             // pool-partial rows per image the depthwise layer that ran last wrote
   const float* cur_gate = nullptr;   // gates of the squeeze-excitation op that ran last (consumed by the project conv)
   int cur_gate_stride = 0;

@@ -273,6 +273,7 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->scale_bias) hipFree(m->scale_bias);
   if (m->dwpack) hipFree(m->dwpack);
   if (m->w8pack) hipFree(m->w8pack);
+  if (m->fp8_shadow) hipFree(m->fp8_shadow);
   if (m->s8) hipFree(m->s8);
   if (m->side) hipStreamDestroy(m->side);
   if (m->fork) hipEventDestroy(m->fork);
@@ -817,8 +818,11 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
       const int kpad = (L.d.cin + 63) / 64 * 64;
       const float ys = fp8_scale_of(L.amax_out);
       m->t_fp8_scale[L.d.dst] = ys;
-      if (spk_launch_pw_fp8(m->T(L.d.src), 0, m->w8pack + L.w8_off, m->T(L.d.dst), 1, nullptr, m->s8 + L.s8_off + L.cout_p,
-                            sc + L.cout_p, nullptr, 0, in.h * in.w, nb * o.h * o.w, kpad, L.cout_p, in.c, o.c, L.d.relu,
+      // the trunk as e4m3 bytes when the previous block's project conv left them (same bytes as converting here)
+      const bool shadow = m->shadow_t == L.d.src && m->fp8_shadow;
+      if (spk_launch_pw_fp8(shadow ? (const void*)m->fp8_shadow : m->T(L.d.src), shadow ? 1 : 0, m->w8pack + L.w8_off,
+                            m->T(L.d.dst), 1, nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p, nullptr, 0, in.h * in.w,
+                            nb * o.h * o.w, kpad, L.cout_p, shadow ? m->shadow_stride : in.c, o.c, L.d.relu,
                             1.f / fp8_scale_of(L.amax_in), 1.f / ys, m->stream))
         return fail(SPK_ERR_HIP, std::string("fp8 expand conv launch failed for ") + L.d.name);
       return SPK_OK;
@@ -863,11 +867,35 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
       if (se_src < 0 || !m->cur_gate) return fail(SPK_ERR_STATE, "fp8 project conv without its squeeze-excitation gate");
       const TDim& e = m->tdims[se_src];
       const int kpad = (L.d.cin + 63) / 64 * 64;
+      // the next block's expand conv reads this output: leave it an e4m3 copy (one buffer, re-used block after block -
+      // the launches are ordered on the stream)
+      unsigned char* y8 = nullptr;
+      int y8_stride = 0;
+      float y8_inv = 0.f;
+      m->shadow_t = -1;
+      const char* sh_env = getenv("SPK_FP8_SHADOW");   // 0: the expand convs convert the fp16 trunk themselves (same result)
+      for (const Layer& E : m->layers)
+        if (E.fp8_role == 1 && E.d.src == L.d.dst && !(sh_env && atoi(sh_env) == 0)) {
+          y8_stride = (o.c + 15) / 16 * 16;
+          const size_t need = (size_t)m->cap_n * o.h * o.w * y8_stride;
+          if (need > m->fp8_shadow_bytes) {
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (m->fp8_shadow) HIP_TRY(hipFree(m->fp8_shadow));
+            m->fp8_shadow = nullptr;
+            m->fp8_shadow_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&m->fp8_shadow, need));
+            m->fp8_shadow_bytes = need;
+          }
+          y8 = m->fp8_shadow;
+          y8_inv = 1.f / fp8_scale_of(E.amax_in);
+          break;
+        }
       if (spk_launch_pw_fp8(m->T(se_src), 1, m->w8pack + L.w8_off, m->T(L.d.dst), 0,
                             L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p,
                             m->cur_gate, m->cur_gate_stride, e.h * e.w, nb * o.h * o.w, kpad, L.cout_p, e.c, o.c, L.d.relu,
-                            1.f, 1.f, m->stream))
+                            1.f, 1.f, m->stream, y8, y8_stride, y8_inv))
         return fail(SPK_ERR_HIP, std::string("fp8 project conv launch failed for ") + L.d.name);
+      if (y8) { m->shadow_t = L.d.dst; m->shadow_stride = y8_stride; }
       m->t_fp8_scale[L.d.dst] = 0.f;
       return SPK_OK;
     }
@@ -981,6 +1009,7 @@ static int prefix_layers(const spk_model* m, int nb, int* mb_out) {
 static int run_layers_eval(spk_model* m, int nb) {
   static const bool two = getenv("SPK_SIDE_STREAM") && atoi(getenv("SPK_SIDE_STREAM")) != 0;
   m->last_eval_nb = nb;
+  m->shadow_t = -1;
   bool any = false;
   for (const Layer& L : m->layers) any |= L.side_branch;
   if (!two || !any) {

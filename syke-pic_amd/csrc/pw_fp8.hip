@@ -53,6 +53,12 @@ struct PwArgs {
   float a_inv_scale;    // fp16 A: x * a_inv_scale -> e4m3
   float y_inv_scale;    // e4m3 output: value * y_inv_scale -> e4m3
   unsigned int x_bytes;
+  // fp16 output only: an e4m3 copy of the (fp16-rounded) output, [M][y8_stride] bytes = e4m3(value * y8_inv_scale), columns
+  // past cout_s zero - the A operand of the NEXT block's expand conv, which then skips its fp16 -> e4m3 conversion (that
+  // conversion, repeated for each of its 3 ... 42 N tiles, was 35-45 % of the expand kernels' time)
+  unsigned char* y8;
+  int y8_stride;
+  float y8_inv_scale;
 };
 
 __device__ __forceinline__ int lds_byte(int row, int granule) {   // granule: 8-B unit within the 64-B row
@@ -225,7 +231,19 @@ __global__ __launch_bounds__(256) void pw_fp8_kernel(PwArgs a, int m_tiles, int 
 #pragma unroll
         for (int j = 0; j < 4; ++j) ov[j] = pack2<DT_F16>(v[2 * j], v[2 * j + 1]);
         *(u32x4_t*)((bf16_t*)a.y + o) = ov;
+        if (a.y8) {   // the same bytes the expand loader would make of the stored fp16 values
+          const float s8 = a.y8_inv_scale;
+          float r[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { r[2 * j] = lo_f32<DT_F16>(ov[j]) * s8; r[2 * j + 1] = hi_f32<DT_F16>(ov[j]) * s8; }
+          u32x2_t o8;
+          o8[0] = cvt4_fp8(r[0], r[1], r[2], r[3]);
+          o8[1] = cvt4_fp8(r[4], r[5], r[6], r[7]);
+          *(u32x2_t*)(a.y8 + (size_t)m * a.y8_stride + gcol) = o8;
+        }
       }
+    } else if (!OUT_FP8 && a.y8 && m < a.M && gcol < a.y8_stride) {
+      *(u32x2_t*)(a.y8 + (size_t)m * a.y8_stride + gcol) = u32x2_t{0u, 0u};   // padding columns of the e4m3 copy
     }
     }
     __builtin_amdgcn_wave_barrier();
@@ -287,7 +305,8 @@ int launch_pw(const PwArgs& a, hipStream_t s) {
 // gate (a_fp8 only): fp32 [M / hw][gate_stride] multiplied into the A operand.  Returns 0 / -1 / -2 (unsupported).
 int spk_launch_pw_fp8(const void* x, int a_fp8, const unsigned char* w, void* y, int out_fp8, const bf16_t* res,
                       const float* scale, const float* bias, const float* gate, int gate_stride, int hw, int M, int Kpad,
-                      int Npad, int cin_s, int cout_s, int act, float a_inv_scale, float y_inv_scale, hipStream_t s) {
+                      int Npad, int cin_s, int cout_s, int act, float a_inv_scale, float y_inv_scale, hipStream_t s,
+                      unsigned char* y8, int y8_stride, float y8_inv_scale) {
   if (M < 1 || Kpad % 64 || Npad % 64 || cout_s % 8 || (a_fp8 ? cin_s % 16 : cin_s % 8) || (out_fp8 && res) ||
       (gate && !a_fp8) || (size_t)M * cin_s * (a_fp8 ? 1 : 2) >= ((size_t)1 << 31))
     return -2;
@@ -296,8 +315,10 @@ int spk_launch_pw_fp8(const void* x, int a_fp8, const unsigned char* w, void* y,
   a.M = M; a.Kpad = Kpad; a.Npad = Npad; a.cin_s = cin_s; a.cout_s = cout_s; a.hw = hw > 0 ? hw : 1;
   a.gate_stride = gate_stride; a.act = act; a.a_inv_scale = a_inv_scale; a.y_inv_scale = y_inv_scale;
   a.x_bytes = (unsigned)((size_t)M * cin_s * (a_fp8 ? 1 : 2));
+  if (y8 && (out_fp8 || y8_stride % 8 || y8_stride < cout_s || y8_stride > Npad)) return -2;
+  a.y8 = y8; a.y8_stride = y8_stride; a.y8_inv_scale = y8_inv_scale;
   if (a_fp8) {
-    if (out_fp8) return -2;
+    if (out_fp8) return gate ? -2 : launch_pw<true, false, true>(a, s);
     return gate ? launch_pw<true, true, false>(a, s) : launch_pw<true, false, false>(a, s);
   }
   return out_fp8 ? launch_pw<false, false, true>(a, s) : launch_pw<false, false, false>(a, s);

@@ -138,7 +138,8 @@ int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, 
 // fp8 (e4m3) mode of the MBConv interior (pw_fp8.hip)
 int spk_launch_pw_fp8(const void* x, int a_fp8, const unsigned char* w, void* y, int out_fp8, const bf16_t* res,
                       const float* scale, const float* bias, const float* gate, int gate_stride, int hw, int M, int Kpad,
-                      int Npad, int cin_s, int cout_s, int act, float a_inv_scale, float y_inv_scale, hipStream_t s);
+                      int Npad, int cin_s, int cout_s, int act, float a_inv_scale, float y_inv_scale, hipStream_t s,
+                      unsigned char* y8 = nullptr, int y8_stride = 0, float y8_inv_scale = 0.f);   // e4m3 copy of an fp16 output
 int spk_launch_pack_fp8(const float* w, unsigned char* out, float* wscale_out, int cout, int cin, int Npad, int Kpad,
                         float col_scale, hipStream_t s);
 int spk_launch_absmax_f16(const bf16_t* x, size_t n8, unsigned int* out_bits, hipStream_t s);

@@ -131,6 +131,15 @@ def test_efficientnet_fp8_mode(golden_dir, network):
     calib = torch.from_numpy(synth.synth_images(16, 3, 224, 224, seed=99)).cuda()
     net.set_fp8(True, calibration_batch=calib)
     p8 = net.probabilities(x).cpu()
+    # the project convs leave an e4m3 copy of the trunk for the next expand conv (no conversion in its loader): it must
+    # hold exactly the bytes the loader would have made, i.e. the network output does not change by a bit
+    import os
+    os.environ["SPK_FP8_SHADOW"] = "0"
+    try:
+        p8_converting = net.probabilities(x).cpu()
+    finally:
+        del os.environ["SPK_FP8_SHADOW"]
+    assert torch.equal(p8, p8_converting)
     # the expanded tensor (expand conv output) of the second MBConv block with an expand conv, read back dequantised
     from oracle import graph_eval
     exp_ops = [o for o in g.ops if o.kind == 1 and o.k == 1 and int(o.relu) == 2 and o.cout % 16 == 0 and o.src != 0]
