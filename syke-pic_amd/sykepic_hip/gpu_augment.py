@@ -213,7 +213,7 @@ class GpuLoader:
     batch 256, a 16-core share of the host): decoding on the training thread fed 3.5 k img/s; a pool of decode THREADS
     with prefetch 4.6-5.1 k (PIL and the per-image Python around it serialise on the GIL).  So, like the reference's
     `DataLoader(num_workers=...)` (sykepic/train/data.py:151-160), the images are decoded by `workers` PROCESSES
-    (torch's DataLoader machinery: fork, persistent, two batches prefetched per worker), which also take the border
+    (torch's DataLoader machinery: fork at construction, persistent, two batches prefetched per worker), which also take the border
     value (pixel histogram) and the colour check of each image; one thread assembles the batches - concatenation,
     the augmentation draws, the host-to-device copies and the preprocessing / augmentation kernels - up to two
     batches ahead of the training loop, so that work overlaps the training step as well.  The random draws stay in
@@ -225,18 +225,49 @@ class GpuLoader:
         import os
         self.paths, self.labels = list(paths), list(labels)
         self.batch_size, self.shuffle, self.sampler = int(batch_size), shuffle, sampler
-        self.pipe = GpuTransform(transform, device, num_chans)
         self.dataset = self.paths  # len(loader.dataset) is used for the [STAT] lines
         if workers is None:
             try:
                 workers = len(os.sched_getaffinity(0))
             except AttributeError:  # pragma: no cover
                 workers = os.cpu_count() or 1
-            workers = max(1, min(16, workers))
+            workers = max(1, min(8, workers))     # 8 decode processes feed ~26 k img/s
         self.workers, self.prefetch = int(workers), max(1, int(prefetch))
         self._need_mode = transform.border == "mode"
         self._batches_of = _EpochBatches(len(self.paths), self.batch_size, shuffle, sampler)
         self._dl = None
+        self._start_workers()     # before this loader touches the GPU (the Normalize table below does)
+        self.pipe = GpuTransform(transform, device, num_chans)
+
+    def _start_workers(self):
+        """Fork the decode processes NOW, from the thread that constructs the loader - train.main builds its loaders
+        before the network exists - instead of from the batch-assembly thread in the middle of training: a child forked
+        while other threads are inside the HIP runtime inherits whatever locks they hold (one worker in ~20 runs of the
+        end-to-end test died with "exited unexpectedly").  The processes are persistent; an empty epoch brings them
+        up, and torch's generator is put back so the epoch orders stay those of the single-threaded loader."""
+        if self.workers <= 1 or not self.paths:
+            return
+        from torch.utils.data import DataLoader
+        # batch_sampler yields index lists; the "batch" a worker returns is [(index, decoded image)]
+        self._dl = DataLoader(_IndexedPng(self.paths, self._need_mode), batch_sampler=self._batches_of,
+                              num_workers=self.workers, collate_fn=_identity, persistent_workers=True,
+                              prefetch_factor=self.prefetch)
+        self._batches_of.pending = []
+        rng_state = torch.get_rng_state()
+        # torch installs a SIGCHLD handler (main thread only) that raises "DataLoader worker ... is killed" at an arbitrary
+        # point of the MAIN thread when a worker dies - in the middle of a training step, say.  The thread that iterates
+        # the DataLoader notices a dead worker by itself and this loader then decodes in-process (`_batches`), so the
+        # previous handler is put back.
+        import signal
+        import threading
+        in_main = threading.current_thread() is threading.main_thread()
+        prev = signal.getsignal(signal.SIGCHLD) if in_main else None
+        for _ in iter(self._dl):
+            pass
+        if in_main:
+            signal.signal(signal.SIGCHLD, prev if prev is not None else signal.SIG_DFL)
+        torch.set_rng_state(rng_state)
+        self._batches_of.pending = None
 
     def __len__(self):
         return len(self._batches_of)
@@ -257,18 +288,28 @@ class GpuLoader:
             for idx in self._batches_of:
                 yield self._to_batch(idx, [pngio.decode_png(self.paths[i], self._need_mode) for i in idx])
             return
-        if self._dl is None:
-            from torch.utils.data import DataLoader
-            # batch_sampler yields index lists; the "batch" a worker returns is [(index, decoded image)]
-            self._dl = DataLoader(_IndexedPng(self.paths, self._need_mode), batch_sampler=self._batches_of,
-                                  num_workers=self.workers, collate_fn=_identity, persistent_workers=True,
-                                  prefetch_factor=self.prefetch)
+        if self._dl is None:     # (no images at construction)
+            return
         self._batches_of.prepare()
         rng_state = torch.get_rng_state()
-        it = iter(self._dl)                 # draws a worker seed nobody uses: the decode workers are deterministic
-        torch.set_rng_state(rng_state)      # ... so the global generator stays where the single-threaded loader leaves it
-        for items in it:
-            yield self._to_batch([i for i, _ in items], [d for _, d in items])
+        done = 0
+        try:
+            it = iter(self._dl)                 # draws a worker seed nobody uses: the decode workers are deterministic
+            torch.set_rng_state(rng_state)      # ... so the global generator stays where the single-threaded loader leaves it
+            for items in it:
+                yield self._to_batch([i for i, _ in items], [d for _, d in items])
+                done += 1
+        except RuntimeError as e:
+            if "DataLoader worker" not in str(e):
+                raise
+            torch.set_rng_state(rng_state) if done == 0 else None
+            # a decode process died (killed from outside, out of memory ...): finish the epoch - and the run - decoding in
+            # this thread rather than losing the training run; the batches and their order do not change
+            import warnings
+            warnings.warn(f"sykepic_hip: {e}; decoding in-process from here on")
+            self._dl, self.workers = None, 1
+            for idx in self._batches_of.pending[done:]:
+                yield self._to_batch(idx, [pngio.decode_png(self.paths[i], self._need_mode) for i in idx])
 
     def __iter__(self):
         """Batches assembled by a background thread, at most two ahead of the consumer."""

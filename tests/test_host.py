@@ -251,3 +251,49 @@ def test_tune_cache_environment_rules(monkeypatch):
     else:
         assert "SPK_TUNE_CACHE" not in os.environ and not os.path.exists("/tmp/spk_test_cache_home")
     monkeypatch.delenv("SPK_TUNE_CACHE", raising=False)
+
+
+def test_gpu_loader_survives_a_dead_decode_worker(tmp_path, monkeypatch):
+    """GpuLoader decodes in worker processes; if one of them dies mid-epoch (killed from outside, out of memory) the
+    loader warns and finishes the epoch - and later epochs - decoding in-process, with the same batches in the same
+    order.  The GPU transform is replaced by a stub, so this runs without a GPU."""
+    import warnings
+    from PIL import Image
+    from sykepic_hip import gpu_augment, preprocess as P
+
+    class StubPipe:
+        def __init__(self, transform, device, num_chans=3):
+            self.transform = transform
+
+        def __call__(self, images, modes=None):
+            return torch.tensor([[float(im.sum()), float(m)] for im, m in zip(images, modes)])
+
+    monkeypatch.setattr(gpu_augment, "GpuTransform", StubPipe)
+    rng = np.random.RandomState(0)
+    paths, labels = [], []
+    for i in range(37):
+        p = tmp_path / f"img_{i:02d}.png"
+        Image.fromarray(rng.randint(0, 256, (20 + i % 5, 30 + i % 7)).astype(np.uint8)).save(p)
+        paths.append(p)
+        labels.append(i % 3)
+    t = P.Compose([P.Resize(), P.ToTensor()], (32, 32), "mode")
+
+    def epochs(workers, kill):
+        torch.manual_seed(3)
+        loader = gpu_augment.GpuLoader(paths, labels, t, 4, "cpu", shuffle=True, workers=workers)
+        out = []
+        for ep in range(2):
+            for k, (x, y) in enumerate(loader):
+                out.append((x.clone(), y.clone()))
+                if kill and ep == 0 and k == 1:
+                    loader._dl._iterator._workers[0].kill()
+        return out
+
+    want = epochs(1, False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = epochs(3, True)
+    assert any("decoding in-process" in str(x.message) for x in w)
+    assert len(got) == len(want) == 20
+    for (xa, ya), (xb, yb) in zip(want, got):
+        assert torch.equal(xa, xb) and torch.equal(ya, yb)
