@@ -256,6 +256,16 @@ int spk_op_conv_wgrad(const void* x_dev, const void* dy_dev, float* dw_dev, int 
 int spk_op_pw_fp8(const void* x_dev, int a_fp8, const float* w_dev, void* y_dev, int out_fp8, const void* res_dev,
                   const float* bn_scale_dev, const float* bn_bias_dev, const float* gate_dev, int hw, int m_rows, int cin,
                   int cout, int act, float a_scale, float y_scale, void* hip_stream);
+/* Eval-path 1x1 convolution (Conv2d(k=1, bias=False) + eval BatchNorm2d (+ shortcut) (+ ReLU); the 36 pointwise convs
+ * `net(x)` runs in a ResNet-50 forward, sykepic/compute/probability.py:189).  x [n,h,w,cin] fp16 NHWC, w float32
+ * [cout][cin], bn_scale / bn_bias float[cout] (folded statistics), res (optional) and y [n,ho,wo,cout] fp16;
+ * stride 1 or 2; relu 0 / 1; split != 0: weights as fp16 hi + lo.  cfg >= 0: that tile configuration of the
+ * direct-operand kernel (0 .. spk_op_conv1x1_num_configs() - 1; SPK_ERR_UNSUPPORTED when it does not fit the
+ * problem), cfg < 0: the implicit-GEMM kernel.  Channel counts: multiples of 64.  Synchronous. */
+int spk_op_conv1x1(const void* x_dev, const float* w_dev, const float* bn_scale_dev, const float* bn_bias_dev,
+                   const void* res_dev, void* y_dev, int n, int h, int w, int cin, int cout, int stride, int relu,
+                   int split, int cfg, void* hip_stream);
+int spk_op_conv1x1_num_configs(void);
 /* Depthwise Conv2d(C, C, k, stride, pad (k-1)/2, groups=C) + folded BatchNorm + activation (EfficientNet MBConv):
  * x [n,h,w,C] fp16 NHWC, w float32 [C][k*k], y [n,ho,wo,C] fp16; pool (optional) float32 [n][C] = per-image sums of
  * the outputs (squeeze-excitation numerator).  lds != 0: the LDS row-ring kernel, else the gather kernel. */

@@ -1,0 +1,601 @@
+// 1x1 ("pointwise") convolution for gfx950 (MI355X): the 36 of ResNet-50's 53 convolutions that are plain GEMMs
+// out[pixel][cout] = sum_k x[pixel][k] * w[cout][k]   (NHWC activations ARE the row-major GEMM operand).
+//
+// Stands in for the torch Conv2d(k=1)+BatchNorm2d(+add)(+ReLU) chains the reference reaches through `net(x)`
+// (sykepic/compute/probability.py:189) - SURVEY.md section 2.2.  Differences from the implicit-GEMM kernel
+// (conv_igemm.hip), each aimed at what bounded that kernel on these layers:
+//
+//  * The ACTIVATION operand never touches LDS.  A lane's 16x16x32 MFMA fragment (pixel l%16, channels 8*(l/16)..+7 of a
+//    32-deep K step) is one 16-byte global load, so each wave fetches the fragments of its own pixels straight into
+//    VGPRs, PA K-steps ahead of their use (and across tile boundaries in the resident flavour).  No LDS-DMA fill, no
+//    ds_write, no ds_read for activations: the L2->LDS path carries the weights only.
+//  * Weights are PRE-PACKED in MFMA fragment order ([k-step][32-cout pair][hi|lo][tile][lane][8]): the LDS image of a
+//    (k-step, cout tile) is one contiguous run, filled by a linear copy and read back with lane-linear ds_read_b128
+//    (conflict-free by construction, no swizzle).
+//  * Swapped operand roles: weights are the MFMA A operand (rows = couts), activations the B operand (columns = pixels),
+//    and the couts of a tile pair are permuted at pack time so that a lane's accumulators of the pair are 8 CONSECUTIVE
+//    couts of ONE pixel.  The epilogue therefore runs from registers: + shortcut, ReLU, 16-bit rounding, one 16-byte
+//    store per (pixel tile, pair) - no LDS round trip, no barrier.
+//  * Eval-BatchNorm stays in fp32: v = acc * scale[c] + shift[c] in the epilogue, the per-cout pairs read from LDS.
+//    (Folding the scale into the 16-bit weights was tried: a small scale moves the weights into fp16's subnormal range,
+//    where hi + lo no longer carries 22 bits - on the calibrated-statistics golden fixture the error doubled.)
+//  * RESIDENT flavour (K*BN*bytes fits LDS): the weight panel is loaded once per block; the block then walks pixel
+//    tiles with no barrier and no weight traffic at all, every wave on its own - the epilogue of one wave overlaps the
+//    MFMAs of the others.  RING flavour (deep K): classic K-outer loop, weights register-staged through a 2-stage LDS
+//    ring, one barrier per 32-deep K step.
+#include "spk_common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(3))) const unsigned char* lds_u8_t;   // LDS reads stay ds_read (never FLAT)
+typedef __attribute__((address_space(3))) const u32x4_t* lds_u32x4_t;
+
+// two already-clamped floats -> one dword of two 16-bit values (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 on gfx950)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+template <int DT> __device__ __forceinline__ unsigned int pack2_nosat(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  if (DT == DT_BF16) return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+}
+
+// KSC > 0: RESIDENT flavour for K = 32 * KSC exactly (the tile body is straight-line code: no K loop), PA unused.
+// KSC = 0: RING flavour, any K, activations PA K-steps ahead.
+// HAS_RES: the launch has a shortcut operand (compile-time: with both epilogues in one kernel the compiler's s_waitcnt
+// placement merges the two paths and waits for the previous epilogue's stores at the top of every tile).
+template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC, bool HAS_RES>
+__global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, int m_tiles, int n_tiles) {
+  constexpr bool RESIDENT = KSC > 0;
+  constexpr int XS = RESIDENT ? KSC : PA;   // activation register sets
+  constexpr int NT = 2 * NPAIR;            // 16-cout MFMA tiles of the block tile
+  constexpr int BN = 32 * NPAIR;           // couts of the block tile
+  constexpr int WPX = MT * 16;             // pixels per wave
+  constexpr int BM = WAVES * WPX;          // pixels per block tile
+  constexpr int T = WAVES * 64;
+  constexpr int CH = NPAIR * NB * 2048;    // bytes of one 32-deep K step of the block's weight panel
+  constexpr int RD = (CH + T * 16 - 1) / (T * 16);  // 16-byte copy rounds per thread and K step
+  static_assert(PA == 2 || PA == 4, "activation prefetch depth");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, p = lane & 15;
+  const int KS = RESIDENT ? KSC : (a.Cin >> 5);
+  const int pairs_total = a.Cout >> 5;
+  const int HoWo = a.Ho * a.Wo;
+
+  const __amdgpu_buffer_rsrc_t rx =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (a.ablate & 4) ? 0 : a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (a.ablate & 1) ? 0 : a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (HAS_RES && !(a.ablate & 2)) ? a.y_bytes : 0, 0x00020000);
+
+  // ---- block -> work ----
+  int n_tile, mt, mt_step;
+  if (RESIDENT) {
+    // blocks b and b+8 share an XCD (round-robin dispatch): the n_tiles blocks that walk the SAME pixel tiles sit on
+    // one XCD, so the activation strip the first of them pulls from HBM is an L2 hit for the others
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    n_tile = j % n_tiles;
+    mt = (j / n_tiles) * 8 + xcd;
+    mt_step = (int)(gridDim.x >> 3) / n_tiles * 8;
+  } else {
+    const int ntiles = m_tiles * n_tiles, w = blockIdx.x;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7, xcd = w & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (w >> 3);
+    n_tile = swz % n_tiles;
+    mt = swz / n_tiles;
+    mt_step = m_tiles;  // one tile per block
+  }
+  const int n0 = n_tile * BN;
+  unsigned char* const sW = smem;
+  float* const sScale = (float*)(smem + (RESIDENT ? KS : 2) * CH);   // [BN] scale, then [BN] shift
+
+  // byte offset of K step s of this block's panel in the packed weights
+  auto w_goff = [&](int s) { return (size_t)(s * pairs_total + n_tile * NPAIR) * (NB * 2048); };
+
+  // pixel tile -> per-lane byte offsets of the activation fragments (pixel p of each of the wave's MT pixel tiles,
+  // 16-byte chunk g of a K step) and of the output row segments (8 couts from n0 + 8g)
+  auto tile_offsets = [&](int tile, unsigned (&aoff)[MT], unsigned (&yoff)[MT]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int px = tile * BM + wave * WPX + m * 16 + p;
+      const bool ok = tile < m_tiles && px < a.M;
+      int ipx = px;
+      if (a.stride != 1) {
+        const int img = px / HoWo, rem = px - img * HoWo;
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        ipx = (img * a.H + ho * a.stride) * a.W + wo * a.stride;
+      }
+      aoff[m] = ok ? (unsigned)ipx * (unsigned)(a.Cin * 2) + g * 16 : 0x80000000u;
+      yoff[m] = ok ? (unsigned)px * (unsigned)(a.Cout * 2) + (unsigned)(n0 + 8 * g) * 2 : 0x80000000u;
+    }
+  };
+
+  f32x4_t acc[MT][NT];
+  u32x4_t xa[XS][MT];
+
+  auto load_a = [&](u32x4_t (&dst)[MT], const unsigned (&off)[MT], int s) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) dst[m] = __builtin_amdgcn_raw_buffer_load_b128(rx, off[m], s * 64, 0);
+  };
+  auto init_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  };
+  // Weight fragments of one 32-cout pair: [hi|lo][tile] x 16 bytes per lane.  Two register sets ping-pong (even / odd
+  // pair), and the set of pair q+1 is read from LDS while the MFMAs of pair q run: hipcc on its own keeps ONE set and
+  // issues each ds_read one or two MFMAs ahead of its use, so every group of four MFMAs paid a full LDS round trip
+  // (measured on 14^2 256->1024: MFMA pipe 35 % busy, 42 % of the wave cycles in s_waitcnt).
+  struct Frag { u32x4_t w[NB][2]; };
+  Frag fr[2];
+  auto load_frag = [&](Frag& f, lds_u8_t q) {
+    f.w[0][0] = *(lds_u32x4_t)(q);
+    f.w[0][1] = *(lds_u32x4_t)(q + 1024);
+    if (NB == 2) {
+      f.w[1][0] = *(lds_u32x4_t)(q + 2048);
+      f.w[1][1] = *(lds_u32x4_t)(q + 3072);
+    }
+  };
+  auto mfma_pair = [&](int P, const Frag& f, const u32x4_t (&x)[MT]) {
+#pragma unroll
+    for (int h = 0; h < NB; ++h)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        acc[m][2 * P] = mfma16<DT>(f.w[h][0], x[m], acc[m][2 * P]);
+        acc[m][2 * P + 1] = mfma16<DT>(f.w[h][1], x[m], acc[m][2 * P + 1]);
+      }
+  };
+  // one K step out of the LDS image at `base`; fr[0] already holds pair 0.  `next`: image whose pair 0 is fetched
+  // during the last pair (the next K step), or null (ring flavour: that stage is not published yet)
+  auto compute = [&](lds_u8_t base, lds_u8_t next, const u32x4_t (&x)[MT], auto has_next) {
+    static_assert(NPAIR % 2 == 0, "pairs ping-pong between two fragment sets");
+#pragma unroll
+    for (int P = 0; P < NPAIR; ++P) {
+      if (!(a.ablate & 8)) {   // (timing experiment 8: no fragment reads at all - the MFMA stream alone)
+        if (P + 1 < NPAIR) load_frag(fr[(P + 1) & 1], base + (P + 1) * (NB * 2048) + lane * 16);
+        else if (decltype(has_next)::value) load_frag(fr[0], next + lane * 16);
+      }
+      mfma_pair(P, fr[P & 1], x);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NB, 0);      // the next pair's ds_reads first ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NB * MT, 0);  // ... then this pair's MFMAs
+    }
+  };
+
+  // Shortcut operand, one whole tile ahead (when it fits the register budget): the loads of tile i+1 are issued inside
+  // the epilogue of tile i, each right after the register it lands in has been consumed.  vmcnt retires in issue order
+  // (loads and stores share the counter), so a load that is waited for soon after a batch of stores was issued makes
+  // the wave sit through the HBM write latency of those stores; one tile later they have long drained.
+  constexpr bool PRE_RES = MT * NPAIR <= 8;
+  u32x4_t rv[PRE_RES ? MT : 1][NPAIR];
+  // ReLU and the fp16 saturation in ONE v_med3_f32 per value: floor 0 (ReLU) or -65504 (none), ceiling 65504
+  const float out_max = DT == DT_F16 ? 65504.f : 3.3895314e38f;
+  const float relu_floor = a.relu == 1 ? 0.f : -out_max;
+  // yoff: this tile's rows; yoff_next: the rows whose shortcut values are fetched for the next epilogue
+  auto epilogue_t = [&](const unsigned (&yoff)[MT], const unsigned (&yoff_next)[MT], auto has_res) {
+    constexpr bool RES = decltype(has_res)::value;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (RES && !PRE_RES) {
+#pragma unroll
+        for (int P = 0; P < NPAIR; ++P) rv[0][P] = __builtin_amdgcn_raw_buffer_load_b128(rr, yoff[m] + P * 64, 0, 0);
+      }
+#pragma unroll
+      for (int P = 0; P < NPAIR; ++P) {
+        // the lane's 8 couts of this pair: 32P + 8g .. +7 (registers 0-3 of tile 2P, then of tile 2P + 1)
+        typedef __attribute__((address_space(3))) const f32x4_t* lds_f32x4_t;
+        lds_f32x4_t sp = (lds_f32x4_t)(sScale + P * 32 + 8 * g);
+        asm volatile("" : "+v"(sp));   // re-read per use: hoisted out of the tile loop these cost 16 VGPRs per pair
+        const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[BN / 4], sh1 = sp[BN / 4 + 1];
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = __builtin_fmaf(acc[m][2 * P][r], sc0[r], sh0[r]);
+          v[4 + r] = __builtin_fmaf(acc[m][2 * P + 1][r], sc1[r], sh1[r]);
+        }
+        if (RES) {
+          const u32x4_t q = rv[PRE_RES ? m : 0][P];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[2 * j] += lo_f32<DT>(q[j]);
+            v[2 * j + 1] += hi_f32<DT>(q[j]);
+          }
+          if (PRE_RES && RESIDENT) rv[m][P] = __builtin_amdgcn_raw_buffer_load_b128(rr, yoff_next[m] + P * 64, 0, 0);
+        }
+        if (a.relu == 2) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], relu_floor, out_max);
+        u32x4_t ov;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ov[j] = pack2_nosat<DT>(v[2 * j], v[2 * j + 1]);
+        // The pair's column offset goes into the VECTOR offset (the compiler folds it into the instruction's immediate
+        // field), never into soffset: hipcc 7.2 pads the gfx950 store-data hazard (a VALU write of a >8-byte store's
+        // data registers within 2 wait states) only for stores whose soffset is NOT a register - with P * 64 >= 128
+        // in an SGPR the next tile's address arithmetic overwrote the 4th data dword of the last store of a tile
+        // (measured: couts 6, 7 of every 8 came out as pixel indices in 0.01-0.1 % of the rows).
+        __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yoff[m] + P * 64, 0, 0);
+      }
+    }
+  };
+  auto epilogue = [&](const unsigned (&yoff)[MT], const unsigned (&yoff_next)[MT]) {
+    if (a.ablate & 16) {   // (timing experiment 16: no epilogue; the accumulators are kept alive)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(acc[m][t]));
+      return;
+    }
+    epilogue_t(yoff, yoff_next, std::integral_constant<bool, HAS_RES>{});
+  };
+  // Before the first tile: the shortcut loads of that tile, interleaved with as many DROPPED stores (zero-record
+  // descriptor) as an epilogue issues.  The tile loop is then entered with the same sequence of outstanding memory
+  // operations as it is re-entered with, so the compiler's s_waitcnt for the activation / shortcut registers counts
+  // past a whole epilogue's stores instead of assuming (from the shorter entry path) that they must have retired.
+  auto prologue_like_an_epilogue = [&](const unsigned (&yoff)[MT]) {
+    const __amdgpu_buffer_rsrc_t rnull = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, 0, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int P = 0; P < NPAIR; ++P) {
+        if (PRE_RES && HAS_RES) rv[m][P] = __builtin_amdgcn_raw_buffer_load_b128(rr, yoff[m] + P * 64, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0, 0, 0, 0}, rnull, yoff[m] + P * 64, 0, 0);
+      }
+  };
+
+  // folded BatchNorm scale / shift of this block's couts
+  for (int c = tid; c < BN; c += T) {
+    sScale[c] = a.scale ? a.scale[n0 + c] : 1.f;
+    sScale[BN + c] = a.shift ? a.shift[n0 + c] : 0.f;
+  }
+
+  if (RESIDENT) {
+    // ---- whole [K x BN] panel into LDS, once ----
+    for (int s = 0; s < KS; ++s) {
+      const unsigned char* src = (const unsigned char*)a.wp + w_goff(s);
+#pragma unroll
+      for (int r = 0; r < RD; ++r) {
+        const int o = r * (T * 16) + tid * 16;
+        if (CH % (T * 16) == 0 || o < CH) *(u32x4_t*)(sW + s * CH + o) = *(const u32x4_t*)(src + o);
+      }
+    }
+    unsigned aoff[MT], yoff[MT], aoff_n[MT], yoff_n[MT];
+    tile_offsets(mt, aoff, yoff);
+    tile_offsets(mt + mt_step, aoff_n, yoff_n);
+#pragma unroll
+    for (int u = 0; u < KSC; ++u) load_a(xa[u], aoff, u);   // the whole first tile
+    prologue_like_an_epilogue(yoff);
+    __syncthreads();
+    const lds_u8_t sWl = (lds_u8_t)sW;
+    load_frag(fr[0], sWl + lane * 16);
+    // Tile loop, straight-line body.  Everything a tile reads from memory was requested one tile earlier: its
+    // activations while the previous tile's K steps consumed theirs (register set by register set), its shortcut
+    // values inside the previous epilogue.  No s_waitcnt of the body refers to an operation younger than the previous
+    // epilogue's stores, so those drain under this tile's MFMAs instead of in front of them.
+    while (mt < m_tiles) {
+      init_acc();
+      // One base register per K step, advanced by a VALU add the compiler cannot fold (the empty asm): with constant
+      // step offsets it addresses the whole panel from ONE base, and past the 64 KB reach of the ds_read immediate
+      // every fragment read gets its own v_add - as many VALU instructions as the tile has MFMAs, on the issue port
+      // the MFMAs of both waves of the SIMD need.
+      lds_u8_t sbase = sWl;
+#pragma unroll
+      for (int u = 0; u < KSC; ++u) {
+        lds_u8_t snext = u + 1 < KSC ? sbase + CH : sWl;   // (past the last K step: step 0, the next tile's)
+        asm volatile("" : "+v"(snext));
+        compute(sbase, snext, xa[u], std::true_type{});
+        load_a(xa[u], aoff_n, u);
+        sbase = snext;
+      }
+      epilogue(yoff, yoff_n);
+      mt += mt_step;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { aoff[m] = aoff_n[m]; yoff[m] = yoff_n[m]; }
+      tile_offsets(mt + mt_step, aoff_n, yoff_n);
+    }
+  } else {
+    // ---- K-outer loop, weights register-staged through a two-stage LDS ring ----
+    unsigned aoff[MT], yoff[MT];
+    tile_offsets(mt, aoff, yoff);
+    u32x4_t rb[RD];
+    auto load_b = [&](int s) {
+      const unsigned char* src = (const unsigned char*)a.wp + w_goff(s);
+#pragma unroll
+      for (int r = 0; r < RD; ++r) {
+        const int o = r * (T * 16) + tid * 16;
+        if (CH % (T * 16) == 0 || o < CH) rb[r] = *(const u32x4_t*)(src + o);
+      }
+    };
+    auto store_b = [&](int stage) {
+#pragma unroll
+      for (int r = 0; r < RD; ++r) {
+        const int o = r * (T * 16) + tid * 16;
+        if (CH % (T * 16) == 0 || o < CH) *(u32x4_t*)(sW + stage * CH + o) = rb[r];
+      }
+    };
+    load_b(0);
+#pragma unroll
+    for (int u = 0; u < PA; ++u) load_a(xa[u], aoff, u);
+    store_b(0);
+    __syncthreads();
+    init_acc();
+    if (PRE_RES && HAS_RES) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int P = 0; P < NPAIR; ++P) rv[m][P] = __builtin_amdgcn_raw_buffer_load_b128(rr, yoff[m] + P * 64, 0, 0);
+    }
+    for (int s = 0; s < KS; s += PA) {
+#pragma unroll
+      for (int u = 0; u < PA; ++u) {
+        const int cur = s + u;
+        if (cur + 1 < KS) load_b(cur + 1);
+        load_frag(fr[0], (lds_u8_t)sW + (u & 1) * CH + lane * 16);
+        compute((lds_u8_t)sW + (u & 1) * CH, (lds_u8_t)sW, xa[u], std::false_type{});
+        if (cur + PA < KS) load_a(xa[u], aoff, cur + PA);
+        if (cur + 1 < KS) store_b((u + 1) & 1);
+        __syncthreads();
+      }
+    }
+    epilogue(yoff, yoff);   // one tile per block: nothing is fetched ahead
+  }
+}
+
+// fp32 master weights [Cout][Cin] (x scale[cout]) -> 16-bit fragment order, hi (and lo = remainder) images
+__global__ void pack_pw_kernel(const float* __restrict__ w, const float* __restrict__ scale, bf16_t* __restrict__ out,
+                               int cout, int cin, int dt, int nb) {
+  const int pairs = cout >> 5;
+  const long total = (long)(cin >> 5) * pairs * 128;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63), t = (int)((idx >> 6) & 1);
+  const long rest = idx >> 7;
+  const int P = (int)(rest % pairs), s = (int)(rest / pairs);
+  const int i = lane & 15, gq = lane >> 4;
+  const int co = 32 * P + 8 * (i >> 2) + 4 * t + (i & 3);
+  const int k = 32 * s + 8 * gq;
+  const float sc = scale ? scale[co] : 1.f;
+  unsigned short hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = w[(size_t)co * cin + k + j] * sc;
+    if (dt == DT_BF16) {
+      hi[j] = to_h16<DT_BF16>(v);
+      lo[j] = to_h16<DT_BF16>(v - bf16_to_f32(hi[j]));
+    } else {
+      hi[j] = to_h16<DT_F16>(v);
+      lo[j] = to_h16<DT_F16>(v - (float)__builtin_bit_cast(_Float16, hi[j]));
+    }
+  }
+  bf16_t* d = out + ((((size_t)s * pairs + P) * nb) * 2 + t) * 512 + lane * 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) d[j] = hi[j];
+  if (nb == 2) {
+    d += 1024;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d[j] = lo[j];
+  }
+}
+
+template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC>
+int launch_k(const PwConvArgs& a, hipStream_t s) {
+  constexpr int BN = 32 * NPAIR, BM = WAVES * MT * 16, CH = NPAIR * NB * 2048;
+  constexpr bool RESIDENT = KSC > 0;
+  const int KS = a.Cin / 32;
+  if (a.Cout % BN) return -3;
+  if (RESIDENT ? KS != KSC : (KS % PA || KS < PA)) return -3;
+  const int n_tiles = a.Cout / BN, m_tiles = (a.M + BM - 1) / BM;
+  const size_t lds = (size_t)(RESIDENT ? KS : 2) * CH + 2 * BN * 4;
+  if (lds > 160 * 1024) return -3;
+  auto k = a.res ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true>
+                 : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false>;
+  static bool attr[2] = {false, false};
+  if (!attr[a.res != nullptr]) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+    attr[a.res != nullptr] = true;
+  }
+  int grid;
+  if (RESIDENT) {
+    // persistent: as many blocks as stay resident, a multiple of 8 * n_tiles
+    if (n_tiles > 32) return -3;
+    int bpc = (int)((160 * 1024) / lds);
+    const int by_waves = 16 / WAVES;  // <= 2 waves per SIMD (launch bounds)
+    bpc = bpc < by_waves ? bpc : by_waves;
+    if (bpc < 1) return -3;
+    const int unit = 8 * n_tiles;
+    grid = (256 * bpc) / unit * unit;
+    const int need = ((m_tiles + 7) / 8) * unit;  // no more members than pixel tiles
+    if (grid > need) grid = need;
+    if (grid < unit) grid = unit;
+  } else {
+    grid = m_tiles * n_tiles;
+  }
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WAVES * 64), lds, s, a, m_tiles, n_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// resident flavour of one tile shape: dispatch on the K-step count it was compiled for
+template <int DT, int NB, int MT, int NPAIR, int WAVES, int KMAX>
+int launch_res(const PwConvArgs& a, hipStream_t s) {
+  const int KS = a.Cin / 32;
+  if (KS == 2) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 2>(a, s);
+  if constexpr (KMAX >= 4) if (KS == 4) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 4>(a, s);
+  if constexpr (KMAX >= 8) if (KS == 8) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 8>(a, s);
+  if constexpr (KMAX >= 16) if (KS == 16) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 16>(a, s);
+  return -3;
+}
+
+// candidate table (index = cfg id).  BN = 32*NPAIR couts, BM = WAVES*MT*16 pixels.
+constexpr int kNumCfgs = 12;
+template <int DT, int NB>
+int launch_cfg(const PwConvArgs& a, int cfg, hipStream_t s) {
+  switch (cfg) {
+    case 0: return launch_k<DT, NB, 2, 8, 8, 4, 0>(a, s);    // ring 256 px x 256 couts
+    case 1: return launch_k<DT, NB, 2, 4, 8, 4, 0>(a, s);    // ring 256 x 128
+    case 2: return -3;   // (ring 256 x 128 as 4 waves of 64 px: 256 VGPRs + ~90 spilled - removed)
+    case 3: return launch_k<DT, NB, 2, 8, 4, 4, 0>(a, s);    // ring 128 x 256
+    case 4: return launch_k<DT, NB, 4, 2, 8, 4, 0>(a, s);    // ring 512 x 64
+    case 5: return launch_k<DT, NB, 2, 4, 4, 2, 0>(a, s);    // ring 128 x 128 (two blocks per CU), K % 64
+    case 6: return launch_res<DT, NB, 2, 8, 8, 2>(a, s);     // resident 256 x 256 (K = 64; K = 128 spills)
+    case 7: return launch_res<DT, NB, 2, 4, 8, 8>(a, s);     // resident 256 x 128 (K <= 256)
+    case 8: return launch_res<DT, NB, 4, 4, 8, 2>(a, s);     // resident 512 x 128 (K = 64)
+    case 9: return launch_res<DT, NB, 2, 2, 8, 16>(a, s);    // resident 256 x 64 (K <= 512)
+    case 10: return launch_res<DT, NB, 4, 2, 8, 4>(a, s);    // resident 512 x 64 (K <= 128)
+    case 11: return launch_res<DT, NB, 2, 4, 4, 8>(a, s);    // resident 128 x 128, 4 waves (two blocks per CU)
+    default: return -3;
+  }
+}
+
+}  // namespace
+
+int spk_pw_num_configs() { return kNumCfgs; }
+
+// 0 ok, -1 HIP error, -2 unsupported problem, -3 this config does not fit the problem
+int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s) {
+  if (a.Cin % 64 || a.Cout % 64 || a.M <= 0) return -2;
+  if ((size_t)a.y_bytes >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull) return -2;
+  if (a.dt == DT_F16) return a.nb == 2 ? launch_cfg<DT_F16, 2>(a, cfg, s) : launch_cfg<DT_F16, 1>(a, cfg, s);
+  return -2;   // (bf16 training path: not instantiated yet)
+}
+
+int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout, int cin, int dt, int nb, hipStream_t s) {
+  if (cout % 32 || cin % 32) return -2;
+  const long total = (long)(cin / 32) * (cout / 32) * 128;
+  hipLaunchKernelGGL(pack_pw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, scale, out, cout, cin, dt, nb);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------------------
+// Eval-path entry: one 1x1 convolution, by whichever kernel is faster for this problem on this machine - the
+// implicit-GEMM kernel (its own best tile x flavour) or one of the configurations above.  Timed once per process
+// and problem like the conv tuner, winners persisted in the same SPK_TUNE_CACHE file ("pw1x1 ..." lines).  The two
+// kernels give bit-identical outputs (same accumulation order, same fp32 epilogue).  The candidates are timed
+// back to back on one problem, i.e. with a warmer cache than inside a forward pass, and the kernel here is the more
+// latency-sensitive of the two (measured per layer inside the network it ran 15-25 % over its isolated time on the
+// 14x14 / 7x7 layers, the implicit GEMM did not): it has to win by 8 % to be chosen.
+// ---------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <tuple>
+namespace {
+typedef std::tuple<int, int, int, int, int, int, int, int, int> Pw1Key;   // nb H W Cin Cout stride res relu N
+std::map<Pw1Key, int> g_pw_choice;   // -1: implicit GEMM, else configuration id
+std::mutex g_pw_mu;
+bool g_pw_loaded = false;
+
+const char* pw_cache_path() {
+  const char* e = getenv("SPK_TUNE_CACHE");
+  return e && *e && strcmp(e, "off") ? e : nullptr;
+}
+void pw_cache_load_locked() {
+  if (g_pw_loaded) return;
+  g_pw_loaded = true;
+  const char* path = pw_cache_path();
+  if (!path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char line[512];
+  while (fgets(line, sizeof line, f)) {
+    int v[10];
+    if (sscanf(line, "pw1x1 %d %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7], &v[8],
+               &v[9]) == 10 && v[9] >= -1 && v[9] < kNumCfgs)
+      g_pw_choice[Pw1Key(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8])] = v[9];
+  }
+  fclose(f);
+}
+// SPK_PW: 1 (default) each problem runs on the faster of the two kernels; 2: always conv_pw (its best tile
+// configuration); 0: never.  The choice never shows in the output: every configuration of this kernel and the
+// implicit GEMM accumulate in the same order and share the fp32 epilogue - bit-identical results, asserted by
+// tests/test_gpu_pw.py - so a row of probabilities does not depend on the batch it was computed in.
+int pw_mode() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SPK_PW");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+}  // namespace
+
+int spk_conv1x1_launch(const ConvArgs& a, const PwConvArgs& q, hipStream_t s) {
+  const bool tune = !getenv("SPK_AUTOTUNE") || atoi(getenv("SPK_AUTOTUNE")) != 0;
+  if (pw_mode() == 0 || a.Cin % 64 || a.Cout % 64 || q.dt != DT_F16) return spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr);
+  const Pw1Key key(q.nb, q.H, q.W, q.Cin, q.Cout, q.stride, q.res != nullptr, q.relu, q.N);
+  int choice = -2;
+  {
+    std::lock_guard<std::mutex> lk(g_pw_mu);
+    pw_cache_load_locked();
+    auto it = g_pw_choice.find(key);
+    if (it != g_pw_choice.end()) choice = it->second;
+    else {
+      // a ragged tail batch re-uses the choice of the nearest tuned batch within a factor of two
+      double best_ratio = 2.0 + 1e-9;
+      for (const auto& kv : g_pw_choice) {
+        Pw1Key k2 = kv.first;
+        const int n2 = std::get<8>(k2);
+        std::get<8>(k2) = q.N;
+        if (k2 != key) continue;
+        const double r = n2 > q.N ? (double)n2 / q.N : (double)q.N / n2;
+        if (r <= best_ratio) { best_ratio = r; choice = kv.second; }
+      }
+    }
+  }
+  if (choice == -2 && !tune) choice = -1;
+  if (choice == -2) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    float best = 1e30f, t_igemm = 1e30f, t_pw = 1e30f;
+    int best_pw = -1;
+    choice = -1;
+    for (int cfg = (pw_mode() == 2 ? 0 : -1); cfg < kNumCfgs; ++cfg) {
+      auto run = [&]() { return cfg < 0 ? spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr) : spk_pw_launch(q, cfg, s); };
+      if (run()) continue;  // warm-up (and the implicit GEMM's own tuning); -3: configuration does not fit
+      (void)hipEventRecord(e0, s);
+      for (int r = 0; r < 3; ++r) run();
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) continue;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (getenv("SPK_TUNE_LOG") && atoi(getenv("SPK_TUNE_LOG")) > 1)
+        fprintf(stderr, "[spk pw cand] %dx%d C%d->%d s%d nb%d res%d: %s %d %.1f us\n", q.H, q.W, q.Cin, q.Cout, q.stride,
+                q.nb, q.res != nullptr, cfg < 0 ? "igemm" : "pw", cfg, ms * 1000.f / 3.f);
+      if (cfg < 0) t_igemm = ms;
+      else if (ms < t_pw) { t_pw = ms; best_pw = cfg; }
+    }
+    if (best_pw >= 0 && t_pw < 0.92f * t_igemm) { choice = best_pw; best = t_pw; }
+    else { choice = -1; best = t_igemm; }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    {
+      std::lock_guard<std::mutex> lk(g_pw_mu);
+      g_pw_choice[key] = choice;
+      if (const char* path = pw_cache_path()) {
+        if (FILE* f = fopen(path, "a")) {
+          fprintf(f, "pw1x1 %d %d %d %d %d %d %d %d %d %d\n", q.nb, q.H, q.W, q.Cin, q.Cout, q.stride, q.res != nullptr,
+                  q.relu, q.N, choice);
+          fclose(f);
+        }
+      }
+    }
+    if (getenv("SPK_TUNE_LOG"))
+      fprintf(stderr, "[spk tune 1x1] N%d %dx%d C%d->%d s%d nb%d res%d: %s %d (%.1f us)\n", q.N, q.H, q.W, q.Cin, q.Cout,
+              q.stride, q.nb, q.res != nullptr, choice < 0 ? "igemm" : "pw", choice, best * 1000.f / 3.f);
+  }
+  if (choice >= 0) {
+    const int r = spk_pw_launch(q, choice, s);
+    if (r != -3) return r;
+  }
+  return spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr);
+}

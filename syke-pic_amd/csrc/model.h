@@ -37,6 +37,8 @@ struct Layer {
   int p_w2 = -1, p_b2 = -1;       // SE: fc2 (p_w / p_b hold fc1)
   int cin_p = 0, cout_p = 0;      // channels as laid out in HBM: padded to a multiple of 64 (zeros)
   size_t wpack_off = 0, sb_off = 0;
+  size_t wpw_off = 0;             // fragment-ordered image of a 1x1 conv's weights (conv_pw.hip), when pw_ok
+  bool pw_ok = false;             // 1x1, stride 1 or 2, no padding anywhere, channels multiples of 64
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)

@@ -239,6 +239,12 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     } else if (L.d.kind == SPK_OP_CONV) {
       L.wpack_off = wpack;
       wpack += (size_t)2 * L.cout_p * L.kpad;  // room for the hi + lo halves
+      L.pw_ok = L.mode == CONV_MODE_GENERIC && L.d.k == 1 && L.d.pad == 0 && L.cin_p == L.d.cin && L.cout_p == L.d.cout &&
+                L.d.cin % 64 == 0 && L.d.cout % 64 == 0 && L.kpad == L.d.cin;
+      if (L.pw_ok) {
+        L.wpw_off = wpack;
+        wpack += (size_t)2 * L.d.cout * L.d.cin;
+      }
     } else {
       continue;
     }
@@ -427,6 +433,8 @@ static int layer_split(const spk_model* m, const Layer& L) {
   // trunk nor reads it (tests/diagnostics/split_rules.py: its weight rounding adds the least logit error per MFMA
   // cycle a lo-product costs).  The first 3x3 conv of a basic block (ResNet-18/34) reads the trunk and stays split:
   // un-split it costs 1.1e-3 of probability on the class-standardised golden fixture (tests/diagnostics/diverse_prec.py)
+  // (Round 3 tried splitting the last stage's inner 3x3 convs as well, tests/diagnostics/split_rules.py "all-but-
+  // inner3x3(stages1-3)": +0.29 ms per forward and no gain on the class-standardised golden fixture.)
   if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 || !L.inner3x3 ? 1 : 0;
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;
 }
@@ -472,6 +480,13 @@ int spk_commit(spk_model* m) {
       r = spk_launch_pack_weights(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
                                   L.mode, m->infer_dt, layer_split(m, L), m->stream);
     if (r) return fail(SPK_ERR_HIP, "pack_weights launch failed");
+    // 1x1 convs: second image in MFMA fragment order (conv_pw.hip).  The BatchNorm scale is NOT folded into it: a
+    // small scale would push the 16-bit weights into fp16's subnormal range (measured on the calibrated-statistics
+    // golden fixture: every conv split, max |dp| 5.9e-4 with the scale in the fp32 epilogue, 1.1e-3 folded)
+    if (L.pw_ok && m->infer_dt == DT_F16 &&
+        spk_launch_pack_pw(m->P(L.p_w), nullptr, m->wpack + L.wpw_off, L.d.cout, L.d.cin, DT_F16, layer_split(m, L) ? 2 : 1,
+                           m->stream))
+      return fail(SPK_ERR_HIP, "pack_pw launch failed");
   }
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
@@ -747,6 +762,17 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     m->stale_stem_t = L.d.dst;
   } else if (L.fuse_pool >= 0) {
     m->stale_stem_t = -1;
+  }
+  if (L.pw_ok && a.dt == DT_F16 && !a.res_lo && !a.y_lo && !a.cin_s && !a.cout_s) {
+    PwConvArgs q;
+    memset(&q, 0, sizeof q);
+    q.x = a.x; q.wp = m->wpack + L.wpw_off; q.y = a.y; q.res = a.res; q.scale = a.scale; q.shift = a.bias;
+    q.N = nb; q.H = in.h; q.W = in.w; q.Ho = o.h; q.Wo = o.w; q.stride = L.d.stride;
+    q.Cin = a.Cin; q.Cout = a.Cout; q.M = a.M; q.relu = a.relu; q.dt = DT_F16; q.nb = a.splitw ? 2 : 1;
+    q.x_bytes = a.x_bytes; q.y_bytes = (unsigned)((size_t)a.M * a.Cout * 2);
+    if (spk_conv1x1_launch(a, q, m->stream))
+      return fail(SPK_ERR_HIP, std::string("1x1 conv launch failed for ") + L.d.name);
+    return SPK_OK;
   }
   if (spk_conv_launch(a, L.mode, m->stream, nullptr))
     return fail(SPK_ERR_HIP, std::string("conv launch failed for ") + L.d.name);

@@ -196,3 +196,49 @@ extern "C" int spk_op_dwconv(const void* x, const float* w, const float* bn_scal
   }
   return SPK_OK;
 }
+
+// 1x1 convolution + folded BatchNorm (+shortcut) (+ReLU) of the eval path (conv_pw.hip) on caller-provided buffers:
+// packs the fp32 weights [cout][cin] into fragment order (hi + lo images when split != 0) and
+// runs configuration `cfg` of the kernel; cfg < 0: the implicit-GEMM kernel on the same operands (the reference
+// point of the two-kernel tuner).  SPK_ERR_UNSUPPORTED when the configuration does not fit the problem.
+extern "C" int spk_op_conv1x1(const void* x, const float* w, const float* bn_scale, const float* bn_bias, const void* res,
+                              void* y, int n, int h, int wd, int cin, int cout, int stride, int relu, int split, int cfg,
+                              void* stream) {
+  if (!x || !w || !bn_scale || !bn_bias || !y || n < 1 || h < 1 || wd < 1 || (stride != 1 && stride != 2))
+    return ofail(SPK_ERR_ARG, "op_conv1x1: bad arguments");
+  if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int ho = (h - 1) / stride + 1, wo = (wd - 1) / stride + 1, M = n * ho * wo;
+  Scratch sc;
+  bf16_t* wp = sc.get<bf16_t>((size_t)2 * cout * cin);
+  if (!wp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  int r;
+  if (cfg < 0) {
+    O_TRY(spk_launch_pack_weights(w, wp, cout, 1, 1, cin, CONV_MODE_GENERIC, DT_F16, split != 0, s), "pack_weights");
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.cfg = a.dma = -1;
+    a.cls_ph = a.cls_pw = -1;
+    a.x = (const bf16_t*)x; a.w = wp; a.y = (bf16_t*)y; a.res = (const bf16_t*)res; a.scale = bn_scale; a.bias = bn_bias;
+    a.N = n; a.H = h; a.W = wd; a.Cin = cin; a.Ho = ho; a.Wo = wo; a.Cout = cout;
+    a.kh = a.kw = 1; a.stride = stride; a.M = M; a.K = cin; a.relu = relu; a.dt = DT_F16; a.splitw = split != 0;
+    a.x_bytes = (unsigned)((size_t)n * h * wd * cin * 2);
+    a.w_bytes = (unsigned)((size_t)cout * cin * 2 * (split ? 2 : 1));
+    r = spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr);
+  } else {
+    O_TRY(spk_launch_pack_pw(w, nullptr, wp, cout, cin, DT_F16, split ? 2 : 1, s), "pack_pw");
+    PwConvArgs q;
+    memset(&q, 0, sizeof q);
+    q.x = (const bf16_t*)x; q.wp = wp; q.y = (bf16_t*)y; q.res = (const bf16_t*)res; q.scale = bn_scale; q.shift = bn_bias;
+    q.N = n; q.H = h; q.W = wd; q.Ho = ho; q.Wo = wo; q.stride = stride; q.Cin = cin; q.Cout = cout; q.M = M;
+    q.relu = relu; q.dt = DT_F16; q.nb = split ? 2 : 1;
+    q.x_bytes = (unsigned)((size_t)n * h * wd * cin * 2);
+    q.y_bytes = (unsigned)((size_t)M * cout * 2);
+    r = spk_pw_launch(q, cfg, s);
+    if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "this configuration does not fit the problem");
+  }
+  if (r) return ofail(SPK_ERR_HIP, "conv1x1 launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "conv1x1 kernel failed");
+  return SPK_OK;
+}
+extern "C" int spk_op_conv1x1_num_configs(void) { return spk_pw_num_configs(); }

@@ -107,6 +107,31 @@ int spk_conv_stem_launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out);  /
 const char* spk_conv_last_config();
 
 // ---------------------------------------------------------------------------
+// 1x1 convolution with activation fragments loaded straight into VGPRs and fragment-ordered weights (conv_pw.hip)
+// ---------------------------------------------------------------------------
+struct PwConvArgs {
+  const bf16_t* x;      // [N,H,W,Cin]
+  const bf16_t* wp;     // packed by spk_launch_pack_pw
+  bf16_t* y;            // [N,Ho,Wo,Cout]
+  const bf16_t* res;    // [N,Ho,Wo,Cout] or null
+  const float* scale;   // [Cout] or null (= 1): applied to the fp32 accumulator
+  const float* shift;   // [Cout] or null (= 0)
+  int N, H, W, Ho, Wo, stride;
+  int Cin, Cout, M;
+  int relu;             // 0 none, 1 ReLU, 2 SiLU
+  int dt;               // DT_BF16 / DT_F16
+  int nb;               // 1: plain weights, 2: hi + lo images (fp16 eval only)
+  unsigned int x_bytes, y_bytes;
+  int ablate;           // timing experiments only: 1 drop the output stores, 2 the shortcut loads, 4 the activation loads
+                        // (zero-record buffer descriptors: the instructions still issue, the range check drops them)
+};
+int spk_pw_num_configs();
+int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s);   // -3: this config does not fit the problem
+int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout, int cin, int dt, int nb, hipStream_t s);
+// eval path: the faster of the implicit GEMM (a) and conv_pw (q) for this problem, tuned once and cached
+int spk_conv1x1_launch(const ConvArgs& a, const PwConvArgs& q, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // Pointwise / pooling / packing kernels (pointwise.hip)
 // ---------------------------------------------------------------------------
 // image batch -> NHWC bf16 with channels padded to 4 (stem input)

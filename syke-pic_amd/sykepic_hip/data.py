@@ -211,9 +211,11 @@ class ModelData:
                 kw = {"num_chans": num_chans, "workers": num_workers if num_workers and num_workers > 0 else None}
                 self.train_loader = G(train_x, train_y, train_transform, batch_size, device, shuffle=sampler is None,
                                       sampler=sampler, **kw)
-                self.val_loader = G(val_x, val_y, eval_transform, batch_size, device, **kw)
+                # validation / test passes are short and rare: their decode pools live for one pass only
+                self.val_loader = G(val_x, val_y, eval_transform, batch_size, device, persistent=False, **kw)
                 if self.test_x:
-                    self.test_loader = G(self.test_x, self.test_y, eval_transform, batch_size, device, **kw)
+                    self.test_loader = G(self.test_x, self.test_y, eval_transform, batch_size, device, persistent=False,
+                                         **kw)
                 return
         self.train_loader = DataLoader(train_data, batch_size, shuffle=sampler is None, sampler=sampler,
                                        num_workers=num_workers)

@@ -77,7 +77,8 @@ def shard_indices(indices, rank, world, pad=True):
 class GradSync:
     """All-reduce of the library's flat gradient buffer.
 
-    overlap=True (the default on the GPU with more than one rank): the buffer is reduced in up to three slices
+    overlap=True (opt-in with SPK_DP_OVERLAP=1 until one RCCL run on >= 2 GPUs has shown gradients bit-equal to the
+    plain path - the builder's boxes have one GPU): the buffer is reduced in up to three slices
     that the library reports back to front while the backward pass is still running (head + last stage first, the
     stem last; `spk_model_set_grad_ready_callback`): each slice's collective is enqueued on a communication
     stream behind an event, so the 96 MB of ResNet-50 gradients cross xGMI underneath the remaining dgrad / wgrad
@@ -93,8 +94,9 @@ class GradSync:
             ptr, numel = net.grad_buffer()
             self.flat = torch.as_tensor(_DevicePtr(ptr, numel), device=net.device)
         self._works, self._cb, self._comm = [], None, None
+        self._covered, self._err = 0, None
         if overlap is None:
-            overlap = self.world > 1 and view is None and os.environ.get("SPK_DP_OVERLAP", "1") != "0"
+            overlap = self.world > 1 and view is None and os.environ.get("SPK_DP_OVERLAP", "0") == "1"
         if overlap and view is None and self.world > 1:
             self._install(buckets)
 
@@ -105,9 +107,17 @@ class GradSync:
         def ready(_user, bucket, offset, numel):
             # called by the library inside forward_backward, after it made the communication stream wait for
             # the kernels that write flat[offset : offset + numel]
-            with torch.cuda.stream(self._comm):
-                self._works.append(self.dist.all_reduce(self.flat[offset:offset + numel], op=self.dist.ReduceOp.SUM,
-                                                        async_op=True))
+            # ctypes prints and DROPS an exception raised inside a callback: keep it and re-raise from all_reduce(),
+            # otherwise a failed collective would leave its slice un-reduced and the replicas would silently diverge
+            try:
+                if offset < 0 or numel <= 0 or offset + numel > self.flat.numel():
+                    raise RuntimeError(f"gradient slice [{offset}, {offset + numel}) outside the buffer")
+                with torch.cuda.stream(self._comm):
+                    self._works.append(self.dist.all_reduce(self.flat[offset:offset + numel],
+                                                            op=self.dist.ReduceOp.SUM, async_op=True))
+                self._covered += int(numel)
+            except BaseException as e:   # noqa: BLE001 - re-raised on the training thread
+                self._err = self._err or e
 
         self._cb = lib.GRAD_READY_FN(ready)   # keep the ctypes thunk alive as long as the handle may call it
         self.net.set_grad_ready_callback(self._cb, self._comm.cuda_stream, buckets)
@@ -120,9 +130,15 @@ class GradSync:
     def all_reduce(self, optimizer=None):
         if self.world > 1:
             if self._cb is not None:
-                for w in self._works:     # makes the current stream wait for each collective
+                works, covered, err = self._works, self._covered, self._err
+                self._works, self._covered, self._err = [], 0, None
+                if err is not None:
+                    raise RuntimeError("gradient all-reduce failed inside the backward pass") from err
+                if covered != self.flat.numel():   # the reported slices must tile the buffer exactly once
+                    raise RuntimeError(f"overlapped all-reduce covered {covered} of {self.flat.numel()} gradient "
+                                       "elements")
+                for w in works:     # makes the current stream wait for each collective
                     w.wait()
-                self._works = []
             else:
                 self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
         if optimizer is not None:

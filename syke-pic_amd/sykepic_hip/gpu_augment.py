@@ -150,28 +150,41 @@ class GpuTransform:
         return self._finish(out)
 
 
-class _PngDataset:
-    """Map-style dataset for the loader's worker processes: index -> pngio.decode_png."""
-
-    def __init__(self, paths, need_mode):
-        self.paths, self.need_mode = [str(p) for p in paths], need_mode
-
-    def __len__(self):
-        return len(self.paths)
-
-    def __getitem__(self, i):
-        return pngio.decode_png(self.paths[i], self.need_mode)
+_MP_CTX = None
 
 
-class _IndexedPng(_PngDataset):
-    """... returning (index, decoded image): the consumer needs the labels of exactly these indices."""
+def decode_context():
+    """The multiprocessing context the decode processes are started with: `forkserver`.
 
-    def __getitem__(self, i):
-        return i, pngio.decode_png(self.paths[i], self.need_mode)
+    Why not the DataLoader default (`fork`): round 2 recorded one decode worker dying with SIGSEGV one epoch into its
+    life ("Unexpected segmentation fault encountered in worker", one run in ~20), a fork()ed child of a process whose
+    other threads were inside the HIP runtime (the batch thread forked the workers while the main thread was uploading
+    the network's parameters).  The cause could NOT be established from that one record: no traceback was captured,
+    and two probes of the plausible mechanisms came back clean on the GPU box (tests/diagnostics/
+    fork_dontfork_probe.py: 50 children forked while another thread copies pageable memory to the GPU read every page
+    of the buffer; children that finalize an inherited CUDA tensor / event / stream / pinned tensor / HipNet handle
+    exit 0).  What is certain is the exposure: a forked child carries the parent's HIP / RCCL state (mapped queues,
+    signal pages, runtime locks, atfork handlers), and forking earlier only narrows the window - the second and
+    third loader, or a data-parallel rank whose RCCL communicator already exists, still fork from a process with
+    live GPU threads.  So the exposure is removed instead: with `forkserver` the workers are children of a helper
+    process that was exec'ed fresh and never loads the HIP runtime - nothing of the GPU process is inherited, whenever
+    the loader is built.  `start_decode_server()` brings the helper up (train.main calls it first thing, before RCCL /
+    HIP exist); the workers need numpy + PIL (and torch's worker loop), all pre-imported in the helper so a worker
+    starts in milliseconds.  Should a worker still die, `pngio.worker_init` has armed faulthandler (a Python
+    traceback on stderr) and the fallback warning carries every dead worker's exit code."""
+    global _MP_CTX
+    if _MP_CTX is None:
+        import multiprocessing as mp
+        ctx = mp.get_context("forkserver")
+        ctx.set_forkserver_preload(["torch", "torch.utils.data", "sykepic_hip.pngio"])
+        _MP_CTX = ctx
+    return _MP_CTX
 
 
-def _identity(batch):
-    return batch
+def start_decode_server():
+    decode_context()
+    from multiprocessing import forkserver
+    forkserver.ensure_running()
 
 
 class _EpochBatches:
@@ -221,7 +234,7 @@ class GpuLoader:
     draw nothing."""
 
     def __init__(self, paths, labels, transform, batch_size, device, shuffle=False, sampler=None, workers=None,
-                 prefetch=2, num_chans=3):
+                 prefetch=2, num_chans=3, persistent=True):
         import os
         self.paths, self.labels = list(paths), list(labels)
         self.batch_size, self.shuffle, self.sampler = int(batch_size), shuffle, sampler
@@ -232,32 +245,38 @@ class GpuLoader:
             except AttributeError:  # pragma: no cover
                 workers = os.cpu_count() or 1
             workers = max(1, min(8, workers))     # 8 decode processes feed ~26 k img/s
+        if not persistent:
+            workers = min(int(workers), 4)        # validation / test loaders: a small pool that lives for one pass
+        self.persistent = bool(persistent)
         self.workers, self.prefetch = int(workers), max(1, int(prefetch))
         self._need_mode = transform.border == "mode"
         self._batches_of = _EpochBatches(len(self.paths), self.batch_size, shuffle, sampler)
         self._dl = None
-        self._start_workers()     # before this loader touches the GPU (the Normalize table below does)
+        self._start_workers()
         self.pipe = GpuTransform(transform, device, num_chans)
 
     def _start_workers(self):
-        """Fork the decode processes NOW, from the thread that constructs the loader - train.main builds its loaders
-        before the network exists - instead of from the batch-assembly thread in the middle of training: a child forked
-        while other threads are inside the HIP runtime inherits whatever locks they hold (one worker in ~20 runs of the
-        end-to-end test died with "exited unexpectedly").  The processes are persistent; an empty epoch brings them
-        up, and torch's generator is put back so the epoch orders stay those of the single-threaded loader."""
+        """The decode processes (`decode_context`: children of the fork server, not of this process).  A persistent
+        pool (the train loader) is brought up now with an empty epoch, so the first training step does not wait for
+        it; torch's generator is put back so the epoch orders stay those of the single-threaded loader.  A
+        non-persistent pool (validation / test loaders) starts when a pass begins and exits when it ends: three loaders
+        no longer hold three idle pools per rank."""
         if self.workers <= 1 or not self.paths:
             return
         from torch.utils.data import DataLoader
         # batch_sampler yields index lists; the "batch" a worker returns is [(index, decoded image)]
-        self._dl = DataLoader(_IndexedPng(self.paths, self._need_mode), batch_sampler=self._batches_of,
-                              num_workers=self.workers, collate_fn=_identity, persistent_workers=True,
-                              prefetch_factor=self.prefetch)
+        self._dl = DataLoader(pngio.IndexedPng(self.paths, self._need_mode), batch_sampler=self._batches_of,
+                              num_workers=self.workers, collate_fn=pngio.identity, persistent_workers=self.persistent,
+                              prefetch_factor=self.prefetch, multiprocessing_context=decode_context(),
+                              worker_init_fn=pngio.worker_init)
+        if not self.persistent:
+            return
         self._batches_of.pending = []
         rng_state = torch.get_rng_state()
         # torch installs a SIGCHLD handler (main thread only) that raises "DataLoader worker ... is killed" at an arbitrary
         # point of the MAIN thread when a worker dies - in the middle of a training step, say.  The thread that iterates
-        # the DataLoader notices a dead worker by itself and this loader then decodes in-process (`_batches`), so the
-        # previous handler is put back.
+        # the DataLoader notices a dead worker by itself (`_batches` reports its exit status), so the previous handler
+        # is put back.
         import signal
         import threading
         in_main = threading.current_thread() is threading.main_thread()
@@ -293,6 +312,7 @@ class GpuLoader:
         self._batches_of.prepare()
         rng_state = torch.get_rng_state()
         done = 0
+        it = None
         try:
             it = iter(self._dl)                 # draws a worker seed nobody uses: the decode workers are deterministic
             torch.set_rng_state(rng_state)      # ... so the global generator stays where the single-threaded loader leaves it
@@ -306,7 +326,12 @@ class GpuLoader:
             # a decode process died (killed from outside, out of memory ...): finish the epoch - and the run - decoding in
             # this thread rather than losing the training run; the batches and their order do not change
             import warnings
-            warnings.warn(f"sykepic_hip: {e}; decoding in-process from here on")
+            status = []
+            try:   # exit code of each decode process: -11 = SIGSEGV, -9 = killed (out of memory, operator) ...
+                status = [f"pid {w.pid}: exitcode {w.exitcode}" for w in it._workers if not w.is_alive()]
+            except Exception:   # pragma: no cover
+                pass
+            warnings.warn(f"sykepic_hip: {e} ({'; '.join(status) or 'no exit status'}); decoding in-process from here on")
             self._dl, self.workers = None, 1
             for idx in self._batches_of.pending[done:]:
                 yield self._to_batch(idx, [pngio.decode_png(self.paths[i], self._need_mode) for i in idx])

@@ -157,3 +157,28 @@ def dwconv(x, weight, bn_scale, bn_bias, k, stride=1, act=2, lds=1):
         lib.check(so.spk_op_dwconv(_p(xh), _p(wk), _p(bn_scale.float().contiguous()), _p(bn_bias.float().contiguous()),
                                    _p(y), _p(pool), n, h, w, c, k, stride, int(act), int(lds), _stream(dev)))
     return y.permute(0, 3, 1, 2), pool
+
+
+def conv1x1_num_configs():
+    return int(lib.load().spk_op_conv1x1_num_configs())
+
+
+def conv1x1(x, weight, bn_scale, bn_bias, stride=1, relu=True, res=None, split=True, cfg=0):
+    """Eval-path 1x1 conv + folded BN (+ shortcut) (+ ReLU) (spk_op_conv1x1).  x [N,Cin,H,W] float16, weight
+    [Cout,Cin] (or [Cout,Cin,1,1]); res [N,Cout,Ho,Wo] float16 or None.  cfg >= 0: that configuration of the
+    direct-operand kernel (raises RuntimeError "does not fit" when it cannot run the problem), cfg < 0: the implicit
+    GEMM.  Returns [N,Cout,Ho,Wo] float16."""
+    so = lib.load()
+    dev = x.device
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    xh = x.half().permute(0, 2, 3, 1).contiguous()
+    rh = res.half().permute(0, 2, 3, 1).contiguous() if res is not None else None
+    y = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.float16, device=dev)
+    wk = weight.float().reshape(cout, cin).contiguous()
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv1x1(_p(xh), _p(wk), _p(bn_scale.float().contiguous()), _p(bn_bias.float().contiguous()),
+                                    _p(rh) if rh is not None else None, _p(y), n, h, w, cin, cout, int(stride),
+                                    int(bool(relu)), int(bool(split)), int(cfg), _stream(dev)))
+    return y.permute(0, 3, 1, 2)

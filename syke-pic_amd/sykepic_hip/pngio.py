@@ -29,3 +29,36 @@ def decode_png(path, need_mode):
                 return rgb, None
             g = np.ascontiguousarray(rgb[..., 0])
     return g, (int(np.argmax(np.bincount(g.reshape(-1), minlength=256))) if need_mode else 0)
+
+
+class PngDataset:
+    """Map-style dataset for the loader's decode processes: index -> decode_png.  Lives here (numpy + PIL only) so
+    that a decode process unpickles it without importing the GPU side of the package."""
+
+    def __init__(self, paths, need_mode):
+        self.paths, self.need_mode = [str(p) for p in paths], need_mode
+
+    def __len__(self):
+        return len(self.paths)
+
+    def __getitem__(self, i):
+        return decode_png(self.paths[i], self.need_mode)
+
+
+class IndexedPng(PngDataset):
+    """... returning (index, decoded image): the consumer needs the labels of exactly these indices."""
+
+    def __getitem__(self, i):
+        return i, decode_png(self.paths[i], self.need_mode)
+
+
+def identity(batch):
+    return batch
+
+
+def worker_init(worker_id):
+    """A decode process that crashes leaves a Python traceback on stderr (the one crash seen so far left only torch's
+    "Unexpected segmentation fault encountered in worker")."""
+    import faulthandler
+    import sys
+    faulthandler.enable(file=sys.stderr, all_threads=True)

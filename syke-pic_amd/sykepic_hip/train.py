@@ -37,6 +37,10 @@ def _dist():
 def main(args):
     config = ConfigParser()
     config.read(args.config)
+    if not os.environ.get("SYKEPIC_HOST_TRANSFORMS"):
+        # the helper process the PNG decode workers are forked from: up before RCCL / HIP exist in this process
+        from . import gpu_augment
+        gpu_augment.start_decode_server()
     dist, rank, world, local = _dist()
     chief = rank == 0
 
@@ -125,6 +129,9 @@ def main(args):
     optimizer_name = config.get("train", "optimizer")
 
     net = get_network(config, num_classes, device=device)
+    # Dropout masks are a function of (seed, step, layer): give every rank its own stream, otherwise the j-th sample of
+    # every shard draws the same mask at every step.  A run stays deterministic for a given random_seed and world size.
+    net.set_seed(random_seed * world + rank)
     dp.broadcast_state(net, dist)   # every replica starts from rank 0's (random / pretrained) tensors
     schedule.freeze(net.base)
     initial = [p for p in net.parameters() if p.requires_grad]

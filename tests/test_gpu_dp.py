@@ -19,6 +19,13 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_grad_buffer_view_aliases_library_memory():
     from sykepic_hip.dp import GradSync
     from sykepic_hip.net import HipNet
@@ -144,7 +151,7 @@ def test_prob_cli_two_ranks_equals_one_rank(tmp_path, golden_dir):
                          text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29519"] + base + ["-o", str(tmp_path / "out2")],
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + base + ["-o", str(tmp_path / "out2")],
                          env=dict(env, SPK_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
     f1 = list((tmp_path / "out1").rglob(f"{name}.prob.csv"))
@@ -179,10 +186,11 @@ def test_tune_cache_persists_and_is_reused(tmp_path):
     assert first.returncode == 0, first.stderr[-2000:]
     assert "[spk tune]" in first.stderr and cache.is_file()
     lines = cache.read_text().splitlines()
-    assert lines and all(ln.startswith(("conv ", "wgrad ")) for ln in lines)
+    assert lines and all(ln.startswith(("conv ", "wgrad ", "pw1x1 ")) for ln in lines)
+    assert any(ln.startswith("pw1x1 ") for ln in lines)          # the 1x1 downsample convs run on conv_pw.hip
     second = subprocess.run([sys.executable, "-c", code, str(tmp_path / "b.npy")], env=env, capture_output=True,
                             text=True, timeout=600)
     assert second.returncode == 0, second.stderr[-2000:]
-    assert "[spk tune]" not in second.stderr
+    assert "[spk tune]" not in second.stderr and "[spk tune 1x1]" not in second.stderr
     assert cache.read_text().splitlines() == lines              # nothing re-tuned, nothing appended
     assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
