@@ -39,6 +39,7 @@ struct Layer {
   size_t wpack_off = 0, sb_off = 0;
   size_t wpw_off = 0;             // fragment-ordered image of a 1x1 conv's weights (conv_pw.hip), when pw_ok
   bool pw_ok = false;             // 1x1, stride 1 or 2, no padding anywhere, channels multiples of 64
+  bool c3_ok = false;             // 3x3 stride 1 pad 1, cin % 64 == 0, cout % 256 == 0: conv_c3.hip (image at wpw_off)
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)

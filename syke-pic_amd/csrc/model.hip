@@ -245,6 +245,12 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
         L.wpw_off = wpack;
         wpack += (size_t)2 * L.d.cout * L.d.cin;
       }
+      L.c3_ok = L.mode == CONV_MODE_GENERIC && L.d.k == 3 && L.d.stride == 1 && L.d.pad == 1 && L.cin_p == L.d.cin &&
+                L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 256 == 0;
+      if (L.c3_ok) {
+        L.wpw_off = wpack;
+        wpack += (size_t)2 * L.d.cout * 9 * L.d.cin;
+      }
     } else {
       continue;
     }
@@ -487,6 +493,9 @@ int spk_commit(spk_model* m) {
         spk_launch_pack_pw(m->P(L.p_w), nullptr, m->wpack + L.wpw_off, L.d.cout, L.d.cin, DT_F16, layer_split(m, L) ? 2 : 1,
                            m->stream))
       return fail(SPK_ERR_HIP, "pack_pw launch failed");
+    if (L.c3_ok && m->infer_dt == DT_F16 &&
+        spk_launch_pack_c3(m->P(L.p_w), m->wpack + L.wpw_off, L.d.cout, L.d.cin, layer_split(m, L) ? 2 : 1, m->stream))
+      return fail(SPK_ERR_HIP, "pack_c3 launch failed");
   }
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
@@ -773,6 +782,19 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     if (spk_conv1x1_launch(a, q, m->stream))
       return fail(SPK_ERR_HIP, std::string("1x1 conv launch failed for ") + L.d.name);
     return SPK_OK;
+  }
+  static const bool use_c3 = !getenv("SPK_C3") || atoi(getenv("SPK_C3")) != 0;
+  if (use_c3 && L.c3_ok && a.dt == DT_F16 && !a.res && !a.y_lo && !a.cin_s && !a.cout_s) {
+    C3Args q;
+    memset(&q, 0, sizeof q);
+    q.x = a.x; q.wp = m->wpack + L.wpw_off; q.y = a.y; q.scale = a.scale; q.shift = a.bias;
+    q.N = nb; q.H = in.h; q.W = in.w; q.Cin = a.Cin; q.Cout = a.Cout; q.M = a.M; q.relu = a.relu; q.dt = DT_F16;
+    q.nb = a.splitw ? 2 : 1;
+    q.x_bytes = a.x_bytes; q.y_bytes = (unsigned)((size_t)a.M * a.Cout * 2);
+    q.wp_bytes = (unsigned)((size_t)a.Cout * 9 * a.Cin * 2 * q.nb);
+    const int r = spk_conv3x3_launch(q, m->stream);
+    if (r == 0) return SPK_OK;
+    if (r != -3) return fail(SPK_ERR_HIP, std::string("3x3 conv launch failed for ") + L.d.name);
   }
   if (spk_conv_launch(a, L.mode, m->stream, nullptr))
     return fail(SPK_ERR_HIP, std::string("conv launch failed for ") + L.d.name);

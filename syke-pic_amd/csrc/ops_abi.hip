@@ -242,3 +242,46 @@ extern "C" int spk_op_conv1x1(const void* x, const float* w, const float* bn_sca
   return SPK_OK;
 }
 extern "C" int spk_op_conv1x1_num_configs(void) { return spk_pw_num_configs(); }
+
+// 3x3 stride-1 pad-1 convolution + folded BatchNorm (+ReLU) of the eval path (conv_c3.hip) on caller-provided buffers;
+// cfg >= 0: that tile configuration (SPK_ERR_UNSUPPORTED when it does not fit), cfg < 0: the implicit-GEMM kernel.
+extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* bn_scale, const float* bn_bias, void* y,
+                              int n, int h, int wd, int cin, int cout, int relu, int split, int cfg, void* stream) {
+  if (!x || !w_ohwi || !bn_scale || !bn_bias || !y || n < 1 || h < 1 || wd < 1)
+    return ofail(SPK_ERR_ARG, "op_conv3x3: bad arguments");
+  if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = n * h * wd;
+  Scratch sc;
+  bf16_t* wp = sc.get<bf16_t>((size_t)2 * cout * 9 * cin);
+  if (!wp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  int r;
+  if (cfg < 0) {
+    O_TRY(spk_launch_pack_weights(w_ohwi, wp, cout, 3, 3, cin, CONV_MODE_GENERIC, DT_F16, split != 0, s), "pack_weights");
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.cfg = a.dma = -1;
+    a.cls_ph = a.cls_pw = -1;
+    a.x = (const bf16_t*)x; a.w = wp; a.y = (bf16_t*)y; a.scale = bn_scale; a.bias = bn_bias;
+    a.N = n; a.H = h; a.W = wd; a.Cin = cin; a.Ho = h; a.Wo = wd; a.Cout = cout;
+    a.kh = a.kw = 3; a.stride = 1; a.pad = 1; a.M = M; a.K = 9 * cin; a.relu = relu; a.dt = DT_F16; a.splitw = split != 0;
+    a.x_bytes = (unsigned)((size_t)M * cin * 2);
+    a.w_bytes = (unsigned)((size_t)cout * 9 * cin * 2 * (split ? 2 : 1));
+    r = spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr);
+  } else {
+    O_TRY(spk_launch_pack_c3(w_ohwi, wp, cout, cin, split ? 2 : 1, s), "pack_c3");
+    C3Args q;
+    memset(&q, 0, sizeof q);
+    q.x = (const bf16_t*)x; q.wp = wp; q.y = (bf16_t*)y; q.scale = bn_scale; q.shift = bn_bias;
+    q.N = n; q.H = h; q.W = wd; q.Cin = cin; q.Cout = cout; q.M = M; q.relu = relu; q.dt = DT_F16; q.nb = split ? 2 : 1;
+    q.x_bytes = (unsigned)((size_t)M * cin * 2);
+    q.y_bytes = (unsigned)((size_t)M * cout * 2);
+    q.wp_bytes = (unsigned)((size_t)cout * 9 * cin * 2 * q.nb);
+    r = spk_c3_launch(q, cfg, s);
+    if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "this configuration does not fit the problem");
+  }
+  if (r) return ofail(SPK_ERR_HIP, "conv3x3 launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "conv3x3 kernel failed");
+  return SPK_OK;
+}
+extern "C" int spk_op_conv3x3_num_configs(void) { return spk_c3_num_configs(); }

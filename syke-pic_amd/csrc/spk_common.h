@@ -132,6 +132,26 @@ int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout
 int spk_conv1x1_launch(const ConvArgs& a, const PwConvArgs& q, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// 3x3 stride-1 pad-1 convolution, activations as a halo window in LDS, weights straight from L2 (conv_c3.hip)
+// ---------------------------------------------------------------------------
+struct C3Args {
+  const bf16_t* x;      // [N,H,W,Cin] fp16
+  const bf16_t* wp;     // packed by spk_launch_pack_c3
+  bf16_t* y;            // [N,H,W,Cout] fp16
+  const float* scale;   // [Cout] or null
+  const float* shift;   // [Cout] or null
+  int N, H, W, Cin, Cout, M;
+  int relu, dt, nb;
+  unsigned int x_bytes, y_bytes, wp_bytes;
+};
+int spk_c3_num_configs();
+int spk_c3_launch(const C3Args& a, int cfg, hipStream_t s);   // -3: this config does not fit the problem
+int spk_launch_pack_c3(const float* w_ohwi, bf16_t* out, int cout, int cin, int nb, hipStream_t s);
+// eval path: the fastest configuration for this problem, tuned once and cached (all give bit-identical results);
+// -3 when none fits (the caller then runs the implicit GEMM)
+int spk_conv3x3_launch(const C3Args& a, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // Pointwise / pooling / packing kernels (pointwise.hip)
 // ---------------------------------------------------------------------------
 // image batch -> NHWC bf16 with channels padded to 4 (stem input)

@@ -182,3 +182,24 @@ def conv1x1(x, weight, bn_scale, bn_bias, stride=1, relu=True, res=None, split=T
                                     _p(rh) if rh is not None else None, _p(y), n, h, w, cin, cout, int(stride),
                                     int(bool(relu)), int(bool(split)), int(cfg), _stream(dev)))
     return y.permute(0, 3, 1, 2)
+
+
+def conv3x3_num_configs():
+    return int(lib.load().spk_op_conv3x3_num_configs())
+
+
+def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0):
+    """Eval-path 3x3 stride-1 pad-1 conv + folded BN (+ ReLU) (spk_op_conv3x3).  x [N,Cin,H,W] float16, weight
+    [Cout,Cin,3,3]; cfg >= 0: that configuration of the LDS-window kernel, cfg < 0: the implicit GEMM."""
+    so = lib.load()
+    dev = x.device
+    n, cin, h, w = x.shape
+    cout = weight.shape[0]
+    xh = x.half().permute(0, 2, 3, 1).contiguous()
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.float16, device=dev)
+    wk = weight.float().permute(0, 2, 3, 1).contiguous()   # OIHW -> O,kh,kw,I
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv3x3(_p(xh), _p(wk), _p(bn_scale.float().contiguous()), _p(bn_bias.float().contiguous()),
+                                    _p(y), n, h, w, cin, cout, int(bool(relu)), int(bool(split)), int(cfg),
+                                    _stream(dev)))
+    return y.permute(0, 3, 1, 2)

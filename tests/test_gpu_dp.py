@@ -186,11 +186,11 @@ def test_tune_cache_persists_and_is_reused(tmp_path):
     assert first.returncode == 0, first.stderr[-2000:]
     assert "[spk tune]" in first.stderr and cache.is_file()
     lines = cache.read_text().splitlines()
-    assert lines and all(ln.startswith(("conv ", "wgrad ", "pw1x1 ")) for ln in lines)
+    assert lines and all(ln.startswith(("conv ", "wgrad ", "pw1x1 ", "c3 ")) for ln in lines)
     assert any(ln.startswith("pw1x1 ") for ln in lines)          # the 1x1 downsample convs run on conv_pw.hip
     second = subprocess.run([sys.executable, "-c", code, str(tmp_path / "b.npy")], env=env, capture_output=True,
                             text=True, timeout=600)
     assert second.returncode == 0, second.stderr[-2000:]
-    assert "[spk tune]" not in second.stderr and "[spk tune 1x1]" not in second.stderr
+    assert not any(t in second.stderr for t in ("[spk tune]", "[spk tune 1x1]", "[spk tune 3x3]"))
     assert cache.read_text().splitlines() == lines              # nothing re-tuned, nothing appended
     assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))

@@ -132,6 +132,90 @@ static void bw_probe(hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
   CK(hipFree(a)); CK(hipFree(b)); CK(hipFree(flag));
 }
 
+
+// ---- 3x3 convs: conv_c3.hip against the implicit GEMM ----
+static int bench_c3(int batch, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+  struct S3 { const char* name; int hw, c; int count; };
+  const S3 shapes[] = {{"s1.conv2 64@56", 56, 64, 3}, {"s2.conv2 128@28", 28, 128, 3}, {"s3.conv2 256@14", 14, 256, 5}, {"s4.conv2 512@7", 7, 512, 2}};
+  const int nb = getenv("PW_NB") ? atoi(getenv("PW_NB")) : 1;
+  const char* filt = getenv("C3_FILT");
+  double tot_old = 0, tot_new = 0;
+  for (const S3& sh : shapes) {
+    if (filt && !strstr(sh.name, filt)) continue;
+    const int H = sh.hw, W = sh.hw, C = sh.c;
+    const size_t M = (size_t)batch * H * W, nx = M * C, nw = (size_t)C * 9 * C;
+    std::vector<unsigned short> hx(nx);
+    std::vector<float> hw(nw), hs(C), hb(C);
+    for (auto& v : hx) { float f = urand() * 2.f - 0.7f; f = f > 0 ? f : 0.f; v = __builtin_bit_cast(unsigned short, (_Float16)f); }
+    const float bound = sqrtf(6.f / (9 * C));
+    for (auto& v : hw) v = (urand() * 2.f - 1.f) * bound;
+    for (auto& v : hs) v = 0.5f + urand();
+    for (auto& v : hb) v = urand() - 0.5f;
+    bf16_t *dx, *dy0, *dy1, *wp_old, *wp_new;
+    float *dw, *dsc, *dbi;
+    CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dy0, nx * 2)); CK(hipMalloc(&dy1, nx * 2));
+    CK(hipMalloc(&wp_old, nw * 4)); CK(hipMalloc(&wp_new, nw * 4));
+    CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dsc, C * 4)); CK(hipMalloc(&dbi, C * 4));
+    CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dsc, hs.data(), C * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbi, hb.data(), C * 4, hipMemcpyHostToDevice));
+    if (spk_launch_pack_weights(dw, wp_old, C, 3, 3, C, CONV_MODE_GENERIC, DT_F16, nb == 2, st)) return 2;
+    if (spk_launch_pack_c3(dw, wp_new, C, C, nb, st)) return 2;
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.cfg = a.dma = -1; a.cls_ph = a.cls_pw = -1;
+    a.x = dx; a.w = wp_old; a.y = dy0; a.scale = dsc; a.bias = dbi;
+    a.N = batch; a.H = H; a.W = W; a.Cin = C; a.Ho = H; a.Wo = W; a.Cout = C;
+    a.kh = a.kw = 3; a.stride = 1; a.pad = 1; a.M = (int)M; a.K = 9 * C; a.relu = 1; a.dt = DT_F16; a.splitw = nb == 2;
+    a.x_bytes = (unsigned)(nx * 2); a.w_bytes = (unsigned)(nw * 2 * nb);
+    if (spk_conv_launch(a, CONV_MODE_GENERIC, st, nullptr)) { fprintf(stderr, "igemm launch failed\n"); return 3; }
+    CK(hipStreamSynchronize(st));
+    const int reps = 10;
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < reps; ++r) spk_conv_launch(a, CONV_MODE_GENERIC, st, nullptr);
+    CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+    float ms_old; CK(hipEventElapsedTime(&ms_old, e0, e1)); ms_old /= reps;
+    std::vector<unsigned short> y0(nx), y1(nx);
+    CK(hipMemcpy(y0.data(), dy0, nx * 2, hipMemcpyDeviceToHost));
+    C3Args q;
+    memset(&q, 0, sizeof q);
+    q.x = dx; q.wp = wp_new; q.y = dy1; q.scale = dsc; q.shift = dbi;
+    q.N = batch; q.H = H; q.W = W; q.Cin = C; q.Cout = C; q.M = (int)M; q.relu = 1; q.dt = DT_F16; q.nb = nb;
+    q.x_bytes = (unsigned)(nx * 2); q.y_bytes = (unsigned)(nx * 2); q.wp_bytes = (unsigned)(nw * 2 * nb);
+    const double flop = 2.0 * M * 9 * C * C;
+    printf("%-20s M=%zu  igemm %.1f us (%.0f TF)\n", sh.name, M, ms_old * 1e3, flop / ms_old / 1e9);
+    float best = 1e30f; int best_cfg = -1;
+    for (int cfg = 0; cfg < spk_c3_num_configs(); ++cfg) {
+      CK(hipMemsetAsync(dy1, 0xee, nx * 2, st));
+      const int r0 = spk_c3_launch(q, cfg, st);
+      if (r0 == -3) continue;
+      if (r0) { fprintf(stderr, "c3 launch cfg %d failed: %d\n", cfg, r0); return 4; }
+      CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(y1.data(), dy1, nx * 2, hipMemcpyDeviceToHost));
+      double maxd = 0; size_t bad = 0;
+      for (size_t i = 0; i < nx; ++i) {
+        const float u = (float)__builtin_bit_cast(_Float16, y0[i]), v = (float)__builtin_bit_cast(_Float16, y1[i]);
+        const double d = fabs((double)u - v);
+        if (!(d <= 4e-3 * (1.0 + fabs(u)))) { if (bad < 8) printf("      bad px %zu cout %zu: want %g got %g\n", i / C, i % C, u, v); ++bad; }
+        if (d > maxd) maxd = d;
+      }
+      CK(hipEventRecord(e0, st));
+      for (int r = 0; r < reps; ++r) spk_c3_launch(q, cfg, st);
+      CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+      printf("    c3 cfg %d: %7.1f us (%4.0f TF)  max|d| %.2e  bad %zu%s\n", cfg, ms * 1e3, flop / ms / 1e9, maxd, bad, bad ? "  <-- MISMATCH" : "");
+      if (!bad && ms < best) { best = ms; best_cfg = cfg; }
+    }
+    printf("    => best c3 cfg %d: %.1f us vs igemm %.1f us (x%.2f)\n", best_cfg, best * 1e3, ms_old * 1e3, ms_old / best);
+    fflush(stdout);
+    tot_old += ms_old * sh.count; tot_new += (best < ms_old ? best : ms_old) * sh.count;
+    hipFree(dx); hipFree(dy0); hipFree(dy1); hipFree(wp_old); hipFree(wp_new); hipFree(dw); hipFree(dsc); hipFree(dbi);
+  }
+  printf("TOTAL over the network's stride-1 3x3 convs: igemm %.3f ms -> best-of %.3f ms\n", tot_old, tot_new);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   const int batch = argc > 1 ? atoi(argv[1]) : 256;
   const char* filt = argc > 2 ? argv[2] : nullptr;
@@ -143,6 +227,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   if (getenv("PW_BW")) bw_probe(st, e0, e1);
+  if (getenv("C3")) return bench_c3(batch, st, e0, e1);
   double tot_old = 0, tot_new = 0;
   for (const Shape& sh : kShapes) {
     if (filt && !strstr(sh.name, filt)) continue;
