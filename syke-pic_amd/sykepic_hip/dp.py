@@ -236,6 +236,16 @@ def all_ok(ok, dist=None):
     return bool(int(t.item()))
 
 
+def gather_parts(part, dist=None, dst=0):
+    """Inference, array form: every rank's shard object (prob.ProbRows) on rank `dst` ([part] without a process
+    group; None on the other ranks).  Host-side object gather like `gather_rows`."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [part]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(part, out, dst=dst)
+    return out
+
+
 def gather_rows(rows, dist=None, dst=None):
     """Inference: the ranks' [(roi, probs)] lists concatenated and sorted by ROI number, as `net_pass` returns them
     (reference probability.py:195-197).  dst=None: on every rank; dst=r: on rank r only (None elsewhere).  The

@@ -30,18 +30,17 @@ class SampleOnGpu:
     """The `.roi` blob of one sample in device memory + its ROI table."""
 
     def __init__(self, adc, roi, device):
-        table = ifcb.parse_adc(adc)
+        num, w, h, start = ifcb.parse_adc_arrays(adc)
         blob = np.fromfile(roi, dtype=np.uint8)
-        for num, w, h, start in table:
-            if start + w * h > blob.size:
-                raise ValueError(f"ROI {num} exceeds the .roi file")
-        self.numbers = [t[0] for t in table]
+        over = start + w * h > blob.size
+        if over.any():
+            raise ValueError(f"ROI {int(num[np.argmax(over)])} exceeds the .roi file")
+        self.numbers = num                      # int64 array, ascending
         self.device = torch.device(device)
         self.blob = torch.from_numpy(blob).to(self.device) if blob.size else torch.zeros(1, dtype=torch.uint8, device=self.device)
-        rois = np.zeros(len(table), dtype=np.dtype([("offset", "<i8"), ("width", "<i4"), ("height", "<i4")]))
-        for i, (_, w, h, start) in enumerate(table):
-            rois[i] = (start, w, h)
-        self.rois = torch.from_numpy(rois.view(np.uint8).copy()).to(self.device) if len(table) else None
+        rois = np.zeros(num.size, dtype=np.dtype([("offset", "<i8"), ("width", "<i4"), ("height", "<i4")]))
+        rois["offset"], rois["width"], rois["height"] = start, w, h
+        self.rois = torch.from_numpy(rois.view(np.uint8).copy()).to(self.device) if num.size else None
         self.blob_bytes = int(blob.size)
 
     def __len__(self):

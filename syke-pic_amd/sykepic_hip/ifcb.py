@@ -17,6 +17,27 @@ def sample_to_datetime(sample, isoformat=False):
     return stamp.isoformat() if isoformat else stamp
 
 
+def parse_adc_arrays(adc):
+    """(roi numbers, widths, heights, start bytes) as int64 arrays, non-empty ROIs only - the columns `next_roi`
+    reads (reference sykepic/utils/ifcb.py:133-145), parsed by pandas' C reader in one call instead of 20 k
+    `line.split(",")` (a tenth of the per-sample host time of `sykepic prob`).  Anything the C reader does not turn
+    into plain integers goes back to the line loop, which raises what the reference raises."""
+    try:
+        import pandas as pd
+        t = pd.read_csv(adc, header=None, usecols=[15, 16, 17], dtype=str, engine="c", skip_blank_lines=False,
+                        na_filter=False)
+        w, h, start = (t[c].to_numpy() for c in (15, 16, 17))
+        w, h, start = (np.array([int(v) for v in col], dtype=np.int64) if col.size < 64 else col.astype(np.int64)
+                       for col in (w, h, start))
+    except Exception:   # noqa: BLE001 - malformed file: the loop below reports it like the reference
+        rows = parse_adc(adc)
+        a = np.array(rows, dtype=np.int64).reshape(-1, 4)
+        return a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+    num = np.arange(1, w.size + 1, dtype=np.int64)
+    keep = (w >= 1) & (h >= 1)          # empty trigger: skipped, so ROI ids are sparse (Q11)
+    return num[keep], w[keep], h[keep], start[keep]
+
+
 def parse_adc(adc):
     """[(roi number (1-based line), width, height, start byte)] for non-empty ROIs."""
     rows = []

@@ -57,9 +57,100 @@ def net_pass(net, dataloader, device="cuda:0"):
     return sorted(results)
 
 
+class ProbRows:
+    """The rows of `net_pass` as two arrays (ROI numbers int64 [n], probabilities float32 [n, classes]) instead of
+    n Python tuples of 50 Python floats: what the per-sample loop of `sykepic prob` carries between the GPU and the
+    CSV file.  Iterating yields the reference's `(roi, [p, ...])` rows."""
+
+    def __init__(self, numbers, probs):
+        self.numbers = np.asarray(numbers, dtype=np.int64).reshape(-1)
+        self.probs = np.asarray(probs, dtype=np.float32).reshape(self.numbers.size, -1)
+
+    def __len__(self):
+        return int(self.numbers.size)
+
+    def __iter__(self):
+        return iter(zip(self.numbers.tolist(), self.probs.tolist()))
+
+    def sorted(self):
+        order = np.argsort(self.numbers, kind="stable")
+        return ProbRows(self.numbers[order], self.probs[order])
+
+    @staticmethod
+    def concat(parts):
+        parts = [p for p in parts if len(p)]
+        if not parts:
+            return ProbRows(np.zeros(0, np.int64), np.zeros((0, 0), np.float32))
+        return ProbRows(np.concatenate([p.numbers for p in parts]), np.concatenate([p.probs for p in parts]))
+
+
+class PendingRows:
+    """Rows whose probabilities are still being computed: ROI numbers on the host, one device tensor per batch.
+    `result()` is the only point that waits for the GPU (one device->host copy)."""
+
+    def __init__(self, nums, outs):
+        self.nums, self.outs = nums, outs
+
+    def result(self):
+        if not self.outs:
+            return ProbRows(np.zeros(0, np.int64), np.zeros((0, 0), np.float32))
+        return ProbRows(np.concatenate(self.nums), torch.cat(self.outs).cpu().numpy()).sorted()
+
+
+def net_pass_launch(net, batches, device="cuda:0"):
+    """`net_pass` for batches of (x, ROI numbers), launch half: every batch is queued on the stream, nothing is
+    read back and no per-ROI Python object is built."""
+    net.to(device)
+    net.eval()
+    nums, outs = [], []
+    for x, numbers in batches:
+        outs.append(net.probabilities(x, SOFTMAX_EXP))      # async on the stream
+        nums.append(np.asarray(numbers, dtype=np.int64))
+    return PendingRows(nums, outs)
+
+
+def net_pass_arrays(net, batches, device="cuda:0"):
+    return net_pass_launch(net, batches, device).result()
+
+
+def _format_rows(rows, n_classes):
+    """`"%d," + ",".join(["%.5f"] * n) % row` for every row, as bytes, with vectorised integer arithmetic: the value
+    rounded to 5 decimals is rint(p * 1e5); `%.5f` rounds the exact binary value, p * 1e5 carries one more rounding
+    (2^-53 relative), so entries within 1e-6 of a half are redone with `%` itself.  None: not representable this way
+    (a value outside [0, 10), a ragged row) - the caller formats row by row."""
+    p = rows.probs.astype(np.float64)
+    if p.ndim != 2 or p.shape[1] != n_classes or p.size == 0:
+        return None
+    if not np.isfinite(p).all() or p.min() < 0.0 or p.max() >= 9.999994:
+        return None
+    s = p * 1e5
+    v = np.rint(s).astype(np.int64)
+    for i, j in np.argwhere(np.abs(s - np.floor(s) - 0.5) < 1e-6):
+        v[i, j] = int(("%.5f" % p[i, j]).replace(".", ""))
+    buf = np.empty(p.shape + (8,), dtype=np.uint8)
+    buf[..., 0] = 48 + v // 100000
+    buf[..., 1] = 46
+    r = v % 100000
+    for k, d in enumerate((10000, 1000, 100, 10, 1)):
+        buf[..., 2 + k] = 48 + (r // d) % 10
+    buf[..., 7] = 44
+    buf[:, -1, 7] = 10
+    body = buf.reshape(p.shape[0], -1)
+    out = []
+    for num, row in zip(rows.numbers.tolist(), body):
+        out.append(b"%d," % num)
+        out.append(row.tobytes())
+    return b"".join(out)
+
+
 def probabilities_to_csv(probabilities, classes, csv_path):
     csv_path = Path(csv_path)
     csv_path.parent.mkdir(parents=True, exist_ok=True)
+    if isinstance(probabilities, ProbRows):
+        body = _format_rows(probabilities, len(classes))
+        if body is not None:
+            csv_path.write_bytes(("roi," + ",".join(classes) + "\n").encode() + body)
+            return
     lines = ["roi," + ",".join(classes)]
     row_fmt = "%d," + ",".join(["%.5f"] * len(classes))      # one C-level format per row, not one per value
     for roi, probs in probabilities:
@@ -113,22 +204,24 @@ def _finish(rows, error, what, classes, csv_path, dist):
     rank, _ = dp.rank_world(dist)
     if not dp.all_ok(error is None, dist):
         raise error if error is not None else RuntimeError(f"another rank failed on {what}")
-    probabilities = dp.gather_rows(rows, dist, dst=0)
+    if isinstance(rows, ProbRows):
+        parts = dp.gather_parts(rows, dist, dst=0)
+        probabilities = ProbRows.concat(parts).sorted() if parts is not None else None
+    else:
+        probabilities = dp.gather_rows(rows, dist, dst=0)
     if rank == 0:
         probabilities_to_csv(probabilities, classes, csv_path)
 
 
-def process_sample(sample_path, net, params, out_dir, force=False, dist=None):
-    """One IFCB sample -> `<out>/YYYY/MM/DD/<sample>.prob.csv`.  Under `torch.distributed` (one process per GPU)
-    the ROI list is split into contiguous shards (`dp.shard_range`), every rank runs `net_pass` on its shard
-    with its full weight replica, rank 0 merges the rows by ROI number and writes the file: the batch split of
-    SURVEY.md section 8e, no collective on the data path."""
+def launch_sample(sample_path, net, params, out_dir, force=False, dist=None):
+    """First half of `process_sample`: parse the sample, put its `.roi` blob on the GPU and queue preprocessing +
+    forward for this rank's shard.  Returns None (CSV exists, not forced) or the state `complete_sample` finishes."""
     from . import dp, files, ifcb
     sample_path = Path(sample_path)
     sample = sample_path.name
     csv_path = files.sample_csv_path(sample_path, out_dir, suffix=FILE_SUFFIX)
     if _skip_existing(csv_path, force, dist):
-        return sample
+        return None
     log.debug(f"Computing probabilities for {sample}")
     rank, world = dp.rank_world(dist)
     rows, error = [], None
@@ -145,17 +238,40 @@ def process_sample(sample_path, net, params, out_dir, force=False, dist=None):
             def gpu_batches():
                 for b in range(lo, hi, params.batch_size):
                     e = min(hi, b + params.batch_size)
-                    yield gs.batch(b, e, th, tw, code), [f"{sample}_{num:05d}.png" for num in gs.numbers[b:e]]
-            rows = net_pass(net, gpu_batches(), params.device)
+                    yield gs.batch(b, e, th, tw, code), gs.numbers[b:e]
+            rows = net_pass_launch(net, gpu_batches(), params.device)
         else:
             rois = ifcb.read_rois(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"))
             lo, hi = dp.shard_range(len(rois), rank, world)
             items = [(f"{sample}_{num:05d}.png", _as_chans(img, params.img_shape[0])) for num, img in rois[lo:hi]]
             rows = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
-    except Exception as e:  # noqa: BLE001 - re-raised below on every rank
+    except Exception as e:  # noqa: BLE001 - re-raised by complete_sample on every rank
         error = e
+    return sample, rows, error, csv_path
+
+
+def complete_sample(state, params, dist=None):
+    """Second half: wait for the GPU, gather the ranks' rows, write the CSV (rank 0).  Raises what went wrong in
+    either half."""
+    sample, rows, error, csv_path = state
+    if error is None and isinstance(rows, PendingRows):
+        try:
+            rows = rows.result()
+        except Exception as e:  # noqa: BLE001
+            rows, error = [], e
     _finish(rows, error, sample, params.classes, csv_path, dist)
     return sample
+
+
+def process_sample(sample_path, net, params, out_dir, force=False, dist=None):
+    """One IFCB sample -> `<out>/YYYY/MM/DD/<sample>.prob.csv`.  Under `torch.distributed` (one process per GPU)
+    the ROI list is split into contiguous shards (`dp.shard_range`), every rank runs `net_pass` on its shard
+    with its full weight replica, rank 0 merges the rows by ROI number and writes the file: the batch split of
+    SURVEY.md section 8e, no collective on the data path."""
+    state = launch_sample(sample_path, net, params, out_dir, force, dist)
+    if state is None:
+        return Path(sample_path).name
+    return complete_sample(state, params, dist)
 
 
 def _as_chans(gray, num_chans):
@@ -203,14 +319,36 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
     it = sample_paths
     if progress_bar and tqdm:
         it = tqdm(it, desc="Processing samples")
+    # Two samples in flight: while the GPU runs sample k+1 the host reads back, formats and writes sample k (the
+    # reference handles one sample at a time, probability.py:97-114; same files, same per-sample error handling).
     done = set()
-    for sample_path in it:
+    pending = None          # (sample path, state of launch_sample)
+
+    def guarded(fn, sample_path):
         try:
-            done.add(process_sample(sample_path, net, params, out_dir, force, dist))
+            return fn()
         except ValueError:
             log.exception(f"Faulty raw data for {Path(sample_path).name}")
         except Exception:
             log.exception(f"Unexpected error for {Path(sample_path).name}")
+        return None
+
+    def finish(p):
+        if p is None:
+            return
+        name = guarded(lambda: complete_sample(p[1], params, dist), p[0])
+        if name is not None:
+            done.add(name)
+
+    for sample_path in it:
+        state = guarded(lambda: launch_sample(sample_path, net, params, out_dir, force, dist) or "skip", sample_path)
+        finish(pending)
+        pending = None
+        if state == "skip":
+            done.add(Path(sample_path).name)
+        elif state is not None:
+            pending = (sample_path, state)
+    finish(pending)
     return done
 
 

@@ -321,7 +321,84 @@ def golden_prediction():
     print(res)
 
 
+def golden_input_helpers():
+    """The cv2-free input helpers of the reference, run unmodified: `image.get_new_dims` over a size grid,
+    `ifcb.raw_to_numpy` / `next_roi` on the valid raw fixture, and `image.Compose` (+ every transform class) with the
+    stand-in primitives of tests/golden/standins.py installed as `cv2` - the call log and the output of each run pin the
+    control flow around the pixel interpolation (sykepic/train/image.py:9-180, sykepic/utils/ifcb.py:121-145)."""
+    import random
+    import cv2
+    import standins as S
+    from sykepic.train import image as rimg
+    from sykepic.utils import ifcb as rifcb
+    out = {}
+    grid = []
+    for th, tw in ((180, 180), (224, 224), (299, 299), (64, 96), (96, 64)):
+        for h in (1, 2, 3, 7, 16, 41, 42, 56, 99, 100, 179, 180, 181, 223, 224, 225, 500, 1023):
+            for w in (1, 2, 5, 17, 42, 55, 56, 57, 100, 180, 224, 333, 1024):
+                nh, nw = rimg.get_new_dims(h, w, th, tw)
+                grid.append([h, w, th, tw, int(nh), int(nw)])
+    out["get_new_dims"] = grid
+    data = HERE / "ref_data"
+    rois = []
+    for i, a in rifcb.raw_to_numpy(data / "D20180712T065600_IFCB114.adc", data / "D20180712T065600_IFCB114.roi"):
+        rois.append({"id": int(i), "shape": [int(v) for v in a.shape], "sum": int(a.astype(np.int64).sum()),
+                     "crc": S.crc(a), "dtype": str(a.dtype)})
+    out["raw_to_numpy"] = rois
+    # ---- Compose under recording stand-ins ----
+    log = []
+
+    def resize(img, dsize, fx=0, fy=0, interpolation=None):
+        h, w = img.shape[:2]
+        if dsize is None:
+            nw, nh = int(np.rint(w * fx)), int(np.rint(h * fy))     # cv2: saturate_cast<int>(src * f)
+            log.append(["resize", nw, nh, round(float(fx), 9)])
+        else:
+            nw, nh = int(dsize[0]), int(dsize[1])
+            log.append(["resize", nw, nh, None])
+        return S.nn_resize(img, nw, nh)
+
+    def copy_make_border(img, top, bot, left, right, borderType=None, value=None):
+        log.append(["pad", int(top), int(bot), int(left), int(right), S.border_list(value)])
+        return S.pad(img, top, bot, left, right, S.border_list(value))
+
+    def calc_hist(imgs, channels, mask, sizes, ranges):
+        return np.bincount(imgs[0][..., channels[0]].reshape(-1), minlength=256).astype(np.float32)
+
+    def flip(img, code):
+        log.append(["flip", int(code)])
+        return np.ascontiguousarray(img[:, ::-1] if code == 1 else img[::-1])
+
+    def warp_affine(img, m, dsize, borderValue=None):
+        log.append(["warp", S.mat_list(m), [int(dsize[0]), int(dsize[1])], S.border_list(borderValue)])
+        return S.warp(img, m, S.border_list(borderValue))
+
+    def get_rot(center, angle, scale):
+        log.append(["rot", [int(center[0]), int(center[1])], int(angle), float(scale)])
+        return S.rotation_matrix(center, angle, scale)
+
+    cv2.resize, cv2.copyMakeBorder, cv2.calcHist, cv2.flip = resize, copy_make_border, calc_hist, flip
+    cv2.warpAffine, cv2.getRotationMatrix2D = warp_affine, get_rot
+    runs = []
+    for pname, dims, border, spec in S.PIPELINES:
+        ts = [getattr(rimg, t[0])(*t[1:]) for t in spec]
+        comp = rimg.Compose(ts, dims, border)
+        for iname, img in S.test_images():
+            for seed in (0, 1, 2):
+                random.seed(seed * 1000 + len(iname))
+                del log[:]
+                mode = rimg.mode_pixel_value(img)
+                res = comp(img.copy())
+                runs.append({"pipeline": pname, "image": iname, "seed": seed, "mode": int(mode),
+                             "trace": json.loads(json.dumps(log)), "out_shape": [int(v) for v in res.shape],
+                             "out_crc": S.crc(res), "rand_after": random.random()})
+    out["compose"] = runs
+    (HERE / "input_helpers.json").write_text(json.dumps(out))
+    print("input helpers:", len(grid), "size pairs,", len(rois), "ROIs,", len(runs), "Compose runs")
+
+
 if __name__ == "__main__":
+    sys.path.insert(0, str(HERE))
     install_shims()
     torch.set_num_threads(8)
     import tempfile
@@ -340,3 +417,5 @@ if __name__ == "__main__":
         golden_schedules()
     if "pred" in which:
         golden_prediction()
+    if "helpers" in which:
+        golden_input_helpers()

@@ -46,7 +46,7 @@ def test_matches_host_pipeline_bytewise(tmp_path, border):
     adc, roi = _write_sample(tmp_path, "D20200101T000000_IFCB114", imgs)
     th, tw = 180, 180
     gs = gpu_preprocess.SampleOnGpu(adc, roi, "cuda:0")
-    assert gs.numbers == list(range(2, len(imgs) + 1))          # the empty trigger is skipped
+    assert gs.numbers.tolist() == list(range(2, len(imgs) + 1))          # the empty trigger is skipped
     tr = preprocess.Compose([preprocess.Resize(), preprocess.ToTensor()], (th, tw), border)
     assert gpu_preprocess.supported(tr, 3)
     got = gs.batch(0, len(gs), th, tw, gpu_preprocess.border_code(tr)).cpu().numpy()
@@ -61,7 +61,7 @@ def test_reference_fixture_and_forward(golden_dir):
     from sykepic_hip.net import HipNet
     d = golden_dir / "ref_data"
     gs = gpu_preprocess.SampleOnGpu(d / "D20180712T065600_IFCB114.adc", d / "D20180712T065600_IFCB114.roi", "cuda:0")
-    assert gs.numbers == [2, 3]
+    assert gs.numbers.tolist() == [2, 3]
     x8 = gs.batch(0, 2, 180, 180, -1)
     assert int(x8[0, 0, 0, 0]) == 164 and int(x8[1, 0, 0, 0]) == 206     # modal greys
     # the uint8 NHWC batch drives the forward exactly like the float NCHW tensor the host pipeline builds

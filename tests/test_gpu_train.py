@@ -250,10 +250,20 @@ def test_resnet50_train_step_at_the_benched_size():
           f"layer4+head worst gradient rel-L2 {worst[1]:.3e} at {worst[0]}; gradient entering layer4 {r_in:.3e}")
 
 
+GOLD_SLICES = ("base.0.weight", "base.1.weight", "base.1.running_mean", "base.1.running_var", "base.4.0.conv1.weight",
+               "base.7.1.conv2.weight", "base.7.1.bn2.bias", "head.0.weight", "head.2.weight", "head.2.bias")
+
+
 @pytest.mark.parametrize("optim_name", ["SGD", "Adam"])
 def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
-    """Same 3-epoch run as tests/golden/make_golden.py drove through the
-    reference's train_net: freeze -> LRWarmup steps at epochs 1,2,3."""
+    """Same 3-epoch run as tests/golden/make_golden.py drove through the reference's train_net: freeze -> LRWarmup
+    steps at epochs 1,2,3, one optimizer step per phase of the unfreeze schedule.
+
+    Round 3: besides losses and per-tensor norms (a norm barely moves in one lr = 0.01 step, so a wrong-signed or
+    mis-scaled update would pass those), the UPDATE of every stored 64-element parameter slice, p_after - p_before, is
+    compared with the reference's: direction (cosine) and length for SGD, element signs for Adam (whose first steps
+    are lr * sign(g) up to eps), for every phase in which the reference moved that slice at all - and the training
+    logits of every step against the reference's (bf16 forward vs fp32)."""
     gold = np.load(golden_dir / f"train_{optim_name.lower()}.npz")
     n, hw, classes = 8, 64, 10
     g, specs, ref, net = _pair("resnet18", classes, seed=5)
@@ -268,15 +278,22 @@ def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
     xv = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=12)).cuda()
     yv = torch.from_numpy(synth.synth_labels(n, classes, seed=13)).cuda()
     keys = [k for k, _, _ in specs]
+    sd0 = net.state_dict()
+    prev_hip = {k: sd0[k].flatten()[:64].double().cpu().numpy() for k in GOLD_SLICES}
+    prev_gold = dict(prev_hip)          # both runs start from the same synthetic state (seed 5)
+    moved = 0
     for epoch in (1, 2, 3):
         warm(epoch)
         net.train()
         net.reset_stats()
-        net.forward_backward(x, y)
+        logits = net.forward_backward(x, y, want_logits=True)
         opt.step()
         loss_n, _ = net.read_stats()
         # loss within 3 % of the reference's fp32 run (bf16 forward)
         assert abs(loss_n / n - gold["train_loss"][epoch - 1]) < 0.03 * gold["train_loss"][epoch - 1] + 0.02
+        gl = gold["train_logits"][epoch - 1]
+        rel = float(np.linalg.norm(logits.float().cpu().numpy() - gl) / np.linalg.norm(gl))
+        assert rel <= 3e-2, f"epoch {epoch}: training logits rel-L2 {rel:.3e} vs the reference's"
         net.eval()
         net.reset_stats()
         net.eval_step(xv, yv)
@@ -286,6 +303,33 @@ def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
         l2 = np.array([float(sd[k].double().norm()) for k in keys])
         assert np.allclose(l2, gold[f"e{epoch}_l2"], rtol=2e-2, atol=1e-3), epoch
         assert int(sd["base.1.num_batches_tracked"]) == int(gold[f"e{epoch}_nbt"])
+        for k in GOLD_SLICES:
+            cur_hip = sd[k].flatten()[:64].double().cpu().numpy()
+            cur_gold = gold[f"e{epoch}_{k}"].astype(np.float64)
+            du_hip, du_gold = cur_hip - prev_hip[k], cur_gold - prev_gold[k]
+            prev_hip[k], prev_gold[k] = cur_hip, cur_gold
+            scale = max(float(np.abs(cur_gold).max()), 1e-6)
+            if np.abs(du_gold).max() < 1e-7 * scale:
+                # the reference did not move this slice in this phase (frozen): neither may the HIP path
+                assert np.abs(du_hip).max() < 1e-6 * scale, (epoch, k)
+                continue
+            moved += 1
+            if k.endswith(("running_mean", "running_var")):
+                # BatchNorm buffers: momentum update from the batch statistics (no optimizer involved)
+                assert np.allclose(du_hip, du_gold, rtol=5e-2, atol=2e-3 * scale), (epoch, k)
+                continue
+            big = np.abs(du_gold) > 0.05 * np.abs(du_gold).max()
+            if optim_name == "Adam":
+                agree = float((np.sign(du_hip[big]) == np.sign(du_gold[big])).mean())
+                assert agree >= 0.97, f"epoch {epoch} {k}: update signs agree on {agree:.2f} of the elements"
+                ratio = np.linalg.norm(du_hip[big]) / np.linalg.norm(du_gold[big])
+                assert 0.85 <= ratio <= 1.15, (epoch, k, ratio)
+            else:
+                cos = float(du_hip @ du_gold / (np.linalg.norm(du_hip) * np.linalg.norm(du_gold)))
+                ratio = float(np.linalg.norm(du_hip) / np.linalg.norm(du_gold))
+                assert cos >= 0.98, f"epoch {epoch} {k}: update cosine {cos:.4f}"
+                assert 0.95 <= ratio <= 1.05, f"epoch {epoch} {k}: update norm ratio {ratio:.3f}"
+    assert moved >= 12      # head + BN slices move in every phase, the conv slices from their unfreeze epoch on
     assert np.allclose([gp["lr"] for gp in opt.param_groups], gold["group_lr"][0])
     assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == gold["group_sizes"].tolist()
 

@@ -24,6 +24,10 @@ import os
 for k in range(3):
     for ext in ("adc", "roi"):
         os.link(raw / f"D20200101T000000_IFCB114.{ext}", raw3 / f"D20200101T00000{k + 1}_IFCB114.{ext}")
+raw9 = tmp / "raw9"; raw9.mkdir()
+for k in range(9):
+    for ext in ("adc", "roi"):
+        os.link(raw / f"D20200101T000000_IFCB114.{ext}", raw9 / f"D20200101T0001{k:02d}_IFCB114.{ext}")
 model = tmp / "model"; model.mkdir()
 g = arch.build_graph(network, 50)
 sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
@@ -48,10 +52,15 @@ for bs in (64, 512):
     prob.call(Args(str(raw3), None, None, None, str(model), out, bs, 2, True))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3        # three more samples in one call: what a further sample of a run costs
+    t0 = time.perf_counter()
+    prob.call(Args(str(raw9), None, None, None, str(model), out, bs, 2, True))
+    torch.cuda.synchronize()
+    dt9 = (time.perf_counter() - t0) / 9       # nine samples in one call: the model load is 1/9 per sample
     if prof:
         import pstats
         prof.disable()
         pstats.Stats(prof).sort_stats("cumulative").print_stats(28)
     print(f"{network} 180x180, {n_roi} ROIs ({off/1e6:.0f} MB .roi), batch {bs}: first call {dt_first:.2f} s = {n_roi/dt_first:.0f} ROI/s "
-          f"(model load + kernel tuning included); three more samples in one call: {dt:.2f} s each = {n_roi/dt:.0f} ROI/s", flush=True)
+          f"(model load + kernel tuning included); three more samples in one call: {dt:.2f} s each = {n_roi/dt:.0f} ROI/s; "
+          f"nine samples in one call: {dt9:.3f} s each = {n_roi/dt9:.0f} ROI/s", flush=True)
 shutil.rmtree(tmp)
