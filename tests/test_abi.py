@@ -39,3 +39,22 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(lib.LayerDesc) == 11 * 4 + 4 + 96 + 96
     assert ctypes.sizeof(lib.OptimDesc) == 4 + 12 + 12 + 4 + 4 + 4 + 16
     assert ctypes.sizeof(lib.LayerTime) == 96 + 4 + 4 + 8 + 8  # 4 B padding before the doubles
+
+
+def test_host_code_under_address_and_ub_sanitizers():
+    """`csrc/build.sh asan`: every translation unit with -fsanitize=address,undefined on its host pass + csrc/
+    asan_driver.hip, which walks handle creation and its error paths, the parameter table (with a deliberately short
+    key buffer), spk_last_error and the three tuner-cache parsers (valid, truncated, garbage and over-long lines).
+    Without a GPU every HIP call fails and the error paths run; a sanitizer report aborts the driver (exit != 0)."""
+    import os
+    import subprocess
+    csrc = ROOT / "syke-pic_amd" / "csrc"
+    exe = csrc / "build" / "asan" / "asan_driver"
+    srcs = list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))
+    if not exe.is_file() or any(f.stat().st_mtime > exe.stat().st_mtime for f in srcs):
+        subprocess.run(["bash", str(csrc / "build.sh"), "asan"], check=True, timeout=1500)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("SPK_TUNE_CACHE", None)
+    r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "asan_driver: ok" in r.stdout and "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
