@@ -61,17 +61,33 @@ def parse():
 
 # the sources the ResNet inference conv kernels (the roofline's dominant kernel) are built from, and the model code that
 # chooses their precision mode and tiles: the PMC traffic figure is re-taken when any of these changes
-TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_stem.hip", "spk_common.h", "model.hip", "model.h")
+# the sources the ResNet conv KERNELS are built from (not the executor: an EfficientNet / fp8 edit of model.hip no longer
+# stales the ResNet figure); tools/pmc_traffic.py carries the same list
+TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_pw.hip", "conv_c3.hip", "conv_stem.hip", "spk_common.h")
+CONV_KERNELS = "conv_pw_kernel + conv_c3_kernel + conv_igemm_kernel + conv_stem_kernel"
 
 
-def kernel_source_sha():
+def kernel_source_sha(sources=None):
     """sha256 over those sources: a committed PMC traffic figure is only quoted for the kernels it was taken on."""
     h = hashlib.sha256()
-    for name in TRAFFIC_SOURCES:
+    for name in sources or TRAFFIC_SOURCES:
         f = ROOT / "syke-pic_amd" / "csrc" / name
         h.update(name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
+
+
+def train_traffic(args):
+    """HBM bytes per conv launch of the training step from the committed PMC passes (tools/pmc_traffic.py train), quoted
+    only for the kernel sources it was taken on."""
+    cands = sorted((ROOT / "profiles").glob("r*_pmc_traffic_train_bf16.json"))
+    if not cands or args.batch != 256 or args.network != "resnet50" or args.size != 224:
+        return None
+    rec = json.loads(cands[-1].read_text())
+    return round(rec["traffic_bytes_per_launch"]) if rec.get("kernel_src_sha") == kernel_source_sha(TRAIN_SOURCES) else None
+
+
+TRAIN_SOURCES = ("conv_igemm.hip", "conv_wgrad.hip", "conv_stem.hip", "spk_common.h")
 
 
 def cpu_model():
@@ -214,7 +230,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd, dgrad) + conv_wgrad_kernel",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": train_traffic(args),
                 "launches": int(sum(l for n_, _, fl, l in phases if fl > 0)),
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
                 "phases_ms": {n_: round(ms, 3) for n_, ms, _, _ in phases}}
@@ -228,7 +244,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
         conv_fl = sum(fl for _, _, fl, _ in conv)
         all_ms = sum(ms for _, ms, _, _ in layers)
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": round(achieved, 2),
+        roof = {"bound": "mfma", "kernel": CONV_KERNELS, "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "traffic": None,
                 "launches": len(conv), "avg_launch_us": round(conv_ms * 1e3 / len(conv), 2),
