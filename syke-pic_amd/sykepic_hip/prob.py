@@ -85,16 +85,24 @@ class ProbRows:
 
 
 class PendingRows:
-    """Rows whose probabilities are still being computed: ROI numbers on the host, one device tensor per batch.
-    `result()` is the only point that waits for the GPU (one device->host copy)."""
+    """Rows whose probabilities are still being computed: ROI numbers on the host, the probabilities on their way
+    into one pinned host buffer (queued behind the sample's last batch, before anything of the next sample).
+    `result()` is the only point that waits, and only for that copy's event - callable from another thread."""
 
     def __init__(self, nums, outs):
-        self.nums, self.outs = nums, outs
+        self.nums, self.host, self.event = nums, None, None
+        if outs:
+            dev = torch.cat(outs)
+            self.host = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+            self.host.copy_(dev, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
 
     def result(self):
-        if not self.outs:
+        if self.host is None:
             return ProbRows(np.zeros(0, np.int64), np.zeros((0, 0), np.float32))
-        return ProbRows(np.concatenate(self.nums), torch.cat(self.outs).cpu().numpy()).sorted()
+        self.event.synchronize()
+        return ProbRows(np.concatenate(self.nums), self.host.numpy()).sorted()
 
 
 def net_pass_launch(net, batches, device="cuda:0"):
@@ -319,10 +327,17 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
     it = sample_paths
     if progress_bar and tqdm:
         it = tqdm(it, desc="Processing samples")
-    # Two samples in flight: while the GPU runs sample k+1 the host reads back, formats and writes sample k (the
-    # reference handles one sample at a time, probability.py:97-114; same files, same per-sample error handling).
+    # Two samples in flight: while the GPU runs sample k+1 the previous sample is read back, formatted and written
+    # (the reference handles one sample at a time, probability.py:97-114; same files, same per-sample error
+    # handling).  Single process: the second half runs on a writer thread (device->host copy, numpy formatting and
+    # file I/O all release the GIL), so the main thread goes straight on to parse and launch the next sample.  Under
+    # torch.distributed the second half holds collectives (all_ok / gather) and stays on the main thread, in order.
     done = set()
-    pending = None          # (sample path, state of launch_sample)
+    pending = None          # (sample path, state of launch_sample) or a Future of the writer thread
+    pool = None
+    if dist is None:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sykepic-csv")
 
     def guarded(fn, sample_path):
         try:
@@ -333,22 +348,29 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
             log.exception(f"Unexpected error for {Path(sample_path).name}")
         return None
 
+    def complete(p):
+        return guarded(lambda: complete_sample(p[1], params, dist), p[0])
+
     def finish(p):
         if p is None:
             return
-        name = guarded(lambda: complete_sample(p[1], params, dist), p[0])
+        name = p.result() if pool is not None else complete(p)
         if name is not None:
             done.add(name)
 
-    for sample_path in it:
-        state = guarded(lambda: launch_sample(sample_path, net, params, out_dir, force, dist) or "skip", sample_path)
+    try:
+        for sample_path in it:
+            state = guarded(lambda: launch_sample(sample_path, net, params, out_dir, force, dist) or "skip", sample_path)
+            finish(pending)
+            pending = None
+            if state == "skip":
+                done.add(Path(sample_path).name)
+            elif state is not None:
+                pending = pool.submit(complete, (sample_path, state)) if pool is not None else (sample_path, state)
         finish(pending)
-        pending = None
-        if state == "skip":
-            done.add(Path(sample_path).name)
-        elif state is not None:
-            pending = (sample_path, state)
-    finish(pending)
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
     return done
 
 

@@ -210,9 +210,11 @@ def test_traffic_provenance_digest_is_shared():
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
         mods.append(mod)
-    assert mods[0].TRAFFIC_SOURCES == mods[1].TRAFFIC_SOURCES
-    assert mods[0].kernel_source_sha() == mods[1].kernel_source_sha()
-    for f in mods[0].TRAFFIC_SOURCES:
+    bench, pmc = mods
+    assert bench.TRAFFIC_SOURCES == pmc.SOURCES["infer"] and bench.TRAIN_SOURCES == pmc.SOURCES["train"]
+    assert bench.kernel_source_sha() == pmc.kernel_source_sha("infer")
+    assert bench.kernel_source_sha(bench.TRAIN_SOURCES) == pmc.kernel_source_sha("train")
+    for f in bench.TRAFFIC_SOURCES + bench.TRAIN_SOURCES:
         assert (root / "syke-pic_amd" / "csrc" / f).is_file()
 
 
