@@ -86,25 +86,40 @@ def run_train_bf16(graph, state, x, eps=1e-5):
     return acts
 
 
-def run_train_forced(graph, state, x, forced, eps=1e-5):
+def _act(v, op):
+    a = int(op.relu)
+    return F.silu(v) if a == arch.ACT_SILU else (F.relu(v) if a else v)
+
+
+def run_train_forced(graph, state, x, forced, eps=1e-5, row_scale=None):
     """Train-mode forward in which every activation is overwritten (straight
     through) with the value the GPU produced (`forced[id]`).  Each layer's
     local derivative is then evaluated at exactly the GPU's operating point —
     same ReLU masks, same BatchNorm statistics — so autograd through this
-    graph isolates the backward kernels from forward rounding chaos."""
+    graph isolates the backward kernels from forward rounding chaos.
+    EfficientNet graphs (torchvision MBConv: depthwise conv, squeeze-excitation, SiLU) are covered too;
+    `row_scale[dst]` is the per-image StochasticDepth factor (0 or 1/(1-p), "row" mode) of the block that writes
+    tensor `dst`, as drawn by the implementation under test (None: no row dropped)."""
     def force(v, t):
         return v + (forced[t].to(v.dtype) - v).detach() if t in forced else v
 
     acts = {0: _bf16_st(x)}
     for op in graph.ops:
         a = acts[op.src]
-        if op.kind == arch.OP_CONV:
-            y32 = F.conv2d(a, _bf16_st(state[op.name + ".weight"]), None, op.stride, op.pad)
+        if op.kind in (arch.OP_CONV, arch.OP_DWCONV):
+            groups = op.cin if op.kind == arch.OP_DWCONV else 1
+            y32 = F.conv2d(a, _bf16_st(state[op.name + ".weight"]), None, op.stride, op.pad, groups=groups)
             v = F.batch_norm(y32, None, None, state[op.bn + ".weight"], state[op.bn + ".bias"], True, 0.1, eps)
             if op.res >= 0:
+                if row_scale is not None and op.dst in row_scale:
+                    v = v * row_scale[op.dst].view(-1, 1, 1, 1)
                 v = v + acts[op.res]
-            if op.relu:
-                v = F.relu(v)
+            v = _act(v, op)
+        elif op.kind == arch.OP_SE:
+            s = a.mean((2, 3), keepdim=True)
+            s = F.silu(F.conv2d(s, state[op.name + ".fc1.weight"], state[op.name + ".fc1.bias"]))
+            s = torch.sigmoid(F.conv2d(s, state[op.name + ".fc2.weight"], state[op.name + ".fc2.bias"]))
+            v = a * s
         elif op.kind == arch.OP_MAXPOOL:
             v = F.max_pool2d(a, op.k, op.stride, op.pad)
         elif op.kind == arch.OP_GAVGPOOL:

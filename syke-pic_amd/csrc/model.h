@@ -72,7 +72,9 @@ struct spk_model {
   bf16_t* wpack = nullptr;     // bf16 conv weights, [Cout][K] per layer
   float* scale_bias = nullptr; // eval-BN folded scale/bias per conv
   float* dwpack = nullptr;     // fp32 tap-major weights of depthwise / 3x3-stem layers (EfficientNet)
-  bool eval_only = false;      // graph has ops without a training path (EfficientNet)
+  bool effnet = false;         // EfficientNet graph (widths that are not multiples of 64, depthwise / SE / SiLU ops): its
+                               // TRAINING plan pads every activation tensor to a multiple of 64 channels (train_effnet.hip)
+  bool plan_pad = false;       // the current activation plan is the channel-padded one
   size_t se_off = 0;           // arena offset of the squeeze-excitation scratch (partials + scales)
   bool dirty = true;
   int infer_dt = DT_F16;       // 16-bit storage type of the eval path
@@ -135,7 +137,7 @@ struct spk_model {
 
 void spk_set_error(const std::string& s);
 int spk_commit(spk_model* m);
-int spk_plan(spk_model* m, int n, int h, int w);
+int spk_plan(spk_model* m, int n, int h, int w, bool pad = false);
 int spk_run_layer_eval(spk_model* m, Layer& L, int nb);
 int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype,
                             float* logits_dev);

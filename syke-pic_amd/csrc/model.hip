@@ -120,17 +120,17 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       if (stem) L.cin_p = 4;
       L.mode = stem7 ? CONV_MODE_STEM : (stem3 ? CONV_MODE_STEM3 : CONV_MODE_GENERIC);
       L.kpad = stem7 ? 256 : L.d.k * L.d.k * L.cin_p;
-      if (stem3 || (!stem && L.cin_p != L.d.cin) || L.cout_p != L.d.cout || L.d.relu == SPK_ACT_SILU) m->eval_only = true;
+      if (stem3 || (!stem && L.cin_p != L.d.cin) || L.cout_p != L.d.cout || L.d.relu == SPK_ACT_SILU) m->effnet = true;
     } else if (L.d.kind == SPK_OP_DWCONV) {
       if ((L.d.k != 3 && L.d.k != 5) || L.d.cin != L.d.cout || L.d.pad != (L.d.k - 1) / 2) {
         delete m; return fail(SPK_ERR_UNSUPPORTED, "depthwise conv: k 3 or 5, pad (k-1)/2");
       }
-      m->eval_only = true;
+      m->effnet = true;
     } else if (L.d.kind == SPK_OP_SE) {
       if (L.d.cin != L.d.cout || L.d.k < 1 || L.d.k > 1024) {
         delete m; return fail(SPK_ERR_UNSUPPORTED, "squeeze-excitation: cin == cout, 1 <= squeeze <= 1024");
       }
-      m->eval_only = true;
+      m->effnet = true;
     }
   }
   // Layers whose rounding errors enter the residual trunk undamped: the stem,
@@ -539,7 +539,7 @@ static void assign_fp8_roles(spk_model* m) {
 
 extern "C" int spk_model_set_fp8(spk_model* m, int on) {
   if (!m) return fail(SPK_ERR_ARG, "null model");
-  if (on && !m->eval_only) return fail(SPK_ERR_UNSUPPORTED, "the fp8 mode covers the EfficientNet MBConv blocks only");
+  if (on && !m->effnet) return fail(SPK_ERR_UNSUPPORTED, "the fp8 mode covers the EfficientNet MBConv blocks only");
   m->fp8 = on ? 1 : 0;
   return SPK_OK;
 }
@@ -558,7 +558,7 @@ static int fp8_amax(spk_model* m, int t, int nb, unsigned int* dev_word, float* 
 
 extern "C" int spk_model_calibrate_fp8(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype) {
   if (!m || !x || n <= 0) return fail(SPK_ERR_ARG, "calibrate_fp8: bad arguments");
-  if (!m->eval_only) return fail(SPK_ERR_UNSUPPORTED, "the fp8 mode covers the EfficientNet MBConv blocks only");
+  if (!m->effnet) return fail(SPK_ERR_UNSUPPORTED, "the fp8 mode covers the EfficientNet MBConv blocks only");
   if (m->infer_dt != DT_F16) return fail(SPK_ERR_STATE, "calibrate_fp8 needs the fp16 eval path");
   HIP_TRY(hipSetDevice(m->device));
   SPK_TRY(spk_plan(m, n, h, w));
@@ -627,8 +627,10 @@ static int fp8_pack(spk_model* m) {
 // ---------------------------------------------------------------------------
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int spk_plan(spk_model* m, int n, int h, int w) {
-  if (n <= m->cap_n && h == m->cap_h && w == m->cap_w) return SPK_OK;
+int spk_plan(spk_model* m, int n, int h, int w, bool pad) {
+  // pad: the training layout of the EfficientNet graphs (channels of every conv output rounded up to 64, zeros in the
+  // pad); the eval kernels work on the tensors' own widths, so switching between the two re-plans
+  if (n <= m->cap_n && h == m->cap_h && w == m->cap_w && pad == m->plan_pad) return SPK_OK;
   HIP_TRY(hipStreamSynchronize(m->stream));
   free_acts(m);
   m->tdims.assign(m->n_tensors, TDim());
@@ -644,11 +646,11 @@ int spk_plan(spk_model* m, int n, int h, int w) {
         const int ih = in.h, iw = (L.d.src == 0) ? w : in.w;
         o.h = (ih + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
         o.w = (iw + 2 * L.d.pad - L.d.k) / L.d.stride + 1;
-        o.c = L.d.cout;
+        o.c = pad ? (L.d.cout + 63) / 64 * 64 : L.d.cout;
         o.c_log = L.d.cout;
         o.bf16 = true;
         if (o.h < 1 || o.w < 1) return fail(SPK_ERR_ARG, "image too small for the network");
-        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && in.c != L.d.cin)
+        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && (in.c_log > 0 ? in.c_log : in.c) != L.d.cin)
           return fail(SPK_ERR_ARG, std::string("channel mismatch at ") + L.d.name);
         break;
       }
@@ -699,6 +701,7 @@ int spk_plan(spk_model* m, int n, int h, int w) {
   HIP_TRY(hipMalloc((void**)&m->arena, total));
   m->arena_bytes = total;
   m->cap_n = n;
+  m->plan_pad = pad;
   m->cap_h = h;
   m->cap_w = w;
   // 32-bit buffer offsets inside the conv kernel: keep every activation of a

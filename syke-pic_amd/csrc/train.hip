@@ -7,6 +7,7 @@
 // stem's BatchNorm, weight gradients only where requires_grad is set
 // (sykepic/train/network.py:133-172).
 #include "model.h"
+#include "train_effnet.h"
 
 #include <algorithm>
 #include <cmath>
@@ -37,6 +38,9 @@ struct ConvTrain {
   size_t stat_off = 0;      // floats: mean[C], invstd[C], scale[C], shift[C]
   size_t wfwd_off = 0;      // bf16 [Cout][K] forward image
   size_t wdg_off = 0;       // bf16 [Cin][taps][Cout] dgrad image
+  size_t dwt_off = 0;       // depthwise conv: fp32 tap-major weights [taps][C] (floats into TrainState::dwt)
+  size_t se_off = 0;        // squeeze-excitation: pooled [n][C], u1 [n][S], h1 [n][S], gate [n][C] floats kept for backward
+  size_t rs_off = 0;        // stochastic depth: per-image factor [n] floats (0: none)
 };
 
 struct PhaseProf {
@@ -60,6 +64,7 @@ struct TrainState {
   float* m2 = nullptr;     // Adam exp_avg_sq [n_train]
   bf16_t* wpack = nullptr; // bf16 forward + dgrad weight images
   float* stats = nullptr;  // per-conv mean/invstd/scale/shift
+  float* dwt = nullptr;    // depthwise weights, tap-major (EfficientNet)
   std::vector<ConvTrain> conv;  // indexed by layer
   bool weights_dirty = true;
   bool sgd_started = false;
@@ -70,6 +75,7 @@ struct TrainState {
   int cap_n = 0, cap_h = 0, cap_w = 0;
   std::vector<size_t> goff;   // gradient tensor per activation id
   size_t dy_off = 0, idx_off = 0, part_off = 0, coef_off = 0, slab_off = 0, tmp_off = 0;
+  size_t se_tmp_off = 0;   // squeeze-excitation scratch shared by the layers (pool partials, gate / hidden gradients)
   size_t part_floats = 0, slab_floats = 0;
 
   void* G(int t) const { return (char*)arena + goff[t]; }
@@ -86,6 +92,7 @@ void spk_train_free(spk_model* m) {
   if (t->m2) hipFree(t->m2);
   if (t->wpack) hipFree(t->wpack);
   if (t->stats) hipFree(t->stats);
+  if (t->dwt) hipFree(t->dwt);
   delete t;
   m->train = nullptr;
 }
@@ -107,9 +114,6 @@ static void mark(spk_model* m, int phase) {
 }
 
 static int ensure_state(spk_model* m) {
-  if (m->eval_only)
-    return tfail(SPK_ERR_UNSUPPORTED,
-                 "this network (EfficientNet: depthwise / squeeze-excitation / SiLU layers) has an inference path only");
   if (m->train) return SPK_OK;
   TrainState* t = new TrainState();
   m->train = t;
@@ -121,20 +125,30 @@ static int ensure_state(spk_model* m) {
   HIP_TRY(hipMemset(t->m1, 0, nb));
   HIP_TRY(hipMemset(t->m2, 0, nb));
   t->conv.resize(m->layers.size());
-  size_t w = 0, st = 0;
+  // channel counts as the training plan lays them out: cout_p / cin_p (= the layer's own for the ResNets, whose widths
+  // are multiples of 64; rounded up to 64 for the EfficientNets)
+  size_t w = 0, st = 0, dw = 0;
   for (size_t i = 0; i < m->layers.size(); ++i) {
     const Layer& L = m->layers[i];
-    if (L.d.kind != SPK_OP_CONV) continue;
     ConvTrain& c = t->conv[i];
+    if (L.d.kind == SPK_OP_DWCONV) {
+      c.stat_off = st;
+      st += (size_t)4 * L.cout_p;
+      c.dwt_off = dw;
+      dw += (size_t)L.d.k * L.d.k * L.cout_p;
+      continue;
+    }
+    if (L.d.kind != SPK_OP_CONV) continue;
     c.wfwd_off = w;
-    w += (size_t)L.d.cout * L.kpad;
+    w += (size_t)L.cout_p * L.kpad;
     c.wdg_off = w;
-    if (L.mode != CONV_MODE_STEM) w += (size_t)L.d.cin * L.d.k * L.d.k * L.d.cout;
+    if (L.mode == CONV_MODE_GENERIC) w += (size_t)L.cin_p * L.d.k * L.d.k * L.cout_p;
     c.stat_off = st;
-    st += (size_t)4 * L.d.cout;
+    st += (size_t)4 * L.cout_p;
   }
   HIP_TRY(hipMalloc((void**)&t->wpack, std::max<size_t>(w, 8) * 2));
   HIP_TRY(hipMalloc((void**)&t->stats, std::max<size_t>(st, 8) * 4));
+  HIP_TRY(hipMalloc((void**)&t->dwt, std::max<size_t>(dw, 8) * 4));
   return SPK_OK;
 }
 
@@ -142,12 +156,12 @@ static int ensure_state(spk_model* m) {
 // lives in the training arena
 static int plan_train(spk_model* m, int n, int h, int w) {
   TrainState* t = m->train;
-  SPK_TRY(spk_plan(m, n, h, w));
+  SPK_TRY(spk_plan(m, n, h, w, m->effnet));
   if (n <= t->cap_n && h == t->cap_h && w == t->cap_w) return SPK_OK;
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (t->arena) hipFree(t->arena);
   t->arena = nullptr;
-  size_t total = 0, max_conv = 0, max_slab = 0, max_part = 0, max_c = 0;
+  size_t total = 0, max_conv = 0, max_slab = 0, max_part = 0, max_c = 0, max_se = 0;
   t->goff.assign(m->n_tensors, 0);
   for (int id = 0; id < m->n_tensors; ++id) {
     const TDim& d = m->tdims[id];
@@ -159,24 +173,43 @@ static int plan_train(spk_model* m, int n, int h, int w) {
   }
   for (size_t i = 0; i < m->layers.size(); ++i) {
     const Layer& L = m->layers[i];
+    const TDim& in = m->tdims[L.d.src];
     const TDim& o = m->tdims[L.d.dst];
-    if (L.d.kind == SPK_OP_CONV) {
-      const size_t bytes = (size_t)n * o.h * o.w * o.c * 2;
+    if (L.d.kind == SPK_OP_CONV || L.d.kind == SPK_OP_DWCONV) {
+      const int C = o.c;   // channels as laid out
+      const size_t bytes = (size_t)n * o.h * o.w * C * 2;
       t->conv[i].raw_off = total;
       total += al256(bytes);
       t->conv[i].mask_off = total;
       total += al256(bytes / 16);
       max_conv = std::max(max_conv, bytes);
       const int M = n * o.h * o.w;
-      int sp, pps;
-      const int ktot = L.mode == CONV_MODE_STEM ? 256 : L.d.k * L.d.k * L.d.cin;
-      spk_wgrad_plan(M, L.d.cout, ktot, &sp, &pps);
-      max_slab = std::max(max_slab, (size_t)sp * L.d.cout * ktot);
+      if (L.d.kind == SPK_OP_DWCONV) {
+        max_slab = std::max(max_slab, (size_t)spk_dw_wgrad_rows(M, C) * L.d.cout * L.d.k * L.d.k);
+      } else if (L.mode == CONV_MODE_STEM3) {
+        int ppb;
+        max_slab = std::max(max_slab, (size_t)spk_stem3_wgrad_blocks(M, &ppb) * L.d.cout * 9 * L.d.cin);
+      } else {
+        int sp, pps;
+        const int ktot = L.mode == CONV_MODE_STEM ? 256 : L.d.k * L.d.k * in.c;
+        spk_wgrad_plan(M, C, ktot, &sp, &pps);
+        max_slab = std::max(max_slab, (size_t)sp * C * ktot);
+      }
       int rpb;
-      const int nb = spk_bn_bwd_blocks(M, L.d.cout, &rpb);
-      const size_t fwd_part = (size_t)((M + 60) / 61) * 2 * L.d.cout;  // sized for M tiles of 61 rows (the smallest tile any forward kernel has used; today 64)
-      max_part = std::max(max_part, std::max((size_t)nb * 2 * L.d.cout, fwd_part));
-      max_c = std::max(max_c, (size_t)L.d.cout);
+      const int nb = spk_bn_bwd_blocks(M, C, &rpb);
+      const size_t fwd_part = (size_t)((M + 60) / 61) * 2 * C;  // sized for M tiles of 61 rows (the smallest tile any forward kernel has used; today 64)
+      max_part = std::max(max_part, std::max((size_t)nb * 2 * C, fwd_part));
+      max_c = std::max(max_c, (size_t)C);
+      if (L.d.kind == SPK_OP_CONV && L.d.res >= 0 && L.d.p > 0.f) {   // stochastic depth on the residual branch
+        t->conv[i].rs_off = total;
+        total += al256((size_t)n * 4);
+      }
+    } else if (L.d.kind == SPK_OP_SE) {
+      const size_t fl = (size_t)n * (2 * o.c + 2 * L.d.k);
+      t->conv[i].se_off = total;
+      total += al256(fl * 4);
+      // shared scratch: pool partials [n][chunks][C], dgate / du2 / dpool [n][C] each, dh1 / du1 [n][S] each
+      max_se = std::max(max_se, (size_t)n * ((size_t)(spk_se_chunks(o.h * o.w) + 3) * o.c + 2 * L.d.k));
     } else if (L.d.kind == SPK_OP_MAXPOOL) {
       t->idx_off = total;
       total += al256((size_t)n * o.h * o.w * o.c);
@@ -190,9 +223,17 @@ static int plan_train(spk_model* m, int n, int h, int w) {
   t->coef_off = total;    total += al256(max_c * 3 * 4);
   t->tmp_off = total;     total += al256(max_c * 2 * 64 * 4);
   t->slab_off = total;    total += al256(max_slab * 4);
+  t->se_tmp_off = total;  total += al256(max_se * 4);
   t->part_floats = max_part;
   t->slab_floats = max_slab;
   HIP_TRY(hipMalloc(&t->arena, total));
+  if (max_se) HIP_TRY(hipMemsetAsync((char*)t->arena + t->se_tmp_off, 0, al256(max_se * 4), m->stream));
+  for (size_t i = 0; i < m->layers.size(); ++i)   // pad columns of the gate pre-activations stay zero for good
+    if (m->layers[i].d.kind == SPK_OP_SE) {
+      const TDim& o = m->tdims[m->layers[i].d.dst];
+      HIP_TRY(hipMemsetAsync((char*)t->arena + t->conv[i].se_off, 0, (size_t)n * (2 * o.c + 2 * m->layers[i].d.k) * 4,
+                             m->stream));
+    }
   t->cap_n = n; t->cap_h = h; t->cap_w = w;
   return SPK_OK;
 }
@@ -211,7 +252,19 @@ static int repack_weights(spk_model* m) {
   };
   for (size_t i = 0; i < m->layers.size(); ++i) {
     const Layer& L = m->layers[i];
-    if (L.d.kind != SPK_OP_CONV) continue;
+    if (L.d.kind == SPK_OP_DWCONV) {
+      K_TRY(spk_launch_dw_pack(m->P(L.p_w), t->dwt + t->conv[i].dwt_off, L.d.cout, L.cout_p, L.d.k * L.d.k, m->stream),
+            "dw_pack");
+      continue;
+    }
+    if (L.d.kind != SPK_OP_CONV || L.mode == CONV_MODE_STEM3) continue;   // the 3x3 stem reads the master weights
+    if (m->effnet) {   // channel-padded GEMM images, zeros outside the layer's own widths
+      for (int kind = 0; kind < 2; ++kind)
+        K_TRY(spk_launch_pack_train_padded(m->P(L.p_w), t->wpack + (kind ? t->conv[i].wdg_off : t->conv[i].wfwd_off),
+                                           L.d.cout, L.d.k * L.d.k, L.d.cin, L.cout_p, L.cin_p, kind, m->stream),
+              "pack_train_padded");
+      continue;
+    }
     if (L.mode == CONV_MODE_STEM) {
       K_TRY(spk_launch_pack_weights(m->P(L.p_w), t->wpack + t->conv[i].wfwd_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
                                     L.mode, DT_BF16, 0, m->stream), "pack_weights");
@@ -330,9 +383,6 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   if (!m || !x || !y || !stats || n < 1) return tfail(SPK_ERR_ARG, "train step: bad arguments");
   if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return tfail(SPK_ERR_ARG, "train step: dtype must be f32 or u8");
   HIP_TRY(hipSetDevice(m->device));
-  if (m->eval_only)
-    return tfail(SPK_ERR_UNSUPPORTED,
-                 "this network (EfficientNet: depthwise / squeeze-excitation / SiLU layers) has an inference path only");
   SPK_TRY(ensure_state(m));
   SPK_TRY(plan_train(m, n, h, w));
   SPK_TRY(repack_weights(m));
@@ -342,7 +392,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   // last batch of ONE image whose feature map has shrunk to 1x1); a batch of one larger image trains, as in torch
   for (const Layer& L : m->layers) {
     const TDim& o = m->tdims[L.d.dst];
-    if (L.d.kind == SPK_OP_CONV && (long)n * o.h * o.w < 2)
+    if ((L.d.kind == SPK_OP_CONV || L.d.kind == SPK_OP_DWCONV) && (long)n * o.h * o.w < 2)
       return tfail(SPK_ERR_ARG, std::string("Expected more than 1 value per channel when training, got input size [") +
                                     std::to_string(n) + ", " + std::to_string(L.d.cout) + ", " + std::to_string(o.h) +
                                     ", " + std::to_string(o.w) + "] at " + L.d.bn);
@@ -366,22 +416,78 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
     const TDim& o = m->tdims[L.d.dst];
     switch (L.d.kind) {
       case SPK_OP_CONV: {
-        ConvArgs a;
-        fill_conv(a, (const bf16_t*)m->T(L.d.src), t->wpack + t->conv[i].wfwd_off, t->RAW(i), n, in.h, in.w,
-                  in.c, o.h, o.w, L.d.cout, L.d.k, L.d.stride, L.d.pad, L.kpad);
-        a.stats = part;
-        int m_tiles = 0;
-        K_TRY(spk_conv_launch(a, L.mode, s, &m_tiles), "conv");
-        mark(m, PH_CONV_FWD);
+        const int C = o.c;   // channels as laid out (= cout for the ResNets)
+        const int M = n * o.h * o.w;
         float* st = t->stats + t->conv[i].stat_off;
-        const int C = L.d.cout;
-        K_TRY(spk_launch_bn_finalize(part, m_tiles, C, (double)a.M, m->P(L.p_g), m->P(L.p_b),
-                                     m->P(L.p_mean), m->P(L.p_var), st, st + C, st + 2 * C, st + 3 * C,
-                                     1e-5f, 0.1f, tmp, s), "bn_finalize");
+        int m_tiles = 0;
+        if (L.mode == CONV_MODE_STEM3) {
+          K_TRY(spk_launch_stem3_train_fwd((const bf16_t*)m->T(0), m->P(L.p_w), t->RAW(i), n, in.h, w, in.w, L.d.cin,
+                                           L.d.cout, C, o.h, o.w, s), "stem3 fwd");
+          K_TRY(spk_launch_col_stats(t->RAW(i), part, M, C, &m_tiles, s), "col_stats");
+        } else {
+          ConvArgs a;
+          fill_conv(a, (const bf16_t*)m->T(L.d.src), t->wpack + t->conv[i].wfwd_off, t->RAW(i), n, in.h, in.w,
+                    in.c, o.h, o.w, C, L.d.k, L.d.stride, L.d.pad, L.kpad);
+          a.stats = part;
+          K_TRY(spk_conv_launch(a, L.mode, s, &m_tiles), "conv");
+        }
+        mark(m, PH_CONV_FWD);
         L.nbt += 1;
-        K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
-                                  L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
-                                  (bf16_t*)m->T(L.d.dst), t->MASK(i), (size_t)a.M * C, C, L.d.relu, s), "bn_apply");
+        if (!m->effnet) {
+          K_TRY(spk_launch_bn_finalize(part, m_tiles, C, (double)M, m->P(L.p_g), m->P(L.p_b),
+                                       m->P(L.p_mean), m->P(L.p_var), st, st + C, st + 2 * C, st + 3 * C,
+                                       1e-5f, 0.1f, tmp, s), "bn_finalize");
+          K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
+                                    L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
+                                    (bf16_t*)m->T(L.d.dst), t->MASK(i), (size_t)M * C, C, L.d.relu, s), "bn_apply");
+        } else {
+          K_TRY(spk_launch_bna_finalize(part, m_tiles, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
+                                        m->P(L.p_var), st, 1e-5f, 0.1f, s), "bn_finalize");
+          float* rs = nullptr;
+          if (t->conv[i].rs_off) {   // StochasticDepth(p, "row") on the residual branch, train mode
+            rs = (float*)((char*)t->arena + t->conv[i].rs_off);
+            K_TRY(spk_launch_sd_rowscale(rs, n, L.d.p,
+                                         (m->seed * 0x100000001B3ull) ^ (t->steps << 12) ^ (unsigned long long)i, s),
+                  "stochastic depth");
+          }
+          K_TRY(spk_launch_bna_apply(t->RAW(i), st + 2 * C, st + 3 * C,
+                                     L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr, rs, (bf16_t*)m->T(L.d.dst), M,
+                                     C, o.h * o.w, L.d.relu, s), "bn_apply");
+        }
+        mark(m, PH_BN_FWD);
+        break;
+      }
+      case SPK_OP_DWCONV: {
+        const int C = o.c, M = n * o.h * o.w;
+        float* st = t->stats + t->conv[i].stat_off;
+        int nbk = 0;
+        K_TRY(spk_launch_dw_train_fwd((const bf16_t*)m->T(L.d.src), t->dwt + t->conv[i].dwt_off, t->RAW(i), n, in.h, in.w,
+                                      C, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s), "depthwise fwd");
+        K_TRY(spk_launch_col_stats(t->RAW(i), part, M, C, &nbk, s), "col_stats");
+        mark(m, PH_CONV_FWD);
+        L.nbt += 1;
+        K_TRY(spk_launch_bna_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
+                                      m->P(L.p_var), st, 1e-5f, 0.1f, s), "bn_finalize");
+        K_TRY(spk_launch_bna_apply(t->RAW(i), st + 2 * C, st + 3 * C, nullptr, nullptr, (bf16_t*)m->T(L.d.dst), M, C,
+                                   o.h * o.w, L.d.relu, s), "bn_apply");
+        mark(m, PH_BN_FWD);
+        break;
+      }
+      case SPK_OP_SE: {
+        // s = sigmoid(fc2(silu(fc1(mean_hw(a))))), out = a * s; fp32 on the [n][C] vectors
+        const int C = o.c, Cl = L.d.cout, S = L.d.k, HW = o.h * o.w;
+        float* pooled = (float*)((char*)t->arena + t->conv[i].se_off);
+        float* u1 = pooled + (size_t)n * C;
+        float* h1 = u1 + (size_t)n * S;
+        float* gate = h1 + (size_t)n * S;
+        float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
+        const bf16_t* a = (const bf16_t*)m->T(L.d.src);
+        K_TRY(spk_launch_pool_rows(a, nullptr, scratch, pooled, n, HW, C, 1.f / (float)HW, s), "se pool");
+        K_TRY(spk_launch_sgemm(pooled, C, 1, m->P(L.p_w), Cl, 1, m->P(L.p_b), u1, S, 1, n, S, Cl, 1.f, 0, s), "se fc1");
+        K_TRY(spk_launch_ew(SPK_EW_SILU, u1, nullptr, h1, (size_t)n * S, s), "se silu");
+        K_TRY(spk_launch_sgemm(h1, S, 1, m->P(L.p_w2), S, 1, m->P(L.p_b2), gate, C, 1, n, Cl, S, 1.f, 0, s), "se fc2");
+        K_TRY(spk_launch_ew(SPK_EW_SIGMOID, gate, nullptr, gate, (size_t)n * C, s), "se sigmoid");
+        K_TRY(spk_launch_se_scale(a, gate, (bf16_t*)m->T(L.d.dst), n, HW, C, s), "se scale");
         mark(m, PH_BN_FWD);
         break;
       }
@@ -437,7 +543,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   bool any_group = false;
   for (const Param& p : m->params) any_group |= p.trainable && p.group >= 0;
   auto trainable = [&](const Layer& Q) {
-    for (int pi : {Q.p_w, Q.p_g, Q.p_b})
+    for (int pi : {Q.p_w, Q.p_g, Q.p_b, Q.p_w2, Q.p_b2})
       if (pi >= 0 && m->params[pi].requires_grad && (!any_group || m->params[pi].group >= 0)) return true;
     return false;
   };
@@ -489,35 +595,117 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         mark(m, PH_POOL_BWD);
         has_grad[L.d.src] = 1;
         break;
-      case SPK_OP_CONV: {
-        const int C = L.d.cout, M = n * o.h * o.w;
+      case SPK_OP_CONV:
+      case SPK_OP_DWCONV: {
+        const int C = o.c, M = n * o.h * o.w;   // C: channels as laid out
         float* st = t->stats + t->conv[i].stat_off;
         const Param& pg = m->params[L.p_g];
         const Param& pb = m->params[L.p_b];
         bf16_t* g_res = L.d.res >= 0 && needs[L.d.res] ? (bf16_t*)t->G(L.d.res) : nullptr;
-        K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st,
-                                st + C, m->P(L.p_g), part, coef,
-                                pg.requires_grad ? t->gbuf + pg.off : nullptr,
-                                pb.requires_grad ? t->gbuf + pb.off : nullptr, dy, g_res,
-                                g_res ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
+        float* dgam = pg.requires_grad ? t->gbuf + pg.off : nullptr;
+        float* dbet = pb.requires_grad ? t->gbuf + pb.off : nullptr;
+        if (!m->effnet) {
+          K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st, st + C, m->P(L.p_g), part, coef,
+                                  dgam, dbet, dy, g_res, g_res ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
+        } else {
+          const float* rs = t->conv[i].rs_off ? (const float*)((char*)t->arena + t->conv[i].rs_off) : nullptr;
+          const bf16_t* g = (const bf16_t*)t->G(L.d.dst);
+          int nbk = 0;
+          K_TRY(spk_launch_bna_bwd_reduce(g, t->RAW(i), st + 2 * C, st + 3 * C, st, st + C, rs, part, M, C, o.h * o.w,
+                                          L.d.relu, &nbk, s), "bn bwd reduce");
+          K_TRY(spk_launch_bna_bwd_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), st + C, dgam, dbet, coef, s),
+                "bn bwd finalize");
+          K_TRY(spk_launch_bna_bwd_apply(g, t->RAW(i), st + 2 * C, st + 3 * C, st, st + C, coef, rs, dy, g_res,
+                                         g_res ? has_grad[L.d.res] : 0, M, C, o.h * o.w, L.d.relu, s), "bn bwd apply");
+        }
         mark(m, PH_BN_BWD);
         if (g_res) has_grad[L.d.res] = 1;
+        const Param& pw = m->params[L.p_w];
+        if (L.d.kind == SPK_OP_DWCONV) {
+          const float* wt = t->dwt + t->conv[i].dwt_off;
+          if (needs[L.d.src]) {
+            K_TRY(spk_launch_dw_dgrad(dy, wt, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n, in.h, in.w, C, L.d.k,
+                                      L.d.stride, L.d.pad, o.h, o.w, s), "depthwise dgrad");
+            mark(m, PH_CONV_DGRAD);
+            has_grad[L.d.src] = 1;
+          }
+          if (pw.requires_grad) {
+            int rows = 0;
+            K_TRY(spk_launch_dw_wgrad((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, C, L.d.cout, L.d.k,
+                                      L.d.stride, L.d.pad, o.h, o.w, &rows, s), "depthwise wgrad");
+            mark(m, PH_CONV_WGRAD);
+            K_TRY(spk_launch_slab_reduce(slabs, t->gbuf + pw.off, (size_t)L.d.cout * L.d.k * L.d.k, rows, s),
+                  "depthwise wgrad reduce");
+            mark(m, PH_WGRAD_REDUCE);
+          }
+          break;
+        }
         if (L.d.src != 0 && needs[L.d.src]) {
           // data gradient: implicit GEMM over the dgrad weight image (stride 2: one launch per parity class)
           SPK_TRY(spk_conv_dgrad_all(dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n,
-                                     o.h, o.w, C, in.h, in.w, L.d.cin, L.d.k, L.d.stride, L.d.pad, s));
+                                     o.h, o.w, C, in.h, in.w, in.c, L.d.k, L.d.stride, L.d.pad, s));
           mark(m, PH_CONV_DGRAD);
           has_grad[L.d.src] = 1;
         }
-        if (m->params[L.p_w].requires_grad) {
+        if (pw.requires_grad) {
+          float* gw = t->gbuf + pw.off;
+          if (L.mode == CONV_MODE_STEM3) {
+            int nbk = 0;
+            K_TRY(spk_launch_stem3_wgrad((const bf16_t*)m->T(0), dy, slabs, n, in.h, w, in.w, L.d.cin, L.d.cout, C, o.h,
+                                         o.w, &nbk, s), "stem3 wgrad");
+            mark(m, PH_CONV_WGRAD);
+            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)L.d.cout * 9 * L.d.cin, nbk, s), "stem3 wgrad reduce");
+            mark(m, PH_WGRAD_REDUCE);
+            break;
+          }
           const bool stem = L.mode == CONV_MODE_STEM;
-          float* gw = t->gbuf + m->params[L.p_w].off;
-          SPK_TRY(spk_conv_wgrad_slabs((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, L.d.cin, o.h, o.w, C, L.d.k,
+          const int cin_t = stem ? L.d.cin : in.c;   // channels of the stored input tensor (the 7x7 stem reads NHWC4 itself)
+          SPK_TRY(spk_conv_wgrad_slabs((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, cin_t, o.h, o.w, C, L.d.k,
                                        L.d.stride, L.d.pad, stem, s));
           mark(m, PH_CONV_WGRAD);
-          SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, L.d.cin, C, L.d.k, stem, s));
+          if (!stem && (C != L.d.cout || cin_t != L.d.cin)) {   // padded GEMM: keep the layer's own rows / columns
+            int sp, pps;
+            spk_wgrad_plan(M, C, L.d.k * L.d.k * cin_t, &sp, &pps);
+            K_TRY(spk_launch_slab_reduce_sub(slabs, gw, L.d.cout, L.d.k * L.d.k, L.d.cin, C, cin_t, sp, s),
+                  "wgrad reduce (padded)");
+          } else {
+            SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, cin_t, C, L.d.k, stem, s));
+          }
           mark(m, PH_WGRAD_REDUCE);
         }
+        break;
+      }
+      case SPK_OP_SE: {
+        // out = a * s(pool(a)):  da = g * s + W1^T[ silu'(u1) * W2^T[ s(1-s) * sum_hw(g * a) ] ] / HW
+        const int C = o.c, Cl = L.d.cout, S = L.d.k, HW = o.h * o.w;
+        float* pooled = (float*)((char*)t->arena + t->conv[i].se_off);
+        float* u1 = pooled + (size_t)n * C;
+        float* h1 = u1 + (size_t)n * S;
+        float* gate = h1 + (size_t)n * S;
+        float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
+        float* dgate = scratch + (size_t)n * spk_se_chunks(HW) * C;   // becomes du2 in place
+        float* dpool = dgate + (size_t)n * C;
+        float* dh1 = dpool + (size_t)n * C;
+        float* du1 = dh1 + (size_t)n * S;
+        const bf16_t* g = (const bf16_t*)t->G(L.d.dst);
+        const bf16_t* a = (const bf16_t*)m->T(L.d.src);
+        K_TRY(spk_launch_pool_rows(g, a, scratch, dgate, n, HW, C, 1.f, s), "se dgate");
+        K_TRY(spk_launch_ew(SPK_EW_SIGMOID_BWD, dgate, gate, dgate, (size_t)n * C, s), "se sigmoid bwd");
+        const Param &w1 = m->params[L.p_w], &b1 = m->params[L.p_b], &w2 = m->params[L.p_w2], &b2 = m->params[L.p_b2];
+        if (w2.requires_grad)   // dW2[c][s] = sum_n du2[n][c] * h1[n][s]
+          K_TRY(spk_launch_sgemm(dgate, 1, C, h1, 1, S, nullptr, t->gbuf + w2.off, S, 1, Cl, S, n, 1.f, 0, s), "se fc2 wgrad");
+        if (b2.requires_grad) K_TRY(spk_launch_colsum_strided(dgate, t->gbuf + b2.off, n, Cl, C, s), "se fc2 bias grad");
+        // dh1[n][s] = sum_c du2[n][c] * W2[c][s]
+        K_TRY(spk_launch_sgemm(dgate, C, 1, m->P(L.p_w2), 1, S, nullptr, dh1, S, 1, n, S, Cl, 1.f, 0, s), "se fc2 dgrad");
+        K_TRY(spk_launch_ew(SPK_EW_SILU_BWD, dh1, u1, du1, (size_t)n * S, s), "se silu bwd");
+        if (w1.requires_grad)   // dW1[s][c] = sum_n du1[n][s] * pooled[n][c]
+          K_TRY(spk_launch_sgemm(du1, 1, S, pooled, 1, C, nullptr, t->gbuf + w1.off, Cl, 1, S, Cl, n, 1.f, 0, s), "se fc1 wgrad");
+        if (b1.requires_grad) K_TRY(spk_launch_colsum_strided(du1, t->gbuf + b1.off, n, S, S, s), "se fc1 bias grad");
+        // dpool[n][c] = sum_s du1[n][s] * W1[s][c]   (pad columns stay zero)
+        K_TRY(spk_launch_sgemm(du1, S, 1, m->P(L.p_w), 1, Cl, nullptr, dpool, C, 1, n, Cl, S, 1.f, 0, s), "se fc1 dgrad");
+        K_TRY(spk_launch_se_bwd_apply(g, gate, dpool, (bf16_t*)t->G(L.d.src), n, HW, C, s), "se bwd apply");
+        mark(m, PH_BN_BWD);
+        has_grad[L.d.src] = 1;
         break;
       }
     }
@@ -656,8 +844,9 @@ extern "C" int spk_model_read_activation_grad(spk_model* m, int t, int n, float*
   if (!m || !host || !m->train || !m->train->arena || t <= 0 || t >= m->n_tensors || n > m->train->cap_n)
     return tfail(SPK_ERR_ARG, "read_activation_grad: bad arguments or no training step has run");
   const TDim& d = m->tdims[t];
+  const int cl = d.c_log > 0 ? d.c_log : d.c;   // the caller sees the layer's own channels, not the padding
   const size_t cnt = (size_t)n * d.h * d.w * d.c;
-  if ((int64_t)cnt != numel) return tfail(SPK_ERR_ARG, "read_activation_grad: size mismatch");
+  if ((int64_t)((size_t)n * d.h * d.w * cl) != numel) return tfail(SPK_ERR_ARG, "read_activation_grad: size mismatch");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (!d.bf16) {
@@ -669,11 +858,11 @@ extern "C" int spk_model_read_activation_grad(spk_model* m, int t, int n, float*
   for (int i = 0; i < n; ++i)
     for (int y = 0; y < d.h; ++y)
       for (int x = 0; x < d.w; ++x)
-        for (int c = 0; c < d.c; ++c) {
+        for (int c = 0; c < cl; ++c) {
           const unsigned u = (unsigned)tmp[(((size_t)i * d.h + y) * d.w + x) * d.c + c] << 16;
           float f;
           memcpy(&f, &u, 4);
-          host[(((size_t)i * d.c + c) * d.h + y) * d.w + x] = f;
+          host[(((size_t)i * cl + c) * d.h + y) * d.w + x] = f;
         }
   return SPK_OK;
 }

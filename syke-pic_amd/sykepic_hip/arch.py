@@ -26,7 +26,7 @@ _RESNETS = {
 }
 
 
-# torchvision efficientnet_b0..b4: (width multiplier, depth multiplier); inference only on the MI355X path.
+# torchvision efficientnet_b0..b4: (width multiplier, depth multiplier).
 # (b5-b7 use BatchNorm eps 1e-3 and are not built.)
 _EFFNETS = {
     "efficientnet_b0": (1.0, 1.0),
@@ -67,7 +67,7 @@ class Op:
     res: int = -1         # residual activation id added before the ReLU
     child: int = -1       # index of the owning child of ``base`` (-1: head)
     last_bn: bool = False  # last BN of a residual block (synthetic init only)
-    p: float = 0.0        # dropout probability
+    p: float = 0.0        # dropout probability; on a block-closing conv with a shortcut: stochastic-depth probability
 
 
 @dataclass
@@ -103,7 +103,7 @@ def _add_head(g, ops, new_t, cur, feat, num_classes, head, dropout):
     return cur
 
 
-def _build_efficientnet(network, num_classes, head, dropout, in_chans):
+def _build_efficientnet(network, num_classes, head, dropout, in_chans, stochastic_depth=0.2):
     """torchvision EfficientNet: children [features, avgpool, classifier]; the reference keeps
     [features, avgpool] as ``base`` and reads ``in_features`` off the classifier's Linear
     (network.py:50-55).  state_dict keys: base.0.<i>... for features[i]."""
@@ -120,6 +120,10 @@ def _build_efficientnet(network, num_classes, head, dropout, in_chans):
 
     cur = new_t()
     ops.append(Op(OP_CONV, "base.0.0.0", "base.0.0.1", in_chans, ch(32), 3, 2, 1, ACT_SILU, 0, cur, -1, 0))
+    # torchvision: sd_prob = stochastic_depth_prob * block index / number of blocks (train mode only: "row" mode
+    # StochasticDepth on the block's branch before the shortcut add)
+    total_blocks = sum(int(math.ceil(n * dm)) for (_, _, _, _, _, n) in _MBCONV)
+    block_id = 0
     for si, (ratio, k, stride, cin, cout, n) in enumerate(_MBCONV):
         cin, cout, n = ch(cin), ch(cout), int(math.ceil(n * dm))
         for b in range(n):
@@ -140,9 +144,11 @@ def _build_efficientnet(network, num_classes, head, dropout, in_chans):
             cur, j = d, j + 1
             d = new_t()
             res = x_in if (bs == 1 and bi == cout) else -1
+            sd = stochastic_depth * block_id / total_blocks if res >= 0 else 0.0
             ops.append(Op(OP_CONV, f"{pre}.{j}.0", f"{pre}.{j}.1", exp, cout, 1, 1, 0, ACT_NONE, cur, d, res, 0,
-                          res >= 0))
+                          res >= 0, sd))
             cur = d
+            block_id += 1
     d = new_t()
     ops.append(Op(OP_CONV, "base.0.8.0", "base.0.8.1", ch(320), 4 * ch(320), 1, 1, 0, ACT_SILU, cur, d, -1, 0))
     cur = d
@@ -152,10 +158,11 @@ def _build_efficientnet(network, num_classes, head, dropout, in_chans):
     return g
 
 
-def build_graph(network, num_classes, head=(256, 128), dropout=(), in_chans=3):
-    """Mirror of ``TorchVisionNet.__init__`` (ResNet and EfficientNet-B0..B4 families)."""
+def build_graph(network, num_classes, head=(256, 128), dropout=(), in_chans=3, stochastic_depth=0.2):
+    """Mirror of ``TorchVisionNet.__init__`` (ResNet and EfficientNet-B0..B4 families).  ``stochastic_depth`` is
+    torchvision's ``stochastic_depth_prob`` (0.2 for every EfficientNet variant; 0 turns the train-mode row dropping off)."""
     if network in _EFFNETS:
-        return _build_efficientnet(network, num_classes, list(head), list(dropout), in_chans)
+        return _build_efficientnet(network, num_classes, list(head), list(dropout), in_chans, stochastic_depth)
     if network not in _RESNETS:
         raise ValueError(
             f"network {network!r} has no MI355X path yet; supported: {supported_networks()}"

@@ -128,14 +128,14 @@ class HipSequential:
 
 class HipNet:
     def __init__(self, name, num_classes, weights="DEFAULT", head=(256, 128), dropout=(),
-                 last_activation=None, device=None, init=True):
+                 last_activation=None, device=None, init=True, stochastic_depth=0.2):
         # `weights` names pretrained torchvision weights; there is nothing to
         # download from here and a best_state.pth / training run overwrites
         # every tensor anyway (quirk Q7) — only None/"" vs. other is recorded.
         self.name, self.num_classes = name, int(num_classes)
         self.weights = weights
         self.last_activation = last_activation
-        self.graph = arch.build_graph(name, num_classes, list(head), list(dropout))
+        self.graph = arch.build_graph(name, num_classes, list(head), list(dropout), stochastic_depth=stochastic_depth)
         self._specs = arch.param_specs(self.graph)
         self._lib = lib.load()
         if not torch.cuda.is_available():

@@ -109,9 +109,10 @@ def test_depthwise_kernels_match_torch(case):
         assert err < 2e-3 and perr < 1e-4
 
 
-def test_efficientnet_odd_size_u8_and_no_training():
-    """Ragged image size (odd height/width), uint8 NHWC input, and the training entry points
-    refusing a network that has an inference path only."""
+def test_efficientnet_odd_size_u8_and_training_step():
+    """Ragged image size (odd height/width), uint8 NHWC input; a training step on the same odd-sized batch runs (the
+    activations are re-planned into the channel-padded training layout) and the eval path gives the same answer again
+    afterwards from the reloaded weights."""
     from oracle import refnet
     from sykepic_hip import arch
     from sykepic_hip.net import HipNet
@@ -131,8 +132,12 @@ def test_efficientnet_odd_size_u8_and_no_training():
     assert np.abs(pg_f - pr).max() <= PROB_TOL
     assert np.abs(pg_u - pg_f).max() < 2e-5
     net.train()
-    with pytest.raises(RuntimeError, match="inference path only"):
-        net.forward_backward(xf.cuda(), torch.zeros(5, dtype=torch.int64).cuda())
+    net.reset_stats()
+    net.forward_backward(xf.cuda(), torch.zeros(5, dtype=torch.int64).cuda())
+    assert np.isfinite(net.read_stats()[0])
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})   # the step moved the running statistics
+    net.eval()
+    assert np.abs(net.probabilities(xf.cuda()).cpu().numpy() - pg_f).max() < 1e-6
 
 
 def test_efficientnet_through_prob_workflow(tmp_path, golden_dir):

@@ -98,7 +98,7 @@ oversample_until = 12
 oversample_with_decay =
 [model]
 path = {models}
-network = resnet18
+network = {network}
 weights =
 id = auto
 exist_ok = no
@@ -136,9 +136,11 @@ verbose = yes
 """
 
 
-def test_train_main_end_to_end(tmp_path, capsys):
+@pytest.mark.parametrize("network", ["resnet18", "efficientnet_b0"])
+def test_train_main_end_to_end(tmp_path, capsys, network):
     """8 epochs on 3 synthetic classes (every phase of the unfreeze schedule): artefacts, checkpoint
-    interchangeable with the torch module of the reference, loss goes down."""
+    interchangeable with the torch module of the reference, loss goes down.  `network = efficientnet_b0` takes the
+    MBConv training path (depthwise / squeeze-excitation / SiLU backward, stochastic depth)."""
     import random
     from oracle import refnet
     from sykepic_hip import train
@@ -159,11 +161,11 @@ def test_train_main_end_to_end(tmp_path, capsys):
             img = np.clip(img.astype(np.int32) + rng.randint(-10, 10, (h, w)), 0, 255).astype(np.uint8)
             Image.fromarray(img).save(ds / name / f"{name}_{i:02d}.png")
     ini = tmp_path / "train.ini"
-    ini.write_text(INI.format(ds=ds, models=tmp_path / "models"))
+    ini.write_text(INI.format(ds=ds, models=tmp_path / "models", network=network))
     train.main(namedtuple("A", "config collage dist save_images")(str(ini), None, None, None))
     out = capsys.readouterr().out
     assert "[ERROR]" not in out, out
-    mdir = tmp_path / "models" / "resnet18_1"
+    mdir = tmp_path / "models" / f"{network}_1"
     for f in ("config.ini", "class_names.txt", "class_distribution.csv", "best_state.pth", "test_report.txt"):
         assert (mdir / f).is_file(), f
     assert (mdir / "class_names.txt").read_text().split("\n") == ["bars", "blob", "flat"]
@@ -173,7 +175,7 @@ def test_train_main_end_to_end(tmp_path, capsys):
     assert min(losses[1:]) < losses[0] - 0.005, losses
     # the checkpoint is a plain state_dict the reference's torch module accepts
     sd = torch.load(mdir / "best_state.pth")
-    ref = refnet.RefNet("resnet18", 3, head=(32, 16))
+    ref = refnet.RefNet(network, 3, head=(32, 16))
     ref.load_state_dict(sd)
-    assert int(sd["base.1.num_batches_tracked"]) > 0
+    assert int(sd["base.1.num_batches_tracked" if network == "resnet18" else "base.0.0.1.num_batches_tracked"]) > 0
     assert "accuracy" in (mdir / "test_report.txt").read_text()
