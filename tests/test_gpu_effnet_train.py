@@ -74,12 +74,14 @@ def test_backward_matches_teacher_forced_autograd(network, hw, n):
         got = net._read_grad(k, tuple(tsd[k].shape))
         r = _rel(got, tsd[k].grad)
         if k in zero_bias:
-            # The trunk feeds only conv -> train-mode BatchNorm, which removes any per-channel constant: the exact gradient
-            # of a block-closing BatchNorm's bias is 0 and autograd returns rounding noise.  The GPU's value must be small
-            # against the gradient of the same layer's weight (bf16 storage noise of ~1e-2 per element, summed).
+            # Where the trunk feeds only 1x1 conv -> train-mode BatchNorm, which removes any per-channel constant, the
+            # exact gradient of a block-closing BatchNorm's bias is 0 and autograd returns rounding noise (not so when a
+            # zero-padded depthwise conv reads the trunk directly).  The GPU's value must then be small against the
+            # gradient of the same layer's weight (bf16 storage noise of ~1e-2 per element, summed).
             scale = float(tsd[k[:-4] + "weight"].grad.norm())
-            assert float(tsd[k].grad.norm()) < 1e-3 * scale and float(got.norm()) < 0.1 * scale, (k, float(got.norm()), scale)
-            continue
+            if float(tsd[k].grad.norm()) < 1e-3 * scale:
+                assert float(got.norm()) < 0.1 * scale, (k, float(got.norm()), scale)
+                continue
         if k.startswith("head."):
             assert r < 1e-3, f"{k}: {r:.3e}"
             continue
