@@ -5,6 +5,8 @@ import ctypes
 import re
 from pathlib import Path
 
+import pytest
+
 from sykepic_hip import lib
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -42,17 +44,20 @@ def test_struct_layouts_match_header():
 
 
 def test_host_code_under_address_and_ub_sanitizers():
-    """`csrc/build.sh asan`: every translation unit with -fsanitize=address,undefined on its host pass + csrc/
+    """`csrc/build_asan.sh`: every translation unit with -fsanitize=address,undefined on its host pass + csrc/
     asan_driver.hip, which walks handle creation and its error paths, the parameter table (with a deliberately short
     key buffer), spk_last_error and the three tuner-cache parsers (valid, truncated, garbage and over-long lines).
     Without a GPU every HIP call fails and the error paths run; a sanitizer report aborts the driver (exit != 0)."""
     import os
     import subprocess
     csrc = ROOT / "syke-pic_amd" / "csrc"
+    recipe = csrc / "build_asan.sh"
+    if not recipe.is_file():
+        pytest.skip("build_asan.sh is not shipped to GPU boxes (.gpurunignore): the sanitizer pass is a CPU-container test")
     exe = csrc / "build" / "asan" / "asan_driver"
     srcs = list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))
     if not exe.is_file() or any(f.stat().st_mtime > exe.stat().st_mtime for f in srcs):
-        subprocess.run(["bash", str(csrc / "build.sh"), "asan"], check=True, timeout=1500)
+        subprocess.run(["bash", str(recipe)], check=True, timeout=1500)
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     env.pop("SPK_TUNE_CACHE", None)
     r = subprocess.run([str(exe)], env=env, capture_output=True, text=True, timeout=300)
