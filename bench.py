@@ -230,7 +230,8 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fwd, dgrad) + conv_wgrad_kernel",
                 "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": train_traffic(args),
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None if args.network.startswith("efficientnet") else train_traffic(args),
                 "launches": int(sum(l for n_, _, fl, l in phases if fl > 0)),
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
                 "phases_ms": {n_: round(ms, 3) for n_, ms, _, _ in phases}}
@@ -369,8 +370,8 @@ def main():
     # headline = the inference step (net_pass body); the training step of the
     # same model/config rides along under "train" (BASELINE metric names both)
     modes = ["infer", "train"] if args.mode == "both" else [args.mode]
-    if args.network.startswith("efficientnet"):
-        modes = ["infer"]   # BASELINE config 5 is an inference config; the MI355X path has no EfficientNet training
+    if args.network.startswith("efficientnet") and args.mode == "both":
+        modes = ["infer"]   # BASELINE config 5 is an inference config; `--mode train` measures the MBConv training step
     results = []
     for m in modes:
         if rank == 0:

@@ -442,7 +442,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                     (bf16_t*)m->T(L.d.dst), t->MASK(i), (size_t)M * C, C, L.d.relu, s), "bn_apply");
         } else {
           K_TRY(spk_launch_bna_finalize(part, m_tiles, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
-                                        m->P(L.p_var), st, 1e-5f, 0.1f, s), "bn_finalize");
+                                        m->P(L.p_var), st, 1e-5f, 0.1f, tmp, s), "bn_finalize");
           float* rs = nullptr;
           if (t->conv[i].rs_off) {   // StochasticDepth(p, "row") on the residual branch, train mode
             rs = (float*)((char*)t->arena + t->conv[i].rs_off);
@@ -467,7 +467,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         mark(m, PH_CONV_FWD);
         L.nbt += 1;
         K_TRY(spk_launch_bna_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
-                                      m->P(L.p_var), st, 1e-5f, 0.1f, s), "bn_finalize");
+                                      m->P(L.p_var), st, 1e-5f, 0.1f, tmp, s), "bn_finalize");
         K_TRY(spk_launch_bna_apply(t->RAW(i), st + 2 * C, st + 3 * C, nullptr, nullptr, (bf16_t*)m->T(L.d.dst), M, C,
                                    o.h * o.w, L.d.relu, s), "bn_apply");
         mark(m, PH_BN_FWD);
@@ -483,10 +483,8 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
         K_TRY(spk_launch_pool_rows(a, nullptr, scratch, pooled, n, HW, C, 1.f / (float)HW, s), "se pool");
-        K_TRY(spk_launch_sgemm(pooled, C, 1, m->P(L.p_w), Cl, 1, m->P(L.p_b), u1, S, 1, n, S, Cl, 1.f, 0, s), "se fc1");
-        K_TRY(spk_launch_ew(SPK_EW_SILU, u1, nullptr, h1, (size_t)n * S, s), "se silu");
-        K_TRY(spk_launch_sgemm(h1, S, 1, m->P(L.p_w2), S, 1, m->P(L.p_b2), gate, C, 1, n, Cl, S, 1.f, 0, s), "se fc2");
-        K_TRY(spk_launch_ew(SPK_EW_SIGMOID, gate, nullptr, gate, (size_t)n * C, s), "se sigmoid");
+        K_TRY(spk_launch_se_gate_fwd(pooled, m->P(L.p_w), m->P(L.p_b), m->P(L.p_w2), m->P(L.p_b2), u1, h1, gate, n, C, Cl, S,
+                                     s), "se gates");
         K_TRY(spk_launch_se_scale(a, gate, (bf16_t*)m->T(L.d.dst), n, HW, C, s), "se scale");
         mark(m, PH_BN_FWD);
         break;
@@ -613,7 +611,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           int nbk = 0;
           K_TRY(spk_launch_bna_bwd_reduce(g, t->RAW(i), st + 2 * C, st + 3 * C, st, st + C, rs, part, M, C, o.h * o.w,
                                           L.d.relu, &nbk, s), "bn bwd reduce");
-          K_TRY(spk_launch_bna_bwd_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), st + C, dgam, dbet, coef, s),
+          K_TRY(spk_launch_bna_bwd_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), st + C, dgam, dbet, coef, tmp, s),
                 "bn bwd finalize");
           K_TRY(spk_launch_bna_bwd_apply(g, t->RAW(i), st + 2 * C, st + 3 * C, st, st + C, coef, rs, dy, g_res,
                                          g_res ? has_grad[L.d.res] : 0, M, C, o.h * o.w, L.d.relu, s), "bn bwd apply");
@@ -685,24 +683,16 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
         float* dgate = scratch + (size_t)n * spk_se_chunks(HW) * C;   // becomes du2 in place
         float* dpool = dgate + (size_t)n * C;
-        float* dh1 = dpool + (size_t)n * C;
-        float* du1 = dh1 + (size_t)n * S;
+        float* du1 = dpool + (size_t)n * C;
         const bf16_t* g = (const bf16_t*)t->G(L.d.dst);
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
         K_TRY(spk_launch_pool_rows(g, a, scratch, dgate, n, HW, C, 1.f, s), "se dgate");
-        K_TRY(spk_launch_ew(SPK_EW_SIGMOID_BWD, dgate, gate, dgate, (size_t)n * C, s), "se sigmoid bwd");
         const Param &w1 = m->params[L.p_w], &b1 = m->params[L.p_b], &w2 = m->params[L.p_w2], &b2 = m->params[L.p_b2];
-        if (w2.requires_grad)   // dW2[c][s] = sum_n du2[n][c] * h1[n][s]
-          K_TRY(spk_launch_sgemm(dgate, 1, C, h1, 1, S, nullptr, t->gbuf + w2.off, S, 1, Cl, S, n, 1.f, 0, s), "se fc2 wgrad");
-        if (b2.requires_grad) K_TRY(spk_launch_colsum_strided(dgate, t->gbuf + b2.off, n, Cl, C, s), "se fc2 bias grad");
-        // dh1[n][s] = sum_c du2[n][c] * W2[c][s]
-        K_TRY(spk_launch_sgemm(dgate, C, 1, m->P(L.p_w2), 1, S, nullptr, dh1, S, 1, n, S, Cl, 1.f, 0, s), "se fc2 dgrad");
-        K_TRY(spk_launch_ew(SPK_EW_SILU_BWD, dh1, u1, du1, (size_t)n * S, s), "se silu bwd");
-        if (w1.requires_grad)   // dW1[s][c] = sum_n du1[n][s] * pooled[n][c]
-          K_TRY(spk_launch_sgemm(du1, 1, S, pooled, 1, C, nullptr, t->gbuf + w1.off, Cl, 1, S, Cl, n, 1.f, 0, s), "se fc1 wgrad");
-        if (b1.requires_grad) K_TRY(spk_launch_colsum_strided(du1, t->gbuf + b1.off, n, S, S, s), "se fc1 bias grad");
-        // dpool[n][c] = sum_s du1[n][s] * W1[s][c]   (pad columns stay zero)
-        K_TRY(spk_launch_sgemm(du1, S, 1, m->P(L.p_w), 1, Cl, nullptr, dpool, C, 1, n, Cl, S, 1.f, 0, s), "se fc1 dgrad");
+        K_TRY(spk_launch_se_gate_bwd(dgate, gate, u1, m->P(L.p_w), m->P(L.p_w2), du1, dpool, n, C, Cl, S, s), "se gates bwd");
+        K_TRY(spk_launch_se_wgrad(dgate, h1, du1, pooled, w1.requires_grad ? t->gbuf + w1.off : nullptr,
+                                  b1.requires_grad ? t->gbuf + b1.off : nullptr,
+                                  w2.requires_grad ? t->gbuf + w2.off : nullptr,
+                                  b2.requires_grad ? t->gbuf + b2.off : nullptr, n, C, Cl, S, s), "se wgrad");
         K_TRY(spk_launch_se_bwd_apply(g, gate, dpool, (bf16_t*)t->G(L.d.src), n, HW, C, s), "se bwd apply");
         mark(m, PH_BN_BWD);
         has_grad[L.d.src] = 1;

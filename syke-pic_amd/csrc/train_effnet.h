@@ -8,14 +8,14 @@ int spk_eff_stat_blocks(int M, int* rows_per_block);
 int spk_launch_col_stats(const bf16_t* x, float* partials, int M, int C, int* blocks, hipStream_t s);
 int spk_launch_bna_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
                             const float* beta, float* rmean, float* rvar, float* st, float eps, float momentum,
-                            hipStream_t s);
+                            float* tmp, hipStream_t s);
 int spk_launch_bna_apply(const bf16_t* raw, const float* scale, const float* shift, const bf16_t* res,
                          const float* rowscale, bf16_t* out, int M, int C, int HW, int act, hipStream_t s);
 int spk_launch_bna_bwd_reduce(const bf16_t* g, const bf16_t* raw, const float* scale, const float* shift,
                               const float* mean, const float* invstd, const float* rowscale, float* partials, int M,
                               int C, int HW, int act, int* blocks, hipStream_t s);
 int spk_launch_bna_bwd_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
-                                const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t s);
+                                const float* invstd, float* dgamma, float* dbeta, float* coef, float* tmp, hipStream_t s);
 int spk_launch_bna_bwd_apply(const bf16_t* g, const bf16_t* raw, const float* scale, const float* shift,
                              const float* mean, const float* invstd, const float* coef, const float* rowscale,
                              bf16_t* dy, bf16_t* g_res, int res_accumulate, int M, int C, int HW, int act,
@@ -46,3 +46,9 @@ int spk_launch_slab_reduce_sub(const float* slabs, float* out, int cout, int tap
                                int splits, hipStream_t s);
 int spk_launch_pack_train_padded(const float* w, bf16_t* out, int cout, int taps, int cin, int cout_p, int cin_p,
                                  int kind, hipStream_t s);
+int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
+                           float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s);
+int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, const float* W1, const float* W2, float* du1,
+                           float* dpool, int n, int C, int Cl, int S, hipStream_t s);
+int spk_launch_se_wgrad(const float* du2, const float* h1, const float* du1, const float* pooled, float* gW1, float* gb1,
+                        float* gW2, float* gb2, int n, int C, int Cl, int S, hipStream_t s);

@@ -217,6 +217,24 @@ __device__ __forceinline__ double colsum16(const float* __restrict__ partials, i
   return tot;
 }
 
+// stage 1 of the ordered reduction when there are many partial rows (one per M tile of the conv kernels): blockIdx.y takes
+// a contiguous slice of the rows and writes one row of out[slices][2][C]
+__global__ __launch_bounds__(1024) void bna_presum_kernel(const float* __restrict__ partials, int count, int C,
+                                                          int rows_per_slice, float* __restrict__ out) {
+  __shared__ double sm[16 * 64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
+  const bool valid = c < C;
+  const int t0 = blockIdx.y * rows_per_slice;
+  const int cnt = max(0, min(count - t0, rows_per_slice));
+  const float* base = partials + (size_t)t0 * 2 * C;
+  const double s1 = colsum16(base, cnt, C, 0, c, r, valid, sm);
+  const double s2 = colsum16(base, cnt, C, 1, c, r, valid, sm);
+  if (r == 0 && valid) {
+    out[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)s1;
+    out[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)s2;
+  }
+}
+
 __global__ __launch_bounds__(1024) void bna_finalize_kernel(
     const float* __restrict__ partials, int count, int C, int c_log, double M, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ st, float eps,
@@ -328,55 +346,69 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(const bf16_t* __restrict
   }
 }
 
-// stem weight gradient: partial[block][co][tap][ci] over the block's pixels
+// stem weight gradient: partial[block][co][tap][ci] over the block's pixels.  A thread owns (tap, co) items and the four
+// input channels of each: per pixel one LDS float of dy and one float4 of the gathered patch feed four FMAs.
 __global__ __launch_bounds__(256) void stem3_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                           float* __restrict__ partials, int n, int h, int wd, int wstride,
                                                           int cin, int cout, int C, int ho, int wo, int pix_per_block) {
-  constexpr int P = 32;
-  extern __shared__ float sm[];  // dys[P][C], xs[P][36]
+  constexpr int P = 64;
+  extern __shared__ float sm[];  // dys[P][C], xs[P][9][4]
   float* dys = sm;
-  float* xs = sm + P * C;
+  float4* xs = (float4*)(sm + P * C);
   const int M = n * ho * wo;
   const int p0 = blockIdx.x * pix_per_block, p1 = min(M, p0 + pix_per_block);
-  const int nout = cout * 36;
-  float acc[10];
+  const int nitem = cout * 9;
+  float4 acc[3];
 #pragma unroll
-  for (int u = 0; u < 10; ++u) acc[u] = 0.f;
+  for (int u = 0; u < 3; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int pb = p0; pb < p1; pb += P) {
     __syncthreads();
     for (int i = threadIdx.x; i < P * C; i += 256) {
       const int pp = pb + i / C;
       dys[i] = pp < p1 ? lo_f32<DT>((unsigned)dy[(size_t)pp * C + i % C]) : 0.f;
     }
-    for (int i = threadIdx.x; i < P * 36; i += 256) {
-      const int pp = pb + i / 36, t = i % 36, tap = t >> 2, ci = t & 3;
-      float v = 0.f;
+    for (int i = threadIdx.x; i < P * 9; i += 256) {
+      const int pp = pb + i / 9, tap = i % 9;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (pp < p1) {
         const int ow = pp % wo, oh = (pp / wo) % ho, img = pp / (wo * ho);
         const int ih = oh * 2 + tap / 3 - 1, iw = ow * 2 + tap % 3 - 1;
-        if (ih >= 0 && ih < h && iw >= 0 && iw < wd)
-          v = lo_f32<DT>((unsigned)x[(((size_t)img * h + ih) * wstride + iw) * 4 + ci]);
+        if (ih >= 0 && ih < h && iw >= 0 && iw < wd) {
+          const uint2 q = *(const uint2*)(x + (((size_t)img * h + ih) * wstride + iw) * 4);
+          v = make_float4(lo_f32<DT>(q.x), hi_f32<DT>(q.x), lo_f32<DT>(q.y), hi_f32<DT>(q.y));
+        }
       }
       xs[i] = v;
     }
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < 10; ++u) {
+    for (int u = 0; u < 3; ++u) {
       const int o = threadIdx.x + u * 256;
-      if (o >= nout) break;
-      const int co = o / 36, t = o % 36;
-      float a = acc[u];
-      for (int pp = 0; pp < P; ++pp) a += dys[pp * C + co] * xs[pp * 36 + t];
-      acc[u] = a;
+      if (o < nitem) {     // (no break: the loop must unroll for acc[] to stay in registers)
+        const int co = o % cout, tap = o / cout;
+        float4 a = acc[u];
+#pragma unroll 8
+        for (int pp = 0; pp < P; ++pp) {
+          const float g = dys[pp * C + co];
+          const float4 v = xs[pp * 9 + tap];
+          a.x += g * v.x; a.y += g * v.y; a.z += g * v.z; a.w += g * v.w;
+        }
+        acc[u] = a;
+      }
     }
   }
   float* out = partials + (size_t)blockIdx.x * cout * 9 * cin;
 #pragma unroll
-  for (int u = 0; u < 10; ++u) {
+  for (int u = 0; u < 3; ++u) {
     const int o = threadIdx.x + u * 256;
-    if (o >= nout) break;
-    const int co = o / 36, t = o % 36, tap = t >> 2, ci = t & 3;
-    if (ci < cin) out[((size_t)co * 9 + tap) * cin + ci] = acc[u];
+    if (o < nitem) {
+      const int co = o % cout, tap = o / cout;
+      float* q = out + ((size_t)co * 9 + tap) * cin;
+      q[0] = acc[u].x;
+      if (cin > 1) q[1] = acc[u].y;
+      if (cin > 2) q[2] = acc[u].z;
+      if (cin > 3) q[3] = acc[u].w;
+    }
   }
 }
 
@@ -461,77 +493,102 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const bf16_t* __restrict_
   }
 }
 
-// gw[c][kh][kw] = sum over output pixels of dy * x(shifted): blockIdx.y = kh; partial rows [(block*rif + lane_r)][c_log][taps]
+// gw[c][kh][kw] = sum over output pixels of dy * x(shifted): blockIdx.y = kh; the rows-in-flight of a block are combined
+// through LDS in a fixed order, one partial row [c_log][taps] per block
 template <int K>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ partials, int n, int h, int wd, int C, int c_log,
                                                        int stride, int pad, int ho, int wo, int rows_per_block) {
+  extern __shared__ float sm[];   // [rif][tpr][K][8]
   const int M = n * ho * wo;
   const RowWalk w(M, C, rows_per_block);
-  if (!w.active) return;
   const int kh = blockIdx.y;
-  float* out = partials + ((size_t)blockIdx.x * w.rif + w.lane_r) * c_log * K * K;
-  for (int cc = w.lane_c; cc < w.c8; cc += w.tpr) {
+  float* out = partials + (size_t)blockIdx.x * c_log * K * K;
+  for (int c0 = 0; c0 < w.c8; c0 += w.tpr) {     // uniform trip count: the barriers below are reached by every thread
+    const int cc = c0 + w.lane_c;
+    const bool mine = w.active && cc < w.c8;
     float acc[K][8];
 #pragma unroll
     for (int q = 0; q < K; ++q)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
-    for (int r = w.row0 + w.lane_r; r < w.row1; r += w.rif) {
-      const int ow = r % wo, oh = (r / wo) % ho, img = r / (wo * ho);
-      const int ih = oh * stride + kh - pad;
-      if (ih < 0 || ih >= h) continue;
-      float gv[8];
-      unpack8(*(const u32x4_t*)(dy + (size_t)r * C + cc * 8), gv);
+    if (mine)
+      for (int r = w.row0 + w.lane_r; r < w.row1; r += w.rif) {
+        const int ow = r % wo, oh = (r / wo) % ho, img = r / (wo * ho);
+        const int ih = oh * stride + kh - pad;
+        if (ih < 0 || ih >= h) continue;
+        float gv[8];
+        unpack8(*(const u32x4_t*)(dy + (size_t)r * C + cc * 8), gv);
 #pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        const int iw = ow * stride + kw - pad;
-        if (iw < 0 || iw >= wd) continue;
-        float xv[8];
-        unpack8(*(const u32x4_t*)(x + (((size_t)img * h + ih) * wd + iw) * C + cc * 8), xv);
+        for (int kw = 0; kw < K; ++kw) {
+          const int iw = ow * stride + kw - pad;
+          if (iw < 0 || iw >= wd) continue;
+          float xv[8];
+          unpack8(*(const u32x4_t*)(x + (((size_t)img * h + ih) * wd + iw) * C + cc * 8), xv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[kw][j] += gv[j] * xv[j];
+          for (int j = 0; j < 8; ++j) acc[kw][j] += gv[j] * xv[j];
+        }
       }
+    __syncthreads();
+    if (w.active) {
+      float* dst = sm + ((size_t)w.lane_r * w.tpr + w.lane_c) * K * 8;
+#pragma unroll
+      for (int q = 0; q < K; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[q * 8 + j] = acc[q][j];
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = cc * 8 + j;
-      if (c < c_log)
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) out[(size_t)c * K * K + kh * K + kw] = acc[kw][j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < w.tpr * K * 8; i += 256) {
+      const int j = i & 7, q = (i >> 3) % K, lc = i / (8 * K);
+      const int c = (c0 + lc) * 8 + j;
+      if (c0 + lc >= w.c8 || c >= c_log) continue;
+      float t = 0.f;
+      for (int r = 0; r < w.rif; ++r) t += sm[((size_t)r * w.tpr + lc) * K * 8 + q * 8 + j];
+      out[(size_t)c * K * K + kh * K + q] = t;
     }
   }
 }
 
 // ---- squeeze-excitation ----
-// partial sums over a chunk of the HW rows of one image: part[img][chunk][C] = sum x (* y when given)
+// partial sums over a chunk of the HW rows of one image: part[img][chunk][C] = sum x (* y when given).  Every thread of
+// the block works (8-channel chunk x row in flight); the rows in flight are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                                            float* __restrict__ part, int HW, int C, int chunks) {
+  extern __shared__ float sm[];   // [rif][C]
   const int img = blockIdx.x, chunk = blockIdx.y;
   const int rows = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   const int c8 = C >> 3;
-  for (int cc = threadIdx.x; cc < c8; cc += 256) {
-    float s[8];
+  const int tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
+  const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
+  if (lane_r < rif)
+    for (int cc = lane_c; cc < c8; cc += tpr) {
+      float s[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const size_t o = ((size_t)img * HW + r) * C + cc * 8;
-      float v[8];
-      unpack8(*(const u32x4_t*)(x + o), v);
-      if (y) {
-        float q[8];
-        unpack8(*(const u32x4_t*)(y + o), q);
+      for (int j = 0; j < 8; ++j) s[j] = 0.f;
+      for (int r = r0 + lane_r; r < r1; r += rif) {
+        const size_t o = ((size_t)img * HW + r) * C + cc * 8;
+        float v[8];
+        unpack8(*(const u32x4_t*)(x + o), v);
+        if (y) {
+          float q[8];
+          unpack8(*(const u32x4_t*)(y + o), q);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += v[j] * q[j];
-      } else {
+          for (int j = 0; j < 8; ++j) s[j] += v[j] * q[j];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] += v[j];
+          for (int j = 0; j < 8; ++j) s[j] += v[j];
+        }
       }
-    }
-    float* o = part + ((size_t)img * chunks + chunk) * C + cc * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = s[j];
+      for (int j = 0; j < 8; ++j) sm[(size_t)lane_r * C + cc * 8 + j] = s[j];
+    }
+  __syncthreads();
+  float* o = part + ((size_t)img * chunks + chunk) * C;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rif; ++r) t += sm[(size_t)r * C + i];
+    o[i] = t;
   }
 }
 __global__ void pool_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int chunks, int C,
@@ -542,6 +599,106 @@ __global__ void pool_finish_kernel(const float* __restrict__ part, float* __rest
   float t = 0.f;
   for (int k = 0; k < chunks; ++k) t += part[((size_t)img * chunks + k) * C + c];
   out[i] = t * scale;
+}
+
+// gates of one image per block: u1 = W1 pooled + b1, h1 = silu(u1), gate = sigmoid(W2 h1 + b2); fp32
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W1,
+                                                          const float* __restrict__ b1, const float* __restrict__ W2,
+                                                          const float* __restrict__ b2, float* __restrict__ u1,
+                                                          float* __restrict__ h1, float* __restrict__ gate, int C, int Cl,
+                                                          int S) {
+  extern __shared__ float sm[];   // pooled[Cl], h[S]
+  float* sp = sm;
+  float* shh = sm + Cl;
+  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < Cl; c += 256) sp[c] = pooled[(size_t)img * C + c];
+  __syncthreads();
+  for (int sidx = wave; sidx < S; sidx += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < Cl; c += 64) acc += W1[(size_t)sidx * Cl + c] * sp[c];
+    for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) {
+      const float u = acc + b1[sidx];
+      const float hv = u / (1.f + expf(-u));
+      u1[(size_t)img * S + sidx] = u;
+      h1[(size_t)img * S + sidx] = hv;
+      shh[sidx] = hv;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cl; c += 256) {
+    float acc = b2[c];
+    for (int sidx = 0; sidx < S; ++sidx) acc += W2[(size_t)c * S + sidx] * shh[sidx];
+    gate[(size_t)img * C + c] = 1.f / (1.f + expf(-acc));
+  }
+}
+
+// backward of the gate path of one image per block.  in: dgate[img][c] = sum_hw g*a; out (in place): du2 = dgate*s(1-s);
+// du1[img][s] = silu'(u1) * sum_c du2[c] W2[c][s];  dpool[img][c] = sum_s du1[s] W1[s][c]
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(float* __restrict__ dgate, const float* __restrict__ gate,
+                                                          const float* __restrict__ u1, const float* __restrict__ W1,
+                                                          const float* __restrict__ W2, float* __restrict__ du1,
+                                                          float* __restrict__ dpool, int C, int Cl, int S) {
+  extern __shared__ float sm[];   // du2[Cl], du1[S]
+  float* s2 = sm;
+  float* s1 = sm + Cl;
+  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < Cl; c += 256) {
+    const float g = gate[(size_t)img * C + c];
+    const float v = dgate[(size_t)img * C + c] * g * (1.f - g);
+    dgate[(size_t)img * C + c] = v;
+    s2[c] = v;
+  }
+  __syncthreads();
+  for (int sidx = wave; sidx < S; sidx += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < Cl; c += 64) acc += s2[c] * W2[(size_t)c * S + sidx];
+    for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) {
+      const float z = u1[(size_t)img * S + sidx], sg = 1.f / (1.f + expf(-z));
+      const float v = acc * sg * (1.f + z * (1.f - sg));
+      du1[(size_t)img * S + sidx] = v;
+      s1[sidx] = v;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < Cl; c += 256) {
+    float acc = 0.f;
+    for (int sidx = 0; sidx < S; ++sidx) acc += s1[sidx] * W1[(size_t)sidx * Cl + c];
+    dpool[(size_t)img * C + c] = acc;
+  }
+}
+
+// parameter gradients of the two 1x1 convs of the gate path (sums over the batch, fixed order); null: not wanted
+__global__ void se_wgrad_kernel(const float* __restrict__ du2, const float* __restrict__ h1, const float* __restrict__ du1,
+                                const float* __restrict__ pooled, float* __restrict__ gW1, float* __restrict__ gb1,
+                                float* __restrict__ gW2, float* __restrict__ gb2, int n, int C, int Cl, int S) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cl * S) return;
+  if (gW2) {   // [Cl][S]
+    const int c = i / S, sidx = i % S;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) acc += du2[(size_t)k * C + c] * h1[(size_t)k * S + sidx];
+    gW2[i] = acc;
+  }
+  if (gW1) {   // [S][Cl]
+    const int sidx = i / Cl, c = i % Cl;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) acc += du1[(size_t)k * S + sidx] * pooled[(size_t)k * C + c];
+    gW1[i] = acc;
+  }
+  if (gb2 && i < Cl) {
+    float acc = 0.f;
+    for (int k = 0; k < n; ++k) acc += du2[(size_t)k * C + i];
+    gb2[i] = acc;
+  }
+  if (gb1 && i < S) {
+    float acc = 0.f;
+    for (int k = 0; k < n; ++k) acc += du1[(size_t)k * S + i];
+    gb1[i] = acc;
+  }
 }
 
 // out = a * gate[img][c]
@@ -702,10 +859,10 @@ int spk_stem3_wgrad_blocks(int M, int* pix_per_block) {
 
 int spk_launch_stem3_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int wstride,
                            int cin, int cout, int C, int ho, int wo, int* blocks, hipStream_t s) {
-  if (cout * 36 > 2560) return -1;
+  if (cout * 9 > 768 || cin > 4) return -1;
   int ppb;
   const int nb = spk_stem3_wgrad_blocks(n * ho * wo, &ppb);
-  hipLaunchKernelGGL(stem3_wgrad_kernel, dim3(nb), dim3(256), (size_t)(32 * C + 32 * 36) * 4, s, x, dy, partials, n, h,
+  hipLaunchKernelGGL(stem3_wgrad_kernel, dim3(nb), dim3(256), (size_t)(64 * C + 64 * 36) * 4, s, x, dy, partials, n, h,
                      wd, wstride, cin, cout, C, ho, wo, ppb);
   *blocks = nb;
   return LAUNCH_OK();
@@ -732,25 +889,31 @@ int spk_launch_dw_dgrad(const bf16_t* dy, const float* wt, bf16_t* dx, int accum
   return LAUNCH_OK();
 }
 
-// partial rows the weight-gradient kernel writes for an [M][C] problem ([rows][c_log][k*k] floats)
+// partial rows the weight-gradient kernel writes for an [M][C] problem ([rows][c_log][k*k] floats): one per block
+static int dw_wgrad_blocks(int M, int* rows_per_block) {
+  int rpb = 8192;
+  while (rpb > 256 && (M + rpb - 1) / rpb < 256) rpb >>= 1;
+  *rows_per_block = rpb;
+  return (M + rpb - 1) / rpb;
+}
 int spk_dw_wgrad_rows(int M, int C) {
   int rpb;
-  const int nb = walk_rows(M, &rpb);
-  const int c8 = C / 8, tpr = c8 < 256 ? c8 : 256;
-  return nb * (256 / tpr);
+  return dw_wgrad_blocks(M, &rpb);
 }
 
 int spk_launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int C, int c_log,
                         int k, int stride, int pad, int ho, int wo, int* rows, hipStream_t s) {
   int rpb;
   const int M = n * ho * wo;
-  const int nb = walk_rows(M, &rpb);
-  *rows = spk_dw_wgrad_rows(M, C);
+  const int nb = dw_wgrad_blocks(M, &rpb);
+  *rows = nb;
+  const int c8 = C / 8, tpr = c8 < 256 ? c8 : 256;
+  const size_t lds = (size_t)(256 / tpr) * tpr * k * 8 * sizeof(float);
   if (k == 3)
-    hipLaunchKernelGGL(dw_wgrad_kernel<3>, dim3(nb, 3), dim3(256), 0, s, x, dy, partials, n, h, wd, C, c_log, stride, pad,
+    hipLaunchKernelGGL(dw_wgrad_kernel<3>, dim3(nb, 3), dim3(256), lds, s, x, dy, partials, n, h, wd, C, c_log, stride, pad,
                        ho, wo, rpb);
   else if (k == 5)
-    hipLaunchKernelGGL(dw_wgrad_kernel<5>, dim3(nb, 5), dim3(256), 0, s, x, dy, partials, n, h, wd, C, c_log, stride, pad,
+    hipLaunchKernelGGL(dw_wgrad_kernel<5>, dim3(nb, 5), dim3(256), lds, s, x, dy, partials, n, h, wd, C, c_log, stride, pad,
                        ho, wo, rpb);
   else
     return -1;
@@ -763,7 +926,7 @@ int spk_se_chunks(int HW) { return HW >= 3136 ? 16 : (HW >= 196 ? 4 : 1); }
 int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* out, int n, int HW, int C, float scale,
                          hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks), dim3(256), 0, s, x, y, part, HW, C, chunks);
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks), dim3(256), walk_lds(C) / 2, s, x, y, part, HW, C, chunks);
   hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, out, n, chunks, C, scale);
   return LAUNCH_OK();
 }
@@ -798,16 +961,27 @@ int spk_launch_slab_reduce_sub(const float* slabs, float* out, int cout, int tap
   return LAUNCH_OK();
 }
 
+static const float* bna_presum(const float* partials, int* count, int C, float* tmp, hipStream_t s) {
+  if (*count <= 128 || !tmp) return partials;
+  const int slices = 64;
+  const int rps = (*count + slices - 1) / slices;
+  hipLaunchKernelGGL(bna_presum_kernel, dim3((C + 63) / 64, slices), dim3(1024), 0, s, partials, *count, C, rps, tmp);
+  *count = slices;
+  return tmp;
+}
+
 int spk_launch_bna_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
                             const float* beta, float* rmean, float* rvar, float* st, float eps, float momentum,
-                            hipStream_t s) {
+                            float* tmp, hipStream_t s) {
+  partials = bna_presum(partials, &count, C, tmp, s);
   hipLaunchKernelGGL(bna_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, count, C, c_log, M, gamma,
                      beta, rmean, rvar, st, eps, momentum);
   return LAUNCH_OK();
 }
 
 int spk_launch_bna_bwd_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
-                                const float* invstd, float* dgamma, float* dbeta, float* coef, hipStream_t s) {
+                                const float* invstd, float* dgamma, float* dbeta, float* coef, float* tmp, hipStream_t s) {
+  partials = bna_presum(partials, &count, C, tmp, s);
   hipLaunchKernelGGL(bna_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, count, C, c_log, M, gamma,
                      invstd, dgamma, dbeta, coef);
   return LAUNCH_OK();
@@ -817,5 +991,27 @@ int spk_launch_pack_train_padded(const float* w, bf16_t* out, int cout, int taps
                                  int kind, hipStream_t s) {
   hipLaunchKernelGGL(pack_train_padded_kernel, dim3(grid_of((size_t)cout_p * taps * cin_p, 256)), dim3(256), 0, s, w, out,
                      cout, taps, cin, cout_p, cin_p, kind);
+  return LAUNCH_OK();
+}
+
+int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
+                           float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s) {
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(n), dim3(256), (size_t)(Cl + S) * 4, s, pooled, W1, b1, W2, b2, u1, h1, gate,
+                     C, Cl, S);
+  return LAUNCH_OK();
+}
+
+int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, const float* W1, const float* W2, float* du1,
+                           float* dpool, int n, int C, int Cl, int S, hipStream_t s) {
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(n), dim3(256), (size_t)(Cl + S) * 4, s, dgate, gate, u1, W1, W2, du1, dpool,
+                     C, Cl, S);
+  return LAUNCH_OK();
+}
+
+int spk_launch_se_wgrad(const float* du2, const float* h1, const float* du1, const float* pooled, float* gW1, float* gb1,
+                        float* gW2, float* gb2, int n, int C, int Cl, int S, hipStream_t s) {
+  if (!gW1 && !gb1 && !gW2 && !gb2) return 0;
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((Cl * S + 255) / 256), dim3(256), 0, s, du2, h1, du1, pooled, gW1, gb1, gW2, gb2,
+                     n, C, Cl, S);
   return LAUNCH_OK();
 }
