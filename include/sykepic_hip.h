@@ -167,6 +167,13 @@ int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops)
  * bits do not reach the 1e-3 probability tolerance of the reference: the fp16 path stays the parity mode. */
 int spk_model_set_fp8(spk_model* m, int on);
 int spk_model_calibrate_fp8(spk_model* m, const void* x_dev, int n, int h, int w, int layout, int dtype);
+/* Which MBConv blocks the fp8 mode covers (round 3).  Blocks are counted in graph order over those that qualify
+ * (expand conv -> depthwise -> squeeze-excitation -> project conv); flags[i] != 0 puts block i on the e4m3 path, 0 keeps
+ * it fp16.  n_blocks = 0 (or never calling this) selects the default set: every qualifying block that has a
+ * shortcut (a block without one replaces the trunk by its e4m3-computed output and costs most of the accuracy).  Takes
+ * effect at the next spk_model_calibrate_fp8.  spk_model_num_fp8_blocks returns how many blocks qualify. */
+int spk_model_set_fp8_blocks(spk_model* m, const unsigned char* flags, int n_blocks);
+int spk_model_num_fp8_blocks(spk_model* m);
 /* Dropout mask seed for training steps. */
 int spk_model_set_seed(spk_model* m, uint64_t seed);
 

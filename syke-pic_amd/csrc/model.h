@@ -100,6 +100,7 @@ struct spk_model {
   int fp8 = 0;                  // requested
   bool fp8_calibrated = false;  // roles assigned + activation ranges measured
   bool fp8_packed = false;
+  std::vector<unsigned char> fp8_blocks;   // per qualifying MBConv block (graph order): on the e4m3 path?  empty: all
   unsigned char* w8pack = nullptr;
   float* s8 = nullptr;
   unsigned char* fp8_shadow = nullptr;  // fp8 mode: e4m3 copy of the trunk tensor the last project conv wrote (pw_fp8.hip)

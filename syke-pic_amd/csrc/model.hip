@@ -515,15 +515,17 @@ static float fp8_scale_of(float amax) {
 }
 
 // expand 1x1 conv -> depthwise conv -> squeeze-excitation -> project 1x1 conv with e4m3 tensors in between
-static void assign_fp8_roles(spk_model* m) {
+static int assign_fp8_roles(spk_model* m, bool count_only = false) {
   const int nl = (int)m->layers.size();
+  int blk = 0;
   auto consumer = [&](int t, int* idx) {
     int cnt = 0;
     for (int j = 0; j < nl; ++j)
       if (m->layers[j].d.src == t || (m->layers[j].d.kind == SPK_OP_CONV && m->layers[j].d.res == t)) { *idx = j; ++cnt; }
     return cnt;
   };
-  for (Layer& L : m->layers) L.fp8_role = 0;
+  if (!count_only)
+    for (Layer& L : m->layers) L.fp8_role = 0;
   for (int i = 0; i < nl; ++i) {
     Layer& E = m->layers[i];
     if (E.d.kind != SPK_OP_CONV || E.d.k != 1 || E.d.stride != 1 || E.d.res >= 0 || E.d.cout % 16 || E.d.src == 0) continue;
@@ -533,8 +535,28 @@ static void assign_fp8_roles(spk_model* m) {
     if (consumer(m->layers[si].d.dst, &pi) != 1) continue;
     Layer& P = m->layers[pi];
     if (P.d.kind != SPK_OP_CONV || P.d.k != 1 || P.d.stride != 1 || P.d.src != m->layers[si].d.dst) continue;
+    const int idx = blk++;
+    if (count_only) continue;
+    // Default (no explicit flags): only blocks that ADD their branch to the trunk.  A block without a shortcut (the first
+    // of every stage) replaces the trunk by its e4m3-computed output, ~10 % relative error on the trunk itself, and alone
+    // flips more arg-maxes than all residual blocks together (tests/diagnostics/fp8_block_sweep.py).
+    if (m->fp8_blocks.empty() ? P.d.res < 0 : (idx >= (int)m->fp8_blocks.size() || !m->fp8_blocks[idx])) continue;
     E.fp8_role = 1; m->layers[di].fp8_role = 2; m->layers[si].fp8_role = 3; P.fp8_role = 4;
   }
+  return blk;
+}
+
+extern "C" int spk_model_num_fp8_blocks(spk_model* m) { return m ? assign_fp8_roles(m, true) : 0; }
+
+extern "C" int spk_model_set_fp8_blocks(spk_model* m, const unsigned char* flags, int n_blocks) {
+  if (!m || n_blocks < 0 || (n_blocks > 0 && !flags)) return fail(SPK_ERR_ARG, "set_fp8_blocks: bad arguments");
+  if (n_blocks > 0 && n_blocks != assign_fp8_roles(m, true))
+    return fail(SPK_ERR_ARG, "set_fp8_blocks: one flag per qualifying MBConv block (spk_model_num_fp8_blocks)");
+  m->fp8_blocks.assign(flags, flags + n_blocks);
+  m->fp8_calibrated = false;     // roles are assigned by the next calibration
+  m->fp8_packed = false;
+  m->shadow_t = -1;
+  return SPK_OK;
 }
 
 extern "C" int spk_model_set_fp8(spk_model* m, int on) {

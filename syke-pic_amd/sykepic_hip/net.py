@@ -232,11 +232,22 @@ class HipNet:
         lib.check(self._lib.spk_model_set_precision(self._h, int(split_weights), int(bool(precise_residual))))
         return self
 
-    def set_fp8(self, on=True, calibration_batch=None):
+    def num_fp8_blocks(self):
+        """MBConv blocks that qualify for the e4m3 path (those with an expand conv)."""
+        return int(self._lib.spk_model_num_fp8_blocks(self._h))
+
+    def set_fp8(self, on=True, calibration_batch=None, blocks=None):
         """fp8 (e4m3) eval mode of the EfficientNet MBConv blocks (BASELINE config 5; include/sykepic_hip.h).
         `calibration_batch`: a representative image batch (as `forward` takes it) whose activation ranges set the
-        tensor scales; required before the first fp8 forward."""
+        tensor scales; required before the first fp8 forward.  `blocks`: one flag per qualifying block (graph order),
+        True = e4m3, False = keep that block fp16; "all" = every block; None = the library default (blocks with a
+        shortcut only)."""
         self._ensure_init()
+        if isinstance(blocks, str) and blocks == "all":
+            blocks = [True] * self.num_fp8_blocks()
+        if blocks is not None:
+            flags = (C.c_ubyte * len(blocks))(*[1 if b else 0 for b in blocks])
+            lib.check(self._lib.spk_model_set_fp8_blocks(self._h, flags, len(blocks)))
         lib.check(self._lib.spk_model_set_fp8(self._h, int(bool(on))))
         if on and calibration_batch is not None:
             x, n, h, w, layout, dtype = self._prep(calibration_batch)
