@@ -108,6 +108,23 @@ def test_bench_two_ranks_like_the_driver(tmp_path):
     assert res["value"] > 0 and res["train"]["value"] > 0 and res["config"]["parallelism"] == "dp2"
 
 
+def test_bench_two_ranks_efficientnet_training(tmp_path):
+    """The MBConv training step under data parallelism (2 ranks over gloo on the one GPU): squeeze-excitation and
+    depthwise gradients travel in the same flat buffer the all-reduce sums."""
+    env = dict(os.environ, SPK_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29531", str(ROOT / "bench.py"), "--gpus", "2",
+           "--steps", "2", "--warmup", "1", "--batch", "8", "--size", "64", "--network", "efficientnet_b0",
+           "--mode", "train", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1
+    res = json.loads(line[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 16 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and "train step" in res["metric"]
+
+
 def _synthetic_sample(raw_dir, n_rois=150, seed=5):
     """.adc + .roi of a synthetic IFCB sample (column 16/17/18 = width/height/start byte, one empty trigger)."""
     rng = np.random.default_rng(seed)
