@@ -49,7 +49,8 @@ template <int DT> __device__ __forceinline__ unsigned int pack2_nosat(float lo, 
 // KSC = 0: RING flavour, any K, activations PA K-steps ahead.
 // HAS_RES: the launch has a shortcut operand (compile-time: with both epilogues in one kernel the compiler's s_waitcnt
 // placement merges the two paths and waits for the previous epilogue's stores at the top of every tile).
-template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC, bool HAS_RES>
+// DUAL: K-concatenated second activation source (PwConvArgs::x2).
+template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC, bool HAS_RES, bool DUAL = false>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, int m_tiles, int n_tiles) {
   constexpr bool RESIDENT = KSC > 0;
   constexpr int XS = RESIDENT ? KSC : PA;   // activation register sets
@@ -67,12 +68,15 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, p = lane & 15;
-  const int KS = RESIDENT ? KSC : (a.Cin >> 5);
+  const int KS = RESIDENT ? KSC : ((a.Cin + (DUAL ? a.Cin2 : 0)) >> 5);
+  const int ks1 = a.Cin >> 5;              // DUAL: K steps from ks1 on read the second source
   const int pairs_total = a.Cout >> 5;
   const int HoWo = a.Ho * a.Wo;
 
   const __amdgpu_buffer_rsrc_t rx =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (a.ablate & 4) ? 0 : a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, (DUAL && !(a.ablate & 4)) ? a.x2_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (a.ablate & 1) ? 0 : a.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
@@ -104,18 +108,21 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
 
   // pixel tile -> per-lane byte offsets of the activation fragments (pixel p of each of the wave's MT pixel tiles,
   // 16-byte chunk g of a K step) and of the output row segments (8 couts from n0 + 8g)
-  auto tile_offsets = [&](int tile, unsigned (&aoff)[MT], unsigned (&yoff)[MT]) {
+  constexpr int MT2 = DUAL ? MT : 1;
+  auto tile_offsets = [&](int tile, unsigned (&aoff)[MT], unsigned (&yoff)[MT], unsigned (&aoff2)[MT2]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int px = tile * BM + wave * WPX + m * 16 + p;
       const bool ok = tile < m_tiles && px < a.M;
-      int ipx = px;
-      if (a.stride != 1) {
+      int ipx = px, ipx2 = px;
+      if (a.stride != 1 || (DUAL && a.stride2 != 1)) {
         const int img = px / HoWo, rem = px - img * HoWo;
         const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
         ipx = (img * a.H + ho * a.stride) * a.W + wo * a.stride;
+        if (DUAL) ipx2 = (img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2;
       }
       aoff[m] = ok ? (unsigned)ipx * (unsigned)(a.Cin * 2) + g * 16 : 0x80000000u;
+      if (DUAL) aoff2[m] = ok ? (unsigned)ipx2 * (unsigned)(a.Cin2 * 2) + g * 16 : 0x80000000u;
       yoff[m] = ok ? (unsigned)px * (unsigned)(a.Cout * 2) + (unsigned)(n0 + 8 * g) * 2 : 0x80000000u;
     }
   };
@@ -123,9 +130,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
   f32x4_t acc[MT][NT];
   u32x4_t xa[XS][MT];
 
-  auto load_a = [&](u32x4_t (&dst)[MT], const unsigned (&off)[MT], int s) {
+  auto load_a = [&](u32x4_t (&dst)[MT], const unsigned (&off)[MT], const unsigned (&off2)[MT2], int s) {
+    if (DUAL && s >= ks1) {     // (uniform: s and ks1 are scalars)
 #pragma unroll
-    for (int m = 0; m < MT; ++m) dst[m] = __builtin_amdgcn_raw_buffer_load_b128(rx, off[m], s * 64, 0);
+      for (int m = 0; m < MT; ++m) dst[m] = __builtin_amdgcn_raw_buffer_load_b128(rx2, off2[DUAL ? m : 0], (s - ks1) * 64, 0);
+    } else {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) dst[m] = __builtin_amdgcn_raw_buffer_load_b128(rx, off[m], s * 64, 0);
+    }
   };
   auto init_acc = [&]() {
 #pragma unroll
@@ -271,11 +283,11 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         if (CH % (T * 16) == 0 || o < CH) *(u32x4_t*)(sW + s * CH + o) = *(const u32x4_t*)(src + o);
       }
     }
-    unsigned aoff[MT], yoff[MT], aoff_n[MT], yoff_n[MT];
-    tile_offsets(mt, aoff, yoff);
-    tile_offsets(mt + mt_step, aoff_n, yoff_n);
+    unsigned aoff[MT], yoff[MT], aoff_n[MT], yoff_n[MT], aoff2[MT2], aoff2_n[MT2];
+    tile_offsets(mt, aoff, yoff, aoff2);
+    tile_offsets(mt + mt_step, aoff_n, yoff_n, aoff2_n);
 #pragma unroll
-    for (int u = 0; u < KSC; ++u) load_a(xa[u], aoff, u);   // the whole first tile
+    for (int u = 0; u < KSC; ++u) load_a(xa[u], aoff, aoff2, u);   // the whole first tile
     prologue_like_an_epilogue(yoff);
     __syncthreads();
     const lds_u8_t sWl = (lds_u8_t)sW;
@@ -296,19 +308,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         lds_u8_t snext = u + 1 < KSC ? sbase + CH : sWl;   // (past the last K step: step 0, the next tile's)
         asm volatile("" : "+v"(snext));
         compute(sbase, snext, xa[u], std::true_type{});
-        load_a(xa[u], aoff_n, u);
+        load_a(xa[u], aoff_n, aoff2_n, u);
         sbase = snext;
       }
       epilogue(yoff, yoff_n);
       mt += mt_step;
 #pragma unroll
       for (int m = 0; m < MT; ++m) { aoff[m] = aoff_n[m]; yoff[m] = yoff_n[m]; }
-      tile_offsets(mt + mt_step, aoff_n, yoff_n);
+      tile_offsets(mt + mt_step, aoff_n, yoff_n, aoff2_n);
     }
   } else {
     // ---- K-outer loop, weights register-staged through a two-stage LDS ring ----
-    unsigned aoff[MT], yoff[MT];
-    tile_offsets(mt, aoff, yoff);
+    unsigned aoff[MT], yoff[MT], aoff2[MT2];
+    tile_offsets(mt, aoff, yoff, aoff2);
     u32x4_t rb[RD];
     auto load_b = [&](int s) {
       const unsigned char* src = (const unsigned char*)a.wp + w_goff(s);
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
     };
     load_b(0);
 #pragma unroll
-    for (int u = 0; u < PA; ++u) load_a(xa[u], aoff, u);
+    for (int u = 0; u < PA; ++u) load_a(xa[u], aoff, aoff2, u);
     store_b(0);
     __syncthreads();
     init_acc();
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         if (cur + 1 < KS) load_b(cur + 1);
         load_frag(fr[0], (lds_u8_t)sW + (u & 1) * CH + lane * 16);
         compute((lds_u8_t)sW + (u & 1) * CH, (lds_u8_t)sW, xa[u], std::false_type{});
-        if (cur + PA < KS) load_a(xa[u], aoff, cur + PA);
+        if (cur + PA < KS) load_a(xa[u], aoff, aoff2, cur + PA);
         if (cur + 1 < KS) store_b((u + 1) & 1);
         __syncthreads();
       }
@@ -389,22 +401,47 @@ __global__ void pack_pw_kernel(const float* __restrict__ w, const float* __restr
   }
 }
 
+// K-concatenation of a block-closing conv and its shortcut conv (see spk_launch_pw_dual_prep in spk_common.h)
+__global__ void pw_dual_prep_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ s1,
+                                    const float* __restrict__ s2, const float* __restrict__ b1, const float* __restrict__ b2,
+                                    float* __restrict__ wcat, float* __restrict__ scale_out, float* __restrict__ shift_out,
+                                    int cout, int cin1, int cin2) {
+  const int K = cin1 + cin2;
+  const long total = (long)cout * K;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / K), k = (int)(i % K);
+    const float m = fmaxf(fabsf(s1[c]), fabsf(s2[c]));
+    int e = 0;
+    if (m > 0.f && m < INFINITY) (void)frexpf(m, &e), e -= 1;    // 2^e <= m < 2^(e+1)
+    const float inv = ldexpf(1.f, -e);
+    wcat[i] = k < cin1 ? w1[(size_t)c * cin1 + k] * s1[c] * inv : w2[(size_t)c * cin2 + (k - cin1)] * s2[c] * inv;
+    if (k == 0) {
+      scale_out[c] = ldexpf(1.f, e);
+      shift_out[c] = b1[c] + b2[c];
+    }
+  }
+}
+
 template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC>
 int launch_k(const PwConvArgs& a, hipStream_t s) {
   constexpr int BN = 32 * NPAIR, BM = WAVES * MT * 16, CH = NPAIR * NB * 2048;
   constexpr bool RESIDENT = KSC > 0;
-  const int KS = a.Cin / 32;
+  const bool dual = a.x2 != nullptr;
+  const int KS = (a.Cin + (dual ? a.Cin2 : 0)) / 32;
   if (a.Cout % BN) return -3;
   if (RESIDENT ? KS != KSC : (KS % PA || KS < PA)) return -3;
+  if (dual && a.res) return -3;   // (the fused shortcut IS the second source)
   const int n_tiles = a.Cout / BN, m_tiles = (a.M + BM - 1) / BM;
   const size_t lds = (size_t)(RESIDENT ? KS : 2) * CH + 2 * BN * 4;
   if (lds > 160 * 1024) return -3;
-  auto k = a.res ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true>
-                 : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false>;
-  static bool attr[2] = {false, false};
-  if (!attr[a.res != nullptr]) {
+  auto k = dual ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false, true>
+                : (a.res ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true>
+                         : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false>);
+  static bool attr[3] = {false, false, false};
+  const int which = dual ? 2 : (a.res != nullptr);
+  if (!attr[which]) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-    attr[a.res != nullptr] = true;
+    attr[which] = true;
   }
   int grid;
   if (RESIDENT) {
@@ -429,7 +466,7 @@ int launch_k(const PwConvArgs& a, hipStream_t s) {
 // resident flavour of one tile shape: dispatch on the K-step count it was compiled for
 template <int DT, int NB, int MT, int NPAIR, int WAVES, int KMAX>
 int launch_res(const PwConvArgs& a, hipStream_t s) {
-  const int KS = a.Cin / 32;
+  const int KS = (a.Cin + (a.x2 ? a.Cin2 : 0)) / 32;
   if (KS == 2) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 2>(a, s);
   if constexpr (KMAX >= 4) if (KS == 4) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 4>(a, s);
   if constexpr (KMAX >= 8) if (KS == 8) return launch_k<DT, NB, MT, NPAIR, WAVES, 2, 8>(a, s);
@@ -465,9 +502,20 @@ int spk_pw_num_configs() { return kNumCfgs; }
 // 0 ok, -1 HIP error, -2 unsupported problem, -3 this config does not fit the problem
 int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s) {
   if (a.Cin % 64 || a.Cout % 64 || a.M <= 0) return -2;
+  if (a.x2 && (a.Cin2 % 64 || (size_t)a.x2_bytes >= 0x80000000ull)) return -2;
   if ((size_t)a.y_bytes >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull) return -2;
   if (a.dt == DT_F16) return a.nb == 2 ? launch_cfg<DT_F16, 2>(a, cfg, s) : launch_cfg<DT_F16, 1>(a, cfg, s);
   return -2;   // (bf16 training path: not instantiated yet)
+}
+
+int spk_launch_pw_dual_prep(const float* w1, const float* w2, const float* s1, const float* s2, const float* b1,
+                            const float* b2, float* wcat, float* scale_out, float* shift_out, int cout, int cin1,
+                            int cin2, hipStream_t s) {
+  const long total = (long)cout * (cin1 + cin2);
+  const unsigned grid = (unsigned)std::min<long>((total + 255) / 256, 65535);
+  hipLaunchKernelGGL(pw_dual_prep_kernel, dim3(grid), dim3(256), 0, s, w1, w2, s1, s2, b1, b2, wcat, scale_out, shift_out,
+                     cout, cin1, cin2);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout, int cin, int dt, int nb, hipStream_t s) {
@@ -598,4 +646,90 @@ int spk_conv1x1_launch(const ConvArgs& a, const PwConvArgs& q, hipStream_t s) {
     if (r != -3) return r;
   }
   return spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr);
+}
+
+// The dual-source conv (block-closing 1x1 conv + 1x1 shortcut conv as one K-concatenated GEMM): conv_pw configurations
+// only (the implicit GEMM has no second source); the fastest is timed once per problem and persisted.
+namespace {
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int, int> Pw2Key;  // nb H W Cin H2 W2 Cin2 Cout s s2 N
+std::map<Pw2Key, int> g_pw2_choice;
+bool g_pw2_loaded = false;
+}  // namespace
+
+int spk_conv1x1_dual_launch(const PwConvArgs& q, hipStream_t s) {
+  if (!q.x2 || q.dt != DT_F16) return -3;
+  const bool tune = !getenv("SPK_AUTOTUNE") || atoi(getenv("SPK_AUTOTUNE")) != 0;
+  const Pw2Key key(q.nb, q.H, q.W, q.Cin, q.H2, q.W2, q.Cin2, q.Cout, q.stride, q.stride2, q.N);
+  int choice = -2;
+  {
+    std::lock_guard<std::mutex> lk(g_pw_mu);
+    if (!g_pw2_loaded) {
+      g_pw2_loaded = true;
+      if (const char* path = pw_cache_path())
+        if (FILE* f = fopen(path, "r")) {
+          char line[512];
+          while (fgets(line, sizeof line, f)) {
+            int v[12];
+            if (sscanf(line, "pw2 %d %d %d %d %d %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7],
+                       &v[8], &v[9], &v[10], &v[11]) == 12 && v[11] >= 0 && v[11] < kNumCfgs)
+              g_pw2_choice[Pw2Key(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10])] = v[11];
+          }
+          fclose(f);
+        }
+    }
+    auto it = g_pw2_choice.find(key);
+    if (it != g_pw2_choice.end()) choice = it->second;
+    else {
+      double best_ratio = 2.0 + 1e-9;   // a ragged tail batch re-uses the nearest tuned batch within a factor of two
+      for (const auto& kv : g_pw2_choice) {
+        Pw2Key k2 = kv.first;
+        const int n2 = std::get<10>(k2);
+        std::get<10>(k2) = q.N;
+        if (k2 != key) continue;
+        const double r = n2 > q.N ? (double)n2 / q.N : (double)q.N / n2;
+        if (r <= best_ratio) { best_ratio = r; choice = kv.second; }
+      }
+    }
+  }
+  if (choice == -2 && !tune) {
+    for (int cfg : {5, 1, 0, 3, 4})   // no tuning: the first ring configuration that fits
+      if (spk_pw_launch(q, cfg, s) == 0) return 0;
+    return -3;
+  }
+  if (choice == -2) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1;
+    float best = 1e30f;
+    choice = -1;
+    for (int cfg = 0; cfg < kNumCfgs; ++cfg) {
+      if (spk_pw_launch(q, cfg, s)) continue;
+      (void)hipEventRecord(e0, s);
+      for (int r = 0; r < 3; ++r) spk_pw_launch(q, cfg, s);
+      (void)hipEventRecord(e1, s);
+      if (hipEventSynchronize(e1) != hipSuccess) continue;
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      if (getenv("SPK_TUNE_LOG") && atoi(getenv("SPK_TUNE_LOG")) > 1)
+        fprintf(stderr, "[spk pw2 cand] %dx%d C%d+%d->%d nb%d: pw %d %.1f us\n", q.Ho, q.Wo, q.Cin, q.Cin2, q.Cout, q.nb, cfg,
+                ms * 1000.f / 3.f);
+      if (ms < best) { best = ms; choice = cfg; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (choice < 0) return -3;
+    {
+      std::lock_guard<std::mutex> lk(g_pw_mu);
+      g_pw2_choice[key] = choice;
+      if (const char* path = pw_cache_path())
+        if (FILE* f = fopen(path, "a")) {
+          fprintf(f, "pw2 %d %d %d %d %d %d %d %d %d %d %d %d\n", q.nb, q.H, q.W, q.Cin, q.H2, q.W2, q.Cin2, q.Cout, q.stride,
+                  q.stride2, q.N, choice);
+          fclose(f);
+        }
+    }
+    if (getenv("SPK_TUNE_LOG"))
+      fprintf(stderr, "[spk tune 1x1 dual] N%d %dx%d C%d+%d->%d nb%d: pw %d (%.1f us)\n", q.N, q.Ho, q.Wo, q.Cin, q.Cin2,
+              q.Cout, q.nb, choice, best * 1000.f / 3.f);
+  }
+  return spk_pw_launch(q, choice, s);
 }

@@ -40,6 +40,13 @@ struct Layer {
   size_t wpw_off = 0;             // fragment-ordered image of a 1x1 conv's weights (conv_pw.hip), when pw_ok
   bool pw_ok = false;             // 1x1, stride 1 or 2, no padding anywhere, channels multiples of 64
   bool c3_ok = false;             // 3x3 stride 1 pad 1, cin % 64 == 0, cout % 256 == 0: conv_c3.hip (image at wpw_off)
+  // eval: a block-closing 1x1 conv and the 1x1 shortcut (downsample) conv of its block as ONE K-concatenated GEMM
+  // (conv_pw.hip, PwConvArgs::x2): the shortcut tensor is neither written nor re-read
+  int dual_src = -1;              // block-closing conv: index of the shortcut conv it absorbs, or -1
+  int fused_into = -1;            // shortcut conv: index of the block-closing conv that absorbs it, or -1
+  bool dual_ok = false;           // images packed for the current precision settings (spk_commit)
+  size_t wdual_off = 0;           // fragment-ordered concatenated weights (elements into spk_model::wdual)
+  size_t sdual_off = 0;           // [2^e per cout][summed shifts] (floats into spk_model::sdual)
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)
@@ -72,6 +79,10 @@ struct spk_model {
   bf16_t* wpack = nullptr;     // bf16 conv weights, [Cout][K] per layer
   float* scale_bias = nullptr; // eval-BN folded scale/bias per conv
   float* dwpack = nullptr;     // fp32 tap-major weights of depthwise / 3x3-stem layers (EfficientNet)
+  bf16_t* wdual = nullptr;     // K-concatenated weight images of the fused (block-closing + shortcut) convs
+  float* sdual = nullptr;      // their epilogue factors
+  bool fuse_ds = true;         // SPK_FUSE_DS=0 turns the fusion off
+  std::vector<char> stale;     // per tensor: the last eval forward did not write it (a fused-away shortcut tensor)
   bool effnet = false;         // EfficientNet graph (widths that are not multiples of 64, depthwise / SE / SiLU ops): its
                                // TRAINING plan pads every activation tensor to a multiple of 64 channels (train_effnet.hip)
   bool plan_pad = false;       // the current activation plan is the channel-padded one

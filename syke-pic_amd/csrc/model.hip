@@ -174,6 +174,7 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     P.pooled_by_stem = true;
   }
   if (const char* e = getenv("SPK_FUSE_STEM_POOL")) m->fuse_stem_pool = atoi(e) != 0;
+  if (const char* e = getenv("SPK_FUSE_DS")) m->fuse_ds = atoi(e) != 0;
   for (int oi : order) {
     Layer& L = m->layers[oi];
     const std::string nm = L.d.name, bn = L.d.bn;
@@ -257,8 +258,32 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     L.sb_off = sb;
     sb += (size_t)2 * L.cout_p;
   }
+  // block-closing 1x1 conv + the 1x1 shortcut conv whose output only it adds: one K-concatenated GEMM in the eval path
+  size_t wdual = 0, sdual = 0;
+  for (size_t i = 0; i < m->layers.size(); ++i) {
+    Layer& L = m->layers[i];
+    if (L.d.kind != SPK_OP_CONV || !L.pw_ok || L.d.res < 0 || L.d.stride != 1) continue;
+    for (size_t j = 0; j < m->layers.size(); ++j) {
+      Layer& D = m->layers[j];
+      if (D.d.kind != SPK_OP_CONV || D.d.dst != L.d.res || !D.pw_ok || !D.side_branch || D.d.relu != 0 || D.d.res >= 0 ||
+          D.d.cout != L.d.cout || D.fused_into >= 0)
+        continue;
+      int readers = 0;
+      for (const Layer& Q : m->layers) readers += (Q.d.src == D.d.dst) + (Q.d.kind == SPK_OP_CONV && Q.d.res == D.d.dst);
+      if (readers != 1) continue;
+      L.dual_src = (int)j;
+      D.fused_into = (int)i;
+      L.wdual_off = wdual;
+      wdual += (size_t)2 * L.d.cout * (L.d.cin + D.d.cin);
+      L.sdual_off = sdual;
+      sdual += (size_t)2 * L.d.cout;
+    }
+  }
+  m->stale.assign(m->n_tensors, 0);
   if (hipMalloc((void**)&m->wpack, std::max<size_t>(wpack, 8) * 2) != hipSuccess ||
       hipMalloc((void**)&m->dwpack, std::max<size_t>(dwp, 8) * 4) != hipSuccess ||
+      hipMalloc((void**)&m->wdual, std::max<size_t>(wdual, 8) * 2) != hipSuccess ||
+      hipMalloc((void**)&m->sdual, std::max<size_t>(sdual, 8) * 4) != hipSuccess ||
       hipMalloc((void**)&m->scale_bias, std::max<size_t>(sb, 8) * 4) != hipSuccess) {
     spk_model_destroy(m);
     return fail(SPK_ERR_HIP, "hipMalloc(packed weights) failed");
@@ -284,6 +309,8 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->wpack) hipFree(m->wpack);
   if (m->scale_bias) hipFree(m->scale_bias);
   if (m->dwpack) hipFree(m->dwpack);
+  if (m->wdual) hipFree(m->wdual);
+  if (m->sdual) hipFree(m->sdual);
   if (m->w8pack) hipFree(m->w8pack);
   if (m->fp8_shadow) hipFree(m->fp8_shadow);
   if (m->s8) hipFree(m->s8);
@@ -496,6 +523,38 @@ int spk_commit(spk_model* m) {
     if (L.c3_ok && m->infer_dt == DT_F16 &&
         spk_launch_pack_c3(m->P(L.p_w), m->wpack + L.wpw_off, L.d.cout, L.d.cin, layer_split(m, L) ? 2 : 1, m->stream))
       return fail(SPK_ERR_HIP, "pack_c3 launch failed");
+  }
+  // fused (block-closing + shortcut) convs: K-concatenated weights with both eval-BN scales folded in, normalised per
+  // cout by a power of two (exact in the fp32 epilogue), in fragment order
+  {
+    size_t tmp_floats = 0;
+    for (Layer& L : m->layers) {
+      L.dual_ok = false;
+      if (L.dual_src < 0 || m->infer_dt != DT_F16) continue;
+      const Layer& D = m->layers[L.dual_src];
+      if ((layer_split(m, L) != 0) != (layer_split(m, D) != 0)) continue;   // one image, one precision
+      tmp_floats = std::max(tmp_floats, (size_t)L.d.cout * (L.d.cin + D.d.cin));
+    }
+    float* wcat = nullptr;
+    if (tmp_floats) HIP_TRY(hipMalloc((void**)&wcat, tmp_floats * 4));
+    for (Layer& L : m->layers) {
+      if (L.dual_src < 0 || m->infer_dt != DT_F16) continue;
+      const Layer& D = m->layers[L.dual_src];
+      if ((layer_split(m, L) != 0) != (layer_split(m, D) != 0)) continue;
+      const float* sL = m->scale_bias + L.sb_off;
+      const float* sD = m->scale_bias + D.sb_off;
+      float* sd = m->sdual + L.sdual_off;
+      int r = spk_launch_pw_dual_prep(m->P(L.p_w), m->P(D.p_w), sL, sD, sL + L.cout_p, sD + D.cout_p, wcat, sd,
+                                      sd + L.d.cout, L.d.cout, L.d.cin, D.d.cin, m->stream);
+      if (!r) r = spk_launch_pack_pw(wcat, nullptr, m->wdual + L.wdual_off, L.d.cout, L.d.cin + D.d.cin, DT_F16,
+                                     layer_split(m, L) ? 2 : 1, m->stream);
+      if (r) { (void)hipFree(wcat); return fail(SPK_ERR_HIP, "dual-source weight packing failed"); }
+      L.dual_ok = true;
+    }
+    if (wcat) {
+      HIP_TRY(hipStreamSynchronize(m->stream));
+      (void)hipFree(wcat);
+    }
   }
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
@@ -752,9 +811,20 @@ static bool stem_pool_fused(const spk_model* m, const Layer& L) {
   return L.fuse_pool >= 0 && m->fuse_stem_pool && !m->precise_res && !m->force_unfused;
 }
 
+// eval: does the block-closing conv L absorb its shortcut conv in this forward?
+static bool dual_active(const spk_model* m, const Layer& L) {
+  return m->fuse_ds && L.dual_src >= 0 && L.dual_ok && m->infer_dt == DT_F16 && !m->precise_res && !m->force_unfused &&
+         !m->side;
+}
+
 static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
+  if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) {
+    m->stale[L.d.dst] = 1;   // computed inside the block-closing conv's kernel; read_activation recomputes it on demand
+    return SPK_OK;
+  }
+  if (L.d.dst < (int)m->stale.size()) m->stale[L.d.dst] = 0;
   if (L.mode == CONV_MODE_STEM3) {
     const float* sc = m->scale_bias + L.sb_off;
     if (spk_launch_stem3x3((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
@@ -796,6 +866,28 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     m->stale_stem_t = L.d.dst;
   } else if (L.fuse_pool >= 0) {
     m->stale_stem_t = -1;
+  }
+  if (dual_active(m, L) && !a.y_lo) {
+    Layer& D = m->layers[L.dual_src];
+    const TDim& din = m->tdims[D.d.src];
+    PwConvArgs q;
+    memset(&q, 0, sizeof q);
+    q.x = a.x; q.wp = m->wdual + L.wdual_off; q.y = a.y;
+    q.scale = m->sdual + L.sdual_off; q.shift = q.scale + L.d.cout;
+    q.N = nb; q.H = in.h; q.W = in.w; q.Ho = o.h; q.Wo = o.w; q.stride = 1;
+    q.Cin = a.Cin; q.Cout = a.Cout; q.M = a.M; q.relu = a.relu; q.dt = DT_F16; q.nb = a.splitw ? 2 : 1;
+    q.x_bytes = a.x_bytes; q.y_bytes = (unsigned)((size_t)a.M * a.Cout * 2);
+    q.x2 = (const bf16_t*)m->TI(D.d.src); q.Cin2 = D.d.cin; q.H2 = din.h; q.W2 = din.w; q.stride2 = D.d.stride;
+    q.x2_bytes = (unsigned)((size_t)nb * din.h * din.w * din.c * 2);
+    const int r = spk_conv1x1_dual_launch(q, m->stream);
+    if (r == 0) return SPK_OK;
+    if (r != -3) return fail(SPK_ERR_HIP, std::string("fused 1x1 conv launch failed for ") + L.d.name);
+    // no configuration fits this problem: the shortcut conv on its own after all, then this layer the usual way
+    m->force_unfused = true;
+    const int rd = run_conv_eval(m, D, nb);
+    m->force_unfused = false;
+    if (rd != SPK_OK) return rd;
+    L.dual_ok = false;
   }
   if (L.pw_ok && a.dt == DT_F16 && !a.res_lo && !a.y_lo && !a.cin_s && !a.cout_s) {
     PwConvArgs q;
@@ -1192,6 +1284,16 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
   const size_t cnt = (size_t)n * d.h * d.w * d.c;
   if ((int64_t)((size_t)n * d.h * d.w * cl) != numel) return fail(SPK_ERR_ARG, "read_activation: size mismatch");
   HIP_TRY(hipSetDevice(m->device));
+  if (t < (int)m->stale.size() && m->stale[t] && m->last_eval_nb > 0) {
+    // a shortcut conv that the last forward computed inside its block-closing conv: run it alone (its input is still there)
+    for (Layer& L : m->layers)
+      if (L.d.kind == SPK_OP_CONV && L.d.dst == t) {
+        m->force_unfused = true;
+        const int r = run_conv_eval(m, L, m->last_eval_nb);
+        m->force_unfused = false;
+        if (r != SPK_OK) return r;
+      }
+  }
   if (t == m->stale_stem_t && m->last_eval_nb > 0) {
     // the last forward computed stem + max-pool in one kernel and never wrote this tensor: run the stem layer alone
     // (its input is still in the arena)
@@ -1303,6 +1405,13 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
       const double real_in = L.mode == CONV_MODE_STEM ? (double)nb * in.h * in.w * 8 : in_b;
       by = real_in + out_b + (L.d.res >= 0 ? out_b : 0) + (double)L.d.cout * L.kpad * 2;
       snprintf(nm, sizeof nm, "%s", L.d.name);
+      if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) by = 0;   // computed inside the block-closing conv
+      if (dual_active(m, L)) {   // no shortcut tensor: reads both inputs, writes the output once
+        const Layer& D = m->layers[L.dual_src];
+        const TDim& din = m->tdims[D.d.src];
+        by = in_b + (double)nb * o.h * o.w * din.c * 2 + out_b + (double)L.d.cout * (L.d.cin + D.d.cin) * 2;
+        snprintf(nm, sizeof nm, "%s+%s", L.d.name, D.d.name);
+      }
       if (stem_pool_fused(m, L)) {   // the kernel writes the pooled tensor only
         const TDim& po = m->tdims[m->layers[L.fuse_pool].d.dst];
         by = real_in + (double)nb * po.h * po.w * po.c * 2 + (double)L.d.cout * L.kpad * 2;

@@ -124,8 +124,24 @@ struct PwConvArgs {
   unsigned int x_bytes, y_bytes;
   int ablate;           // timing experiments only: 1 drop the output stores, 2 the shortcut loads, 4 the activation loads
                         // (zero-record buffer descriptors: the instructions still issue, the range check drops them)
+  // Second activation source (K-concatenated GEMM: K steps [0, Cin/32) read x, steps [Cin/32, (Cin+Cin2)/32) read x2 at
+  // the same output pixel through its own stride): a block-closing 1x1 conv and the 1x1 shortcut (downsample) conv of
+  // the same block as ONE kernel - the shortcut tensor is never written or re-read.  x2 == null: plain conv.
+  const bf16_t* x2;     // [N,H2,W2,Cin2]
+  int Cin2, H2, W2, stride2;
+  unsigned int x2_bytes;
 };
 int spk_pw_num_configs();
+// K-concatenation of two 1x1 convs that are added (w1 [Cout][Cin1] with eval-BN scale s1, w2 [Cout][Cin2] with s2):
+// wcat[c] = [w1[c] * s1[c] | w2[c] * s2[c]] / 2^e[c], 2^e[c] = the largest power of two <= max(|s1[c]|, |s2[c]|) (so the
+// 16-bit hi + lo images keep their precision whatever the BatchNorm scales are), scale_out[c] = 2^e[c] exactly,
+// shift_out[c] = b1[c] + b2[c].
+int spk_launch_pw_dual_prep(const float* w1, const float* w2, const float* s1, const float* s2, const float* b1,
+                            const float* b2, float* wcat, float* scale_out, float* shift_out, int cout, int cin1,
+                            int cin2, hipStream_t s);
+// the dual-source conv by its fastest configuration (timed once per problem, "pw2 ..." lines of SPK_TUNE_CACHE);
+// -3: no configuration fits
+int spk_conv1x1_dual_launch(const PwConvArgs& q, hipStream_t s);
 int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s);   // -3: this config does not fit the problem
 int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout, int cin, int dt, int nb, hipStream_t s);
 // eval path: the faster of the implicit GEMM (a) and conv_pw (q) for this problem, tuned once and cached
