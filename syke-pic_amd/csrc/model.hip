@@ -1405,10 +1405,11 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
       const double real_in = L.mode == CONV_MODE_STEM ? (double)nb * in.h * in.w * 8 : in_b;
       by = real_in + out_b + (L.d.res >= 0 ? out_b : 0) + (double)L.d.cout * L.kpad * 2;
       snprintf(nm, sizeof nm, "%s", L.d.name);
-      if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) by = 0;   // computed inside the block-closing conv
+      if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) by = fl = 0;   // computed inside the block-closing conv
       if (dual_active(m, L)) {   // no shortcut tensor: reads both inputs, writes the output once
         const Layer& D = m->layers[L.dual_src];
         const TDim& din = m->tdims[D.d.src];
+        fl += 2.0 * nb * o.h * o.w * (double)D.d.cout * D.d.cin;
         by = in_b + (double)nb * o.h * o.w * din.c * 2 + out_b + (double)L.d.cout * (L.d.cin + D.d.cin) * 2;
         snprintf(nm, sizeof nm, "%s+%s", L.d.name, D.d.name);
       }
