@@ -96,7 +96,7 @@ def test_gradient_slices_are_reported_back_to_front_and_complete():
 def test_bench_two_ranks_like_the_driver(tmp_path):
     env = dict(os.environ, SPK_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29517", str(ROOT / "bench.py"), "--gpus", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2",
            "--steps", "2", "--warmup", "1", "--batch", "16", "--size", "96", "--network", "resnet18",
            "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -113,7 +113,7 @@ def test_bench_two_ranks_efficientnet_training(tmp_path):
     depthwise gradients travel in the same flat buffer the all-reduce sums."""
     env = dict(os.environ, SPK_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29531", str(ROOT / "bench.py"), "--gpus", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"), "--gpus", "2",
            "--steps", "2", "--warmup", "1", "--batch", "8", "--size", "64", "--network", "efficientnet_b0",
            "--mode", "train", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
