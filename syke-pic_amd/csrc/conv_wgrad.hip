@@ -33,6 +33,7 @@ struct WgradArgs {
   int M, Ktot;
   int pix_per_split;
   unsigned int x_bytes, dy_bytes;
+  int xcd_map;   // 1: XCD-aware block order (all tiles of a pixel split on one XCD)
 };
 
 namespace {
@@ -82,9 +83,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a, int co_til
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  const int co0 = (blockIdx.x % co_tiles) * BCO;
-  const int kcol0 = (blockIdx.x / co_tiles) * BCI;
-  const int split = blockIdx.y;
+  // Block -> (tile, pixel split).  Blocks are dispatched in linear order (x fastest) round-robin over the 8 XCDs, each
+  // with its own L2.  All tiles of ONE split read the same pixel rows of x and dy, so they are placed on ONE XCD,
+  // back to back: that XCD's L2 fetches the rows once for all of them (with the plain (x = tile, y = split) order the
+  // tiles of a split were spread over all 8 XCDs and every L2 fetched the same rows).  SPK_WGRAD_XCD=0: plain order.
+  int tile_id = blockIdx.x, split = blockIdx.y;
+  if (a.xcd_map) {
+    const int T = gridDim.x, S = gridDim.y;
+    const int lin = blockIdx.y * T + blockIdx.x;
+    const int full = (S >> 3) << 3;                 // splits covered by whole groups of 8
+    if (lin < full * T) {
+      const int xcd = lin & 7, j = lin >> 3;
+      tile_id = j % T;
+      split = (j / T) * 8 + xcd;
+    } else {
+      const int r = lin - full * T;
+      tile_id = r % T;
+      split = full + r / T;
+    }
+  }
+  const int co0 = (tile_id % co_tiles) * BCO;
+  const int kcol0 = (tile_id / co_tiles) * BCI;
   const int p_begin = split * a.pix_per_split;
   const int p_end = min(a.M, p_begin + a.pix_per_split);
 
@@ -338,6 +357,8 @@ int spk_wgrad_launch(const bf16_t* x, const bf16_t* dy, float* slabs, int N, int
   a.M = N * Ho * Wo;
   a.Ktot = stem ? 256 : k * k * Cin;
   a.pix_per_split = pix_per_split;
+  static const int xcd_map = getenv("SPK_WGRAD_XCD") ? atoi(getenv("SPK_WGRAD_XCD")) : 1;
+  a.xcd_map = xcd_map;
   a.x_bytes = (unsigned)((size_t)N * H * W * (stem ? 4 : Cin) * 2);
   a.dy_bytes = (unsigned)((size_t)a.M * Cout * 2);
   if (stem) {
