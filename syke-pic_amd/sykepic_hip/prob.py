@@ -222,9 +222,41 @@ def _finish(rows, error, what, classes, csv_path, dist):
         probabilities_to_csv(probabilities, classes, csv_path)
 
 
-def launch_sample(sample_path, net, params, out_dir, force=False, dist=None):
+def read_sample_ahead(sample_path, params, out_dir, force):
+    """What `launch_sample` needs from the disk, done ahead of time on a reader thread: the `.adc` table and the `.roi`
+    blob in device memory, copied on a side stream (np.fromfile and the host->device copy release the GIL).  Returns
+    (SampleOnGpu | exception | None, event): None = nothing to read ahead (CSV exists and not forced, or the transform has
+    no GPU path); an exception is re-raised inside `launch_sample`, where the sample's error handling lives."""
+    from . import files, gpu_preprocess
+    sample_path = Path(sample_path)
+    csv_path = files.sample_csv_path(sample_path, out_dir, suffix=FILE_SUFFIX)
+    if (csv_path.is_file() and not force) or not gpu_preprocess.supported(params.transform, params.img_shape[0]):
+        return None, None
+    try:
+        side = _reader_stream(params.device)
+        with torch.cuda.stream(side):
+            gs = gpu_preprocess.SampleOnGpu(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"), params.device)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return gs, ev
+    except Exception as e:  # noqa: BLE001
+        return e, None
+
+
+_READER_STREAMS = {}
+
+
+def _reader_stream(device):
+    key = str(device)
+    if key not in _READER_STREAMS:
+        _READER_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _READER_STREAMS[key]
+
+
+def launch_sample(sample_path, net, params, out_dir, force=False, dist=None, ahead=None):
     """First half of `process_sample`: parse the sample, put its `.roi` blob on the GPU and queue preprocessing +
-    forward for this rank's shard.  Returns None (CSV exists, not forced) or the state `complete_sample` finishes."""
+    forward for this rank's shard.  Returns None (CSV exists, not forced) or the state `complete_sample` finishes.
+    `ahead`: the result of `read_sample_ahead` for this sample, if a reader thread already fetched it."""
     from . import dp, files, ifcb
     sample_path = Path(sample_path)
     sample = sample_path.name
@@ -238,8 +270,18 @@ def launch_sample(sample_path, net, params, out_dir, force=False, dist=None):
         from . import gpu_preprocess
         if gpu_preprocess.supported(params.transform, params.img_shape[0]):
             # .roi bytes -> GPU -> resized/bordered uint8 batches -> forward: no PNGs, no per-ROI host work
-            gs = gpu_preprocess.SampleOnGpu(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"),
-                                            params.device)
+            gs, ev = ahead if ahead is not None else (None, None)
+            if isinstance(gs, Exception):
+                raise gs
+            if gs is None:
+                gs = gpu_preprocess.SampleOnGpu(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"),
+                                                params.device)
+            elif ev is not None:
+                cur = torch.cuda.current_stream(params.device)
+                cur.wait_event(ev)                 # the blob was copied on the reader's stream ...
+                gs.blob.record_stream(cur)         # ... and its memory must not be recycled under this stream's kernels
+                if gs.rois is not None:
+                    gs.rois.record_stream(cur)
             th, tw = params.transform.target_dims
             code = gpu_preprocess.border_code(params.transform)
             lo, hi = dp.shard_range(len(gs), rank, world)
@@ -330,9 +372,12 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
         for sample, img_paths in it:
             process_images(img_paths, net, params, Path(out_dir) / f"{sample}{FILE_SUFFIX}.csv", force, dist)
         return None
+    sample_paths = list(sample_paths)
     it = sample_paths
     if progress_bar and tqdm:
         it = tqdm(it, desc="Processing samples")
+    # A reader thread fetches sample k+2's files (.adc table, .roi blob -> device memory on a side stream) while sample
+    # k+1 is parsed into batches and launched.
     # Two samples in flight: while the GPU runs sample k+1 the previous sample is read back, formatted and written
     # (the reference handles one sample at a time, probability.py:97-114; same files, same per-sample error
     # handling).  Single process: the second half runs on a writer thread (device->host copy, numpy formatting and
@@ -341,8 +386,8 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
     done = set()
     pending = None          # (sample path, state of launch_sample) or a Future of the writer thread
     pool = None
+    from concurrent.futures import ThreadPoolExecutor
     if dist is None:
-        from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sykepic-csv")
 
     def guarded(fn, sample_path):
@@ -364,9 +409,16 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
         if name is not None:
             done.add(name)
 
+    reader = None
+    paths = list(sample_paths)
+    if dist is None and paths:
+        reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="sykepic-read")
+    nxt = reader.submit(read_sample_ahead, paths[0], params, out_dir, force) if reader else None
     try:
-        for sample_path in it:
-            state = guarded(lambda: launch_sample(sample_path, net, params, out_dir, force, dist) or "skip", sample_path)
+        for i, sample_path in enumerate(it):
+            ahead = nxt.result() if nxt is not None else None
+            nxt = reader.submit(read_sample_ahead, paths[i + 1], params, out_dir, force) if reader and i + 1 < len(paths) else None
+            state = guarded(lambda: launch_sample(sample_path, net, params, out_dir, force, dist, ahead) or "skip", sample_path)
             finish(pending)
             pending = None
             if state == "skip":
@@ -377,6 +429,8 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
+        if reader is not None:
+            reader.shutdown(wait=True)
     return done
 
 
