@@ -28,6 +28,7 @@
 // 16-bit values are pooled, exactly what the separate kernel reads, so the result is bit-identical to the
 // two-kernel path (max commutes with the monotonic rounding anyway).
 #include "spk_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -50,8 +51,9 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sW = smem;                          // [NW][64][512 B]
   unsigned char* const sP = smem + NW * W_BYTES;           // [2][PATCH_BYTES]
-  float* const sE = (float*)(sP + 2 * PATCH_BYTES);        // [4 waves][16][EPI_LD]
-  unsigned char* const sT = (unsigned char*)(sE + 4 * 16 * EPI_LD);   // POOL: [16][16] stem pixels x 128 B
+  float* const sE = (float*)(sP + 2 * PATCH_BYTES);        // [4 waves][16][EPI_LD]   (not POOL)
+  unsigned char* const sH = sP + 2 * PATCH_BYTES;          // POOL: [16 rows][7 pooled columns] x HSTRIDE bytes
+  constexpr int HSTRIDE = 144;                             // 128 B of channels + 16: conflict-free 16-byte writes
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,7 +64,11 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
   // ---- weights -> LDS, once ----
   for (int c = tid; c < NW * 64 * 32; c += 256) {
     const int ch = c & 31, row = (c >> 5) & 63, half = c >> 11;
-    const u32x4_t v = *(const u32x4_t*)(a.w + ((size_t)(half * 64 + row) * 256 + ch * 8));
+    // POOL: swapped MFMA operand roles (weights = A, rows = couts).  LDS row q holds cout 32(q>>5) + 8((q&15)>>2) +
+    // 4((q>>4)&1) + (q&3), so that a lane's accumulators of the tile pair (2P, 2P+1) are couts 32P + 8(lane>>4) .. +7 of
+    // ONE pixel: the epilogue runs from registers (conv_pw.hip's arrangement), no transposition through LDS.
+    const int srow = POOL ? 32 * (row >> 5) + 8 * ((row & 15) >> 2) + 4 * ((row >> 4) & 1) + (row & 3) : row;
+    const u32x4_t v = *(const u32x4_t*)(a.w + ((size_t)(half * 64 + srow) * 256 + ch * 8));
     *(u32x4_t*)(sW + half * W_BYTES + row * W_ROW_BYTES + ((ch ^ (row & 15)) << 4)) = v;
   }
 
@@ -102,6 +108,16 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
     s1[j] = s2[j] = 0.f;
   }
   float* const epi = sE + wave * (16 * EPI_LD);
+  float psc[POOL ? 2 : 1][8], pbi[POOL ? 2 : 1][8];        // POOL: couts 32P + 8fq + 0..7
+  if (POOL) {
+#pragma unroll
+    for (int P = 0; P < 2; ++P)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        psc[P][j] = a.scale ? a.scale[32 * P + 8 * fq + j] : 1.f;
+        pbi[P][j] = a.bias ? a.bias[32 * P + 8 * fq + j] : 0.f;
+      }
+  }
 
   int tile = blockIdx.x;
   int buf = 0;
@@ -143,11 +159,64 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
-          if (SPLITW) acc[i][j] = mfma16<DT>(fa[i], fl[j], acc[i][j]);
+          if (POOL) {   // D rows = couts, columns = pixels
+            acc[i][j] = mfma16<DT>(fb[j], fa[i], acc[i][j]);
+            if (SPLITW) acc[i][j] = mfma16<DT>(fl[j], fa[i], acc[i][j]);
+          } else {
+            acc[i][j] = mfma16<DT>(fa[i], fb[j], acc[i][j]);
+            if (SPLITW) acc[i][j] = mfma16<DT>(fa[i], fl[j], acc[i][j]);
+          }
         }
     }
 
+    if (POOL) {
+      // ---- register epilogue + the horizontal half of the 3x3/2 max-pool ----
+      // lane (pixel column frow, cout group fq) holds 8 consecutive couts of tile row wave*4 + i per pair P: BN, ReLU,
+      // 16-bit rounding; the max over columns 2c, 2c+1, 2c+2 comes from the two right-hand neighbour lanes (DPP row
+      // shifts; zeros flow in past the tile edge and for pixels outside the stem output - every real value is >= +0
+      // after the ReLU, so zeros never win).  Lanes with an even column < 14 store the 7 pooled columns of the row.
+      typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+      const int ox = tx * TSTEP - TORG + frow;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int oy = ty * TSTEP - TORG + wave * 4 + i;
+        const bool inside = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+          u32x4_t ov = {0u, 0u, 0u, 0u};
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaxf(acc[i][2 * P][r] * psc[P][r] + pbi[P][r], 0.f);
+            v[4 + r] = fmaxf(acc[i][2 * P + 1][r] * psc[P][4 + r] + pbi[P][4 + r], 0.f);
+          }
+          if (inside) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = pack2<DT>(v[2 * j], v[2 * j + 1]) & 0x7fff7fffu;   // -0 -> +0
+          }
+          u32x4_t hm;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // column + 1 from the right-hand neighbour lane, column + 2 as the neighbour's neighbour.  `own` is pinned
+            // in its register across the first DPP move: hipcc 7.2 otherwise allocates the move's destination ON its
+            // source (v_mov_b32_dpp v4, v4 row_shl:2) although the source value is still needed for the max - the lane's
+            // own column dropped out of 3 of the 4 dwords (measured: pooled column 0, whose own column is padding,
+            // right; 40 % of the others wrong).
+            unsigned own = ov[j];
+            asm volatile("" : "+v"(own));
+            unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own, 0x101, 0xf, 0xf, true);
+            asm volatile("" : "+v"(n1), "+v"(own));
+            const u16x2_t t = __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, own), __builtin_bit_cast(u16x2_t, n1));
+            unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)n1, 0x101, 0xf, 0xf, true);
+            asm volatile("" : "+v"(n2));
+            const u16x2_t m = __builtin_elementwise_max(t, __builtin_bit_cast(u16x2_t, n2));
+            hm[j] = __builtin_bit_cast(unsigned, m);
+          }
+          if (!(frow & 1) && frow < 2 * POOL_OUT)
+            *(u32x4_t*)(sH + ((wave * 4 + i) * POOL_OUT + (frow >> 1)) * HSTRIDE + (32 * P + 8 * fq) * 2) = hm;
+        }
+      }
+    } else
     // ---- epilogue: one output row (16 pixels x 64 couts) per i ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -166,16 +235,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         const bool inside = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
         if (POOL) {
-          // the rounded tile goes to LDS; positions outside the stem output are the pool's padding: every real value
-          // is >= +0 after the ReLU, so zeros never win against the window's real maximum
-          u32x4_t ov = {0u, 0u, 0u, 0u};
-          if (inside) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j] * sc[j] + bi[j], 0.f);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) ov[j] = pack2<DT>(v[2 * j], v[2 * j + 1]) & 0x7fff7fffu;   // -0 -> +0
-          }
-          *(u32x4_t*)(sT + ((wave * 4 + i) * TILE + px) * 128 + ecol * 2) = ov;
+          // (the POOL variant takes the register epilogue above)
         } else if (inside) {
           if (a.stats) {
 #pragma unroll
@@ -207,20 +267,18 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
         if (py >= a.pool_ho || pxg >= a.pool_wo) continue;
         u32x4_t mx = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < 3; ++r) {
+          const u32x4_t t = *(const u32x4_t*)(sH + ((2 * ppy + r) * POOL_OUT + ppx) * HSTRIDE + chunk * 16);
 #pragma unroll
-          for (int q = 0; q < 3; ++q) {
-            const u32x4_t t = *(const u32x4_t*)(sT + ((2 * ppy + r) * TILE + 2 * ppx + q) * 128 + chunk * 16);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const unsigned int av = mx[j], bv = t[j];
-              const unsigned int lo = max(av & 0xffffu, bv & 0xffffu), hi = max(av >> 16, bv >> 16);
-              mx[j] = lo | (hi << 16);
-            }
+          for (int j = 0; j < 4; ++j) {
+            const unsigned int av = mx[j], bv = t[j];
+            const unsigned int lo = max(av & 0xffffu, bv & 0xffffu), hi = max(av >> 16, bv >> 16);
+            mx[j] = lo | (hi << 16);
           }
+        }
         *(u32x4_t*)(a.pool_y + (((size_t)img * a.pool_ho + py) * a.pool_wo + pxg) * 64 + chunk * 8) = mx;
       }
-      __syncthreads();   // the next tile's epilogue overwrites sT
+      __syncthreads();   // the next tile's epilogue overwrites sH
     }
     buf ^= 1;
   }
@@ -256,7 +314,7 @@ int launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
   const int tiles_x = POOL ? (a.pool_wo + POOL_OUT - 1) / POOL_OUT : (a.Wo + TILE - 1) / TILE;
   const int tiles_y = POOL ? (a.pool_ho + POOL_OUT - 1) / POOL_OUT : (a.Ho + TILE - 1) / TILE;
   const int n_tiles = a.N * tiles_x * tiles_y;
-  const size_t lds = (SPLITW ? 2 : 1) * 64 * W_ROW_BYTES + 2 * PATCH_BYTES + 4 * 16 * 68 * 4 + (POOL ? TILE * TILE * 128 : 0);
+  const size_t lds = (SPLITW ? 2 : 1) * 64 * W_ROW_BYTES + 2 * PATCH_BYTES + (POOL ? TILE * POOL_OUT * 144 : 4 * 16 * 68 * 4);
   int grid = 256 * 2;  // 2 blocks per CU fit (74 / 107 KB of LDS)
   if (SPLITW || POOL) grid = 256;   // 106 / 139 KB with the pooled tile: one block per CU
   if (grid > n_tiles) grid = n_tiles;
