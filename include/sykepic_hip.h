@@ -276,9 +276,12 @@ int spk_op_conv1x1_num_configs(void);
 /* Eval-path 3x3 stride-1 pad-1 convolution (Conv2d(k=3, padding=1, bias=False) + eval BatchNorm2d (+ ReLU): the
  * middle conv of the bottleneck blocks `net(x)` runs, sykepic/compute/probability.py:189).  x [n,h,w,cin] fp16 NHWC,
  * w float32 [cout][3][3][cin], y [n,h,w,cout] fp16.  cfg >= 0: that tile configuration of the LDS-window kernel
- * (conv_c3.hip; SPK_ERR_UNSUPPORTED when it does not fit), cfg < 0: the implicit-GEMM kernel.  Synchronous. */
-int spk_op_conv3x3(const void* x_dev, const float* w_dev, const float* bn_scale_dev, const float* bn_bias_dev, void* y_dev,
-                   int n, int h, int w, int cin, int cout, int relu, int split, int cfg, void* hip_stream);
+ * (conv_c3.hip; SPK_ERR_UNSUPPORTED when it does not fit), cfg < 0: the implicit-GEMM kernel.  res_dev (may be null):
+ * shortcut [n,h,w,cout] fp16 added before the activation (the block-closing conv of a ResNet-18/34 basic block).
+ * Synchronous. */
+int spk_op_conv3x3(const void* x_dev, const float* w_dev, const float* bn_scale_dev, const float* bn_bias_dev,
+                   const void* res_dev, void* y_dev, int n, int h, int w, int cin, int cout, int relu, int split, int cfg,
+                   void* hip_stream);
 int spk_op_conv3x3_num_configs(void);
 /* Depthwise Conv2d(C, C, k, stride, pad (k-1)/2, groups=C) + folded BatchNorm + activation (EfficientNet MBConv):
  * x [n,h,w,C] fp16 NHWC, w float32 [C][k*k], y [n,ho,wo,C] fp16; pool (optional) float32 [n][C] = per-image sums of

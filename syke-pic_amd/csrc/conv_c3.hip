@@ -69,6 +69,7 @@ __global__ __launch_bounds__(512, 2) void conv_c3_kernel(C3Args a, int m_tiles, 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, a.wp_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res : a.y), 0, a.res ? a.y_bytes : 0, 0x00020000);
 
   // ---- staging map of this thread: unit u = (window pixel, 16-byte part) -> source byte offset (or dropped) ----
   unsigned soff[UMAX], doff[UMAX];
@@ -177,6 +178,11 @@ __global__ __launch_bounds__(512, 2) void conv_c3_kernel(C3Args a, int m_tiles, 
   const f32x4_t sh0 = a.shift ? *(const f32x4_t*)(a.shift + c0) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   const f32x4_t sh1 = a.shift ? *(const f32x4_t*)(a.shift + c0 + 4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
   const float floor_v = a.relu == 1 ? 0.f : -65504.f;
+  // shortcut values of the wave's pixel tiles, all requested up front (a zero-record descriptor when there is none: the
+  // loads return zeros and cost nothing)
+  u32x4_t rq[MTW];
+#pragma unroll
+  for (int j = 0; j < MTW; ++j) rq[j] = __builtin_amdgcn_raw_buffer_load_b128(rr, yoff[j], 0, 0);
 #pragma unroll
   for (int j = 0; j < MTW; ++j) {
     float v[8];
@@ -184,6 +190,11 @@ __global__ __launch_bounds__(512, 2) void conv_c3_kernel(C3Args a, int m_tiles, 
     for (int r = 0; r < 4; ++r) {
       v[r] = __builtin_fmaf(acc[j][0][r], sc0[r], sh0[r]);
       v[4 + r] = __builtin_fmaf(acc[j][1][r], sc1[r], sh1[r]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] += lo_f32<DT_F16>(rq[j][i]);
+      v[2 * i + 1] += hi_f32<DT_F16>(rq[j][i]);
     }
     if (a.relu == 2) {
 #pragma unroll

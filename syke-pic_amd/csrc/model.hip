@@ -901,7 +901,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     return SPK_OK;
   }
   static const bool use_c3 = !getenv("SPK_C3") || atoi(getenv("SPK_C3")) != 0;
-  if (use_c3 && L.c3_ok && a.dt == DT_F16 && !a.res && !a.y_lo && !a.cin_s && !a.cout_s) {
+  if (use_c3 && L.c3_ok && a.dt == DT_F16 && !a.res_lo && !a.y_lo && !a.cin_s && !a.cout_s) {
     C3Args q;
     memset(&q, 0, sizeof q);
     q.x = a.x; q.wp = m->wpack + L.wpw_off; q.y = a.y; q.scale = a.scale; q.shift = a.bias;
@@ -909,6 +909,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     q.nb = a.splitw ? 2 : 1;
     q.x_bytes = a.x_bytes; q.y_bytes = (unsigned)((size_t)a.M * a.Cout * 2);
     q.wp_bytes = (unsigned)((size_t)a.Cout * 9 * a.Cin * 2 * q.nb);
+    q.res = a.res;
     const int r = spk_conv3x3_launch(q, m->stream);
     if (r == 0) return SPK_OK;
     if (r != -3) return fail(SPK_ERR_HIP, std::string("3x3 conv launch failed for ") + L.d.name);

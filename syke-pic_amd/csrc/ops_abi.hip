@@ -245,8 +245,9 @@ extern "C" int spk_op_conv1x1_num_configs(void) { return spk_pw_num_configs(); }
 
 // 3x3 stride-1 pad-1 convolution + folded BatchNorm (+ReLU) of the eval path (conv_c3.hip) on caller-provided buffers;
 // cfg >= 0: that tile configuration (SPK_ERR_UNSUPPORTED when it does not fit), cfg < 0: the implicit-GEMM kernel.
-extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* bn_scale, const float* bn_bias, void* y,
-                              int n, int h, int wd, int cin, int cout, int relu, int split, int cfg, void* stream) {
+extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* bn_scale, const float* bn_bias,
+                              const void* res, void* y, int n, int h, int wd, int cin, int cout, int relu, int split,
+                              int cfg, void* stream) {
   if (!x || !w_ohwi || !bn_scale || !bn_bias || !y || n < 1 || h < 1 || wd < 1)
     return ofail(SPK_ERR_ARG, "op_conv3x3: bad arguments");
   if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
@@ -263,6 +264,7 @@ extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* b
     a.cfg = a.dma = -1;
     a.cls_ph = a.cls_pw = -1;
     a.x = (const bf16_t*)x; a.w = wp; a.y = (bf16_t*)y; a.scale = bn_scale; a.bias = bn_bias;
+    a.res = (const bf16_t*)res;
     a.N = n; a.H = h; a.W = wd; a.Cin = cin; a.Ho = h; a.Wo = wd; a.Cout = cout;
     a.kh = a.kw = 3; a.stride = 1; a.pad = 1; a.M = M; a.K = 9 * cin; a.relu = relu; a.dt = DT_F16; a.splitw = split != 0;
     a.x_bytes = (unsigned)((size_t)M * cin * 2);
@@ -277,6 +279,7 @@ extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* b
     q.x_bytes = (unsigned)((size_t)M * cin * 2);
     q.y_bytes = (unsigned)((size_t)M * cout * 2);
     q.wp_bytes = (unsigned)((size_t)cout * 9 * cin * 2 * q.nb);
+    q.res = (const bf16_t*)res;
     r = spk_c3_launch(q, cfg, s);
     if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "this configuration does not fit the problem");
   }

@@ -159,6 +159,7 @@ struct C3Args {
   int N, H, W, Cin, Cout, M;
   int relu, dt, nb;
   unsigned int x_bytes, y_bytes, wp_bytes;
+  const bf16_t* res;    // shortcut [N,H,W,Cout] added before the activation (ResNet-18/34 block-closing conv), or null
 };
 int spk_c3_num_configs();
 int spk_c3_launch(const C3Args& a, int cfg, hipStream_t s);   // -3: this config does not fit the problem

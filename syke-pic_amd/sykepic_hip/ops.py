@@ -188,9 +188,10 @@ def conv3x3_num_configs():
     return int(lib.load().spk_op_conv3x3_num_configs())
 
 
-def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0):
-    """Eval-path 3x3 stride-1 pad-1 conv + folded BN (+ ReLU) (spk_op_conv3x3).  x [N,Cin,H,W] float16, weight
-    [Cout,Cin,3,3]; cfg >= 0: that configuration of the LDS-window kernel, cfg < 0: the implicit GEMM."""
+def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0, res=None):
+    """Eval-path 3x3 stride-1 pad-1 conv + folded BN (+ shortcut) (+ ReLU) (spk_op_conv3x3).  x [N,Cin,H,W] float16,
+    weight [Cout,Cin,3,3], res [N,Cout,H,W] or None; cfg >= 0: that configuration of the LDS-window kernel, cfg < 0: the
+    implicit GEMM."""
     so = lib.load()
     dev = x.device
     n, cin, h, w = x.shape
@@ -198,8 +199,9 @@ def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0):
     xh = x.half().permute(0, 2, 3, 1).contiguous()
     y = torch.full((n, h, w, cout), float("nan"), dtype=torch.float16, device=dev)
     wk = weight.float().permute(0, 2, 3, 1).contiguous()   # OIHW -> O,kh,kw,I
+    rh = res.half().permute(0, 2, 3, 1).contiguous() if res is not None else None
     with torch.cuda.device(dev):
         lib.check(so.spk_op_conv3x3(_p(xh), _p(wk), _p(bn_scale.float().contiguous()), _p(bn_bias.float().contiguous()),
-                                    _p(y), n, h, w, cin, cout, int(bool(relu)), int(bool(split)), int(cfg),
+                                    _p(rh) if rh is not None else None, _p(y), n, h, w, cin, cout, int(bool(relu)), int(bool(split)), int(cfg),
                                     _stream(dev)))
     return y.permute(0, 3, 1, 2)

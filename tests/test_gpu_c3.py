@@ -24,8 +24,10 @@ SHAPES = [
 ]
 
 
-def _ref(x, wgt, scale, bias, relu):
+def _ref(x, wgt, scale, bias, relu, res=None):
     y = torch.nn.functional.conv2d(x.float(), wgt, padding=1) * scale[None, :, None, None] + bias[None, :, None, None]
+    if res is not None:
+        y = y + res.float()
     return torch.relu(y) if relu else y
 
 
@@ -40,13 +42,16 @@ def test_every_configuration_matches_the_fp32_conv(shape, split):
     scale = 0.5 + torch.rand(cout, generator=g)
     bias = torch.rand(cout, generator=g) - 0.5
     relu = (h + cout) % 3 != 0
-    ref = _ref(x, wgt, scale, bias, relu)
+    # every other shape carries a shortcut operand (the block-closing conv of a ResNet-18/34 basic block)
+    res = torch.randn(n, cout, h, w, generator=g).half() if (n + h) % 2 else None
+    ref = _ref(x, wgt, scale, bias, relu, res)
     tol_rel, tol_abs = (1.5e-3, 2e-3) if split else (6e-3, 8e-3)
     dev = "cuda:0"
     outs = []
     for cfg in range(-1, ops.conv3x3_num_configs()):
         try:
-            y = ops.conv3x3(x.to(dev), wgt.to(dev), scale.to(dev), bias.to(dev), relu=relu, split=split, cfg=cfg)
+            y = ops.conv3x3(x.to(dev), wgt.to(dev), scale.to(dev), bias.to(dev), relu=relu, split=split, cfg=cfg,
+                            res=res.to(dev) if res is not None else None)
         except RuntimeError as e:
             assert "does not fit" in str(e), str(e)
             continue
