@@ -44,7 +44,14 @@ constexpr int POOL_OUT = 7;
 template <int DT, int SPLITW, int POOL>
 __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x, int tiles_y, int n_tiles) {
   constexpr int NW = SPLITW ? 2 : 1;
-  constexpr int W_BYTES = 64 * W_ROW_BYTES;
+  // POOL: a block covers 32 of the 64 couts (pair cb = blockIdx.x & 1) and the two blocks of a pair walk the same
+  // tiles: half the weight panel per block (32 KB with hi + lo) brings the block to 65 KB of LDS, i.e. TWO blocks per
+  // CU - the K loop of one overlaps the epilogue / pool / patch-staging phases of the other (those were 2/3 of the
+  // kernel's time with a single 4-wave block per CU).
+  constexpr int NJ = POOL ? 2 : 4;                         // 16-cout MFMA tiles per block
+  constexpr int WROWS = 16 * NJ;                           // weight rows in LDS
+  constexpr int W_BYTES = WROWS * W_ROW_BYTES;
+  const int cb = POOL ? (int)(blockIdx.x & 1) : 0;
   constexpr int EPI_LD = 68;
   constexpr int TSTEP = POOL ? POOL_STEP : TILE;           // stem pixels between tile origins
   constexpr int TORG = POOL ? 1 : 0;                       // ... and the origin's offset before the multiple
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
   unsigned char* const sP = smem + NW * W_BYTES;           // [2][PATCH_BYTES]
   float* const sE = (float*)(sP + 2 * PATCH_BYTES);        // [4 waves][16][EPI_LD]   (not POOL)
   unsigned char* const sH = sP + 2 * PATCH_BYTES;          // POOL: [16 rows][7 pooled columns] x HSTRIDE bytes
-  constexpr int HSTRIDE = 144;                             // 128 B of channels + 16: conflict-free 16-byte writes
+  constexpr int HSTRIDE = 80;                              // 64 B (the block's 32 channels) + 16: conflict-free 16-byte writes
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -62,12 +69,12 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
 
   // ---- weights -> LDS, once ----
-  for (int c = tid; c < NW * 64 * 32; c += 256) {
-    const int ch = c & 31, row = (c >> 5) & 63, half = c >> 11;
-    // POOL: swapped MFMA operand roles (weights = A, rows = couts).  LDS row q holds cout 32(q>>5) + 8((q&15)>>2) +
-    // 4((q>>4)&1) + (q&3), so that a lane's accumulators of the tile pair (2P, 2P+1) are couts 32P + 8(lane>>4) .. +7 of
+  for (int c = tid; c < NW * WROWS * 32; c += 256) {
+    const int ch = c & 31, row = (c >> 5) % WROWS, half = c / (WROWS * 32);
+    // POOL: swapped MFMA operand roles (weights = A, rows = couts).  LDS row q of the block holds cout 32 cb +
+    // 8((q&15)>>2) + 4(q>>4) + (q&3), so that a lane's accumulators of the two tiles are couts 32 cb + 8(lane>>4) .. +7 of
     // ONE pixel: the epilogue runs from registers (conv_pw.hip's arrangement), no transposition through LDS.
-    const int srow = POOL ? 32 * (row >> 5) + 8 * ((row & 15) >> 2) + 4 * ((row >> 4) & 1) + (row & 3) : row;
+    const int srow = POOL ? 32 * cb + 8 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3) : row;
     const u32x4_t v = *(const u32x4_t*)(a.w + ((size_t)(half * 64 + srow) * 256 + ch * 8));
     *(u32x4_t*)(sW + half * W_BYTES + row * W_ROW_BYTES + ((ch ^ (row & 15)) << 4)) = v;
   }
@@ -108,26 +115,25 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
     s1[j] = s2[j] = 0.f;
   }
   float* const epi = sE + wave * (16 * EPI_LD);
-  float psc[POOL ? 2 : 1][8], pbi[POOL ? 2 : 1][8];        // POOL: couts 32P + 8fq + 0..7
+  float psc[8], pbi[8];                                    // POOL: couts 32 cb + 8fq + 0..7
   if (POOL) {
 #pragma unroll
-    for (int P = 0; P < 2; ++P)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        psc[P][j] = a.scale ? a.scale[32 * P + 8 * fq + j] : 1.f;
-        pbi[P][j] = a.bias ? a.bias[32 * P + 8 * fq + j] : 0.f;
-      }
+    for (int j = 0; j < 8; ++j) {
+      psc[j] = a.scale ? a.scale[32 * cb + 8 * fq + j] : 1.f;
+      pbi[j] = a.bias ? a.bias[32 * cb + 8 * fq + j] : 0.f;
+    }
   }
 
-  int tile = blockIdx.x;
+  const int tstep = POOL ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  int tile = POOL ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   int buf = 0;
   if (tile < n_tiles) {
     issue_patch(tile);
     store_patch(0);
   }
   __syncthreads();
-  for (; tile < n_tiles; tile += gridDim.x) {
-    const int next = tile + gridDim.x;
+  for (; tile < n_tiles; tile += tstep) {
+    const int next = tile + tstep;
     if (next < n_tiles) issue_patch(next);
 
     const int img = tile / (tiles_x * tiles_y);
@@ -136,21 +142,21 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
     const unsigned char* patch = sP + buf * PATCH_BYTES;
 
     // wave w: output rows 4w..4w+3 of the tile (one 16-pixel MFMA row tile each), all 64 couts
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 7; ++r) {
-      u32x4_t fa[4], fb[4], fl[SPLITW ? 4 : 1];
+      u32x4_t fa[4], fb[NJ], fl[SPLITW ? NJ : 1];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int oy = wave * 4 + i;
         fa[i] = *(const u32x4_t*)(patch + ((2 * oy + r) * PWP + frow + fq) * 16);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int n = j * 16 + frow;
         fb[j] = *(const u32x4_t*)(sW + n * W_ROW_BYTES + (((r * 4 + fq) ^ (n & 15)) << 4));
         if (SPLITW) fl[j] = *(const u32x4_t*)(sW + W_BYTES + n * W_ROW_BYTES + (((r * 4 + fq) ^ (n & 15)) << 4));
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           if (POOL) {   // D rows = couts, columns = pixels
             acc[i][j] = mfma16<DT>(fb[j], fa[i], acc[i][j]);
             if (SPLITW) acc[i][j] = mfma16<DT>(fl[j], fa[i], acc[i][j]);
@@ -181,14 +187,13 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
       for (int i = 0; i < 4; ++i) {
         const int oy = ty * TSTEP - TORG + wave * 4 + i;
         const bool inside = (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
-#pragma unroll
-        for (int P = 0; P < 2; ++P) {
+        {
           u32x4_t ov = {0u, 0u, 0u, 0u};
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = fmaxf(acc[i][2 * P][r] * psc[P][r] + pbi[P][r], 0.f);
-            v[4 + r] = fmaxf(acc[i][2 * P + 1][r] * psc[P][4 + r] + pbi[P][4 + r], 0.f);
+            v[r] = fmaxf(acc[i][0][r] * psc[r] + pbi[r], 0.f);
+            v[4 + r] = fmaxf(acc[i][NJ - 1][r] * psc[4 + r] + pbi[4 + r], 0.f);
           }
           if (inside) {
 #pragma unroll
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
             hm[j] = __builtin_bit_cast(unsigned, m);
           }
           if (!(frow & 1) && frow < 2 * POOL_OUT)
-            *(u32x4_t*)(sH + ((wave * 4 + i) * POOL_OUT + (frow >> 1)) * HSTRIDE + (32 * P + 8 * fq) * 2) = hm;
+            *(u32x4_t*)(sH + ((wave * 4 + i) * POOL_OUT + (frow >> 1)) * HSTRIDE + 8 * fq * 2) = hm;
         }
       }
     } else
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) epi[(fq * 4 + rr) * EPI_LD + j * 16 + frow] = acc[i][j][rr];
       __builtin_amdgcn_wave_barrier();
@@ -260,8 +265,8 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
     if (POOL) {
       // 7 x 7 pooled pixels x 8 channel chunks of 16 B: the window of pooled (py, px) is the tile's rows 2py .. 2py+2 and
       // columns 2px .. 2px+2.  Non-negative 16-bit floats order like unsigned integers (fp16 and bf16 alike).
-      for (int it = tid; it < POOL_OUT * POOL_OUT * 8; it += 256) {
-        const int chunk = it & 7, pp = it >> 3;
+      for (int it = tid; it < POOL_OUT * POOL_OUT * 4; it += 256) {
+        const int chunk = it & 3, pp = it >> 2;
         const int ppy = pp / POOL_OUT, ppx = pp - ppy * POOL_OUT;
         const int py = ty * POOL_OUT + ppy, pxg = tx * POOL_OUT + ppx;
         if (py >= a.pool_ho || pxg >= a.pool_wo) continue;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int tiles_x,
             mx[j] = lo | (hi << 16);
           }
         }
-        *(u32x4_t*)(a.pool_y + (((size_t)img * a.pool_ho + py) * a.pool_wo + pxg) * 64 + chunk * 8) = mx;
+        *(u32x4_t*)(a.pool_y + (((size_t)img * a.pool_ho + py) * a.pool_wo + pxg) * 64 + 32 * cb + chunk * 8) = mx;
       }
       __syncthreads();   // the next tile's epilogue overwrites sH
     }
@@ -314,10 +319,15 @@ int launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
   const int tiles_x = POOL ? (a.pool_wo + POOL_OUT - 1) / POOL_OUT : (a.Wo + TILE - 1) / TILE;
   const int tiles_y = POOL ? (a.pool_ho + POOL_OUT - 1) / POOL_OUT : (a.Ho + TILE - 1) / TILE;
   const int n_tiles = a.N * tiles_x * tiles_y;
-  const size_t lds = (SPLITW ? 2 : 1) * 64 * W_ROW_BYTES + 2 * PATCH_BYTES + (POOL ? TILE * POOL_OUT * 144 : 4 * 16 * 68 * 4);
-  int grid = 256 * 2;  // 2 blocks per CU fit (74 / 107 KB of LDS)
-  if (SPLITW || POOL) grid = 256;   // 106 / 139 KB with the pooled tile: one block per CU
-  if (grid > n_tiles) grid = n_tiles;
+  const size_t lds = (SPLITW ? 2 : 1) * (POOL ? 32 : 64) * W_ROW_BYTES + 2 * PATCH_BYTES +
+                     (POOL ? TILE * POOL_OUT * 80 : 4 * 16 * 68 * 4);
+  int grid = 256 * 2;  // 2 blocks per CU fit (74 KB of LDS; POOL: 49 / 65 KB, a block per 32-cout half)
+  if (SPLITW && !POOL) grid = 256;   // 107 KB: one block per CU
+  if (POOL) {
+    if (grid > 2 * n_tiles) grid = 2 * n_tiles;   // pairs of blocks: (tile stream, cout half)
+  } else if (grid > n_tiles) {
+    grid = n_tiles;
+  }
   auto k = conv_stem_kernel<DT, SPLITW, POOL>;
   static bool attr = false;
   if (!attr) {
