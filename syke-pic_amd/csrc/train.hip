@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 static int tfail(int code, const std::string& msg) {
@@ -76,6 +77,16 @@ struct TrainState {
   std::vector<size_t> goff;   // gradient tensor per activation id
   size_t dy_off = 0, idx_off = 0, part_off = 0, coef_off = 0, slab_off = 0, tmp_off = 0;
   size_t se_tmp_off = 0;   // squeeze-excitation scratch shared by the layers (pool partials, gate / hidden gradients)
+  // Weight gradients on a second stream (ResNets): wgrad(i) needs only the layer's input activation and dy(i), so it runs
+  // beside dgrad(i) and the HBM-bound BatchNorm backward of the next layer instead of in front of them.  dy is double
+  // buffered: bn_bwd of layer i-2 may overwrite a buffer only after the wgrad that read it has finished.
+  size_t dy2_off = 0;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_dy_ready[2] = {nullptr, nullptr};   // main: dy buffer written
+  hipEvent_t ev_dy_free[2] = {nullptr, nullptr};    // side: wgrad has read the dy buffer
+  hipEvent_t ev_side_done = nullptr;
+  bool dy_busy[2] = {false, false};
+  int dy_slot = 0;
   size_t part_floats = 0, slab_floats = 0;
 
   void* G(int t) const { return (char*)arena + goff[t]; }
@@ -93,6 +104,12 @@ void spk_train_free(spk_model* m) {
   if (t->wpack) hipFree(t->wpack);
   if (t->stats) hipFree(t->stats);
   if (t->dwt) hipFree(t->dwt);
+  if (t->side) hipStreamDestroy(t->side);
+  for (int i = 0; i < 2; ++i) {
+    if (t->ev_dy_ready[i]) hipEventDestroy(t->ev_dy_ready[i]);
+    if (t->ev_dy_free[i]) hipEventDestroy(t->ev_dy_free[i]);
+  }
+  if (t->ev_side_done) hipEventDestroy(t->ev_side_done);
   delete t;
   m->train = nullptr;
 }
@@ -149,6 +166,15 @@ static int ensure_state(spk_model* m) {
   HIP_TRY(hipMalloc((void**)&t->wpack, std::max<size_t>(w, 8) * 2));
   HIP_TRY(hipMalloc((void**)&t->stats, std::max<size_t>(st, 8) * 4));
   HIP_TRY(hipMalloc((void**)&t->dwt, std::max<size_t>(dw, 8) * 4));
+  static const bool side_wgrad = !getenv("SPK_WGRAD_STREAM") || atoi(getenv("SPK_WGRAD_STREAM")) != 0;
+  if (side_wgrad && !m->effnet) {
+    HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_ready[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_free[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_side_done, hipEventDisableTiming));
+  }
   return SPK_OK;
 }
 
@@ -219,6 +245,7 @@ static int plan_train(spk_model* m, int n, int h, int w) {
     }
   }
   t->dy_off = total;      total += al256(max_conv);
+  t->dy2_off = total;     total += al256(max_conv);
   t->part_off = total;    total += al256(max_part * 4);
   t->coef_off = total;    total += al256(max_c * 3 * 4);
   t->tmp_off = total;     total += al256(max_c * 2 * 64 * 4);
@@ -403,6 +430,10 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   float* tmp = (float*)((char*)t->arena + t->tmp_off);
   float* slabs = (float*)((char*)t->arena + t->slab_off);
   bf16_t* dy = (bf16_t*)((char*)t->arena + t->dy_off);
+  bf16_t* const dy_bufs[2] = {dy, (bf16_t*)((char*)t->arena + t->dy2_off)};
+  const bool side_on = t->side != nullptr && !t->prof.on;   // (the per-phase profile times a single-stream step)
+  t->dy_busy[0] = t->dy_busy[1] = false;
+  t->dy_slot = 0;
   unsigned char* pool_idx = (unsigned char*)((char*)t->arena + t->idx_off);
   const int nl = (int)m->layers.size();
 
@@ -602,6 +633,13 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         bf16_t* g_res = L.d.res >= 0 && needs[L.d.res] ? (bf16_t*)t->G(L.d.res) : nullptr;
         float* dgam = pg.requires_grad ? t->gbuf + pg.off : nullptr;
         float* dbet = pb.requires_grad ? t->gbuf + pb.off : nullptr;
+        int slot = 0;
+        if (side_on) {   // this layer's dy buffer: free once the side-stream wgrad of two layers ago has read it
+          slot = t->dy_slot;
+          t->dy_slot ^= 1;
+          dy = dy_bufs[slot];
+          if (t->dy_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, t->ev_dy_free[slot], 0));
+        }
         if (!m->effnet) {
           K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st, st + C, m->P(L.p_g), part, coef,
                                   dgam, dbet, dy, g_res, g_res ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
@@ -617,6 +655,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                          g_res ? has_grad[L.d.res] : 0, M, C, o.h * o.w, L.d.relu, s), "bn bwd apply");
         }
         mark(m, PH_BN_BWD);
+        if (side_on) HIP_TRY(hipEventRecord(t->ev_dy_ready[slot], s));
         if (g_res) has_grad[L.d.res] = 1;
         const Param& pw = m->params[L.p_w];
         if (L.d.kind == SPK_OP_DWCONV) {
@@ -658,16 +697,23 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           }
           const bool stem = L.mode == CONV_MODE_STEM;
           const int cin_t = stem ? L.d.cin : in.c;   // channels of the stored input tensor (the 7x7 stem reads NHWC4 itself)
+          // ResNets: on the second stream, beside this layer's dgrad and the next layer's BatchNorm backward
+          const hipStream_t ws = side_on ? t->side : s;
+          if (side_on) HIP_TRY(hipStreamWaitEvent(ws, t->ev_dy_ready[slot], 0));
           SPK_TRY(spk_conv_wgrad_slabs((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, cin_t, o.h, o.w, C, L.d.k,
-                                       L.d.stride, L.d.pad, stem, s));
+                                       L.d.stride, L.d.pad, stem, ws));
           mark(m, PH_CONV_WGRAD);
           if (!stem && (C != L.d.cout || cin_t != L.d.cin)) {   // padded GEMM: keep the layer's own rows / columns
             int sp, pps;
             spk_wgrad_plan(M, C, L.d.k * L.d.k * cin_t, &sp, &pps);
-            K_TRY(spk_launch_slab_reduce_sub(slabs, gw, L.d.cout, L.d.k * L.d.k, L.d.cin, C, cin_t, sp, s),
+            K_TRY(spk_launch_slab_reduce_sub(slabs, gw, L.d.cout, L.d.k * L.d.k, L.d.cin, C, cin_t, sp, ws),
                   "wgrad reduce (padded)");
           } else {
-            SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, cin_t, C, L.d.k, stem, s));
+            SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, cin_t, C, L.d.k, stem, ws));
+          }
+          if (side_on) {
+            HIP_TRY(hipEventRecord(t->ev_dy_free[slot], ws));
+            t->dy_busy[slot] = true;
           }
           mark(m, PH_WGRAD_REDUCE);
         }
@@ -702,6 +748,10 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   }
   if (m->grad_cb)
     while (cur_bucket < m->grad_buckets) SPK_TRY(grad_bucket_done(m, cur_bucket++));
+  if (side_on) {   // the step is complete on the caller's stream only when the side-stream weight gradients are
+    HIP_TRY(hipEventRecord(t->ev_side_done, t->side));
+    HIP_TRY(hipStreamWaitEvent(s, t->ev_side_done, 0));
+  }
   return SPK_OK;
 }
 
@@ -743,6 +793,10 @@ static int grad_bucket_done(spk_model* m, int b) {
   if (lo == (size_t)-1) return SPK_OK;
   if (b == m->grad_buckets - 1) lo = 0;              // the last bucket reaches to the front of the buffer
   if (b == 0) hi = m->n_train;
+  if (m->train && m->train->side) {   // weight gradients of the bucket's layers may still be running on the side stream
+    HIP_TRY(hipEventRecord(m->train->ev_side_done, m->train->side));
+    HIP_TRY(hipStreamWaitEvent(m->stream, m->train->ev_side_done, 0));
+  }
   HIP_TRY(hipEventRecord(m->grad_ev[b], m->stream));
   if (m->comm_stream != m->stream) HIP_TRY(hipStreamWaitEvent(m->comm_stream, m->grad_ev[b], 0));
   m->grad_cb(m->grad_cb_user, b, (int64_t)lo, (int64_t)(hi - lo));
