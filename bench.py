@@ -252,6 +252,15 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
                 "algorithmic_bytes_per_launch": round(sum(by for _, _, _, by in conv) / len(conv)),
                 "conv_ms_per_step": round(conv_ms, 3), "all_kernels_ms_per_step": round(all_ms, 3),
                 "hbm_GBs_algorithmic": round(sum(by for _, _, _, by in layers) / (all_ms * 1e-3) / 1e9, 1)}
+        # The timed step runs the two halves of the batch on two streams (kernels of the two chains overlap), so a
+        # kernel's duration inside it is not its own: achieved / frac above are per-kernel figures from a single-stream
+        # pass (spk_model_profile_infer; what rocprofv3 shows under SPK_EVAL_STREAMS=1).  step_*: the same algorithmic
+        # conv FLOPs over the conv share of the TIMED step.
+        step_conv_ms = dt / args.steps * 1e3 * conv_ms / max(all_ms, 1e-9)
+        roof["step_conv_ms"] = round(step_conv_ms, 3)
+        roof["step_achieved"] = round(conv_fl / (step_conv_ms * 1e-3) / 1e12, 2)
+        roof["step_frac"] = round(roof["step_achieved"] / MFMA_PEAK_TFLOPS, 4)
+        roof["streams"] = int(os.environ.get("SPK_EVAL_STREAMS", "2")) if args.batch >= 64 else 1
         if args.network.startswith("efficientnet"):
             # EfficientNet: 2/3 of the time is depthwise / squeeze-excitation / padded 1x1 passes that move bytes:
             # the bound is HBM, over all kernels of the forward

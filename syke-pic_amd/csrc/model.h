@@ -69,6 +69,10 @@ struct spk_model {
   hipStream_t stream = nullptr;
   hipStream_t side = nullptr;  // second stream for the shortcut (downsample) convs of the eval forward
   hipEvent_t fork = nullptr;
+  // eval: the two halves of a batch on two streams (see spk_forward_eval_logits)
+  hipStream_t half_stream = nullptr;
+  hipEvent_t half_fork = nullptr, half_join = nullptr;
+  std::vector<long long> half_warm;   // (n, h, w) keys whose half-batch kernels have been tuned (on a quiet GPU)
   std::vector<Layer> layers;
   std::vector<Param> params;
   std::unordered_map<std::string, int> index;

@@ -287,3 +287,23 @@ def test_block_closing_conv_with_fused_shortcut_conv(golden_dir, shape, monkeypa
             assert torch.equal(ra, rb)      # same input (the max-pool output), same stand-alone kernel
         else:
             assert float((ra - rb).norm() / rb.norm()) < 2e-3    # (its input already differs by the stage before)
+
+
+@pytest.mark.parametrize("network,n,hw", [("resnet50", 96, 64), ("resnet18", 65, 75)])
+def test_two_stream_forward_equals_the_halves_run_alone(golden_dir, network, n, hw):
+    """Round 3: a batch of >= 64 images runs as two halves on two streams that share the activation tensors (images
+    [0, n/2) and [n/2, n)).  Per-image results must not depend on that: the output equals, bit for bit, what the same
+    images give in batches small enough to take the single-stream path - also for an odd batch, repeated calls (the first
+    call of a shape runs both halves on one stream while the kernel tuners time their candidates), and for the tensors
+    read back afterwards."""
+    gold = np.load(golden_dir / "net_pass.npz")
+    g, sd = _state(network, gold, f"{network}_224")
+    net = _hipnet(network, sd)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=77)).cuda()
+    first = net.probabilities(x).cpu()          # tuning pass: both halves on the caller's stream
+    second = net.probabilities(x).cpu()         # two streams
+    third = net.probabilities(x).cpu()
+    assert torch.equal(first, second) and torch.equal(second, third)
+    small = torch.cat([net.probabilities(x[i:i + 32]).cpu() for i in range(0, n, 32)])   # < 64 images: one stream
+    assert torch.equal(second, small)
+    assert torch.isfinite(second).all() and torch.allclose(second.sum(1), torch.ones(n), atol=1e-4)

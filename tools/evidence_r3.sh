@@ -12,6 +12,9 @@ python3 bench.py --mode both --no-cpu-baseline --steps 3 --warmup 2 > gpurun_out
 cp $SPK_TUNE_CACHE gpurun_out/${TAG}_tune_cache.txt
 python3 bench.py --layers-out gpurun_out/${TAG}_infer_mixed_layers.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.err
 echo "bench line done"
+# rocprofv3 / PMC passes run the eval forward on ONE stream (SPK_EVAL_STREAMS=1): per-kernel durations and counters are
+# only a kernel's own when the two half-batch chains do not overlap; the bench line above is the two-stream default
+export SPK_EVAL_STREAMS=1
 for MODE in infer train; do
   rm -rf gpurun_out/prof_${TAG}_${MODE}
   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_${MODE} -- python3 bench.py --mode $MODE --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${TAG}_${MODE}_under_rocprof.json 2> gpurun_out/${TAG}_${MODE}_rocprof.err
