@@ -167,7 +167,7 @@ static int ensure_state(spk_model* m) {
   HIP_TRY(hipMalloc((void**)&t->stats, std::max<size_t>(st, 8) * 4));
   HIP_TRY(hipMalloc((void**)&t->dwt, std::max<size_t>(dw, 8) * 4));
   static const bool side_wgrad = !getenv("SPK_WGRAD_STREAM") || atoi(getenv("SPK_WGRAD_STREAM")) != 0;
-  if (side_wgrad && !m->effnet) {
+  if (side_wgrad) {
     {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo: numerically greatest = lowest priority
@@ -676,11 +676,17 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           }
           if (pw.requires_grad) {
             int rows = 0;
+            const hipStream_t ws = side_on ? t->side : s;   // weight gradients: second stream (see the conv case below)
+            if (side_on) HIP_TRY(hipStreamWaitEvent(ws, t->ev_dy_ready[slot], 0));
             K_TRY(spk_launch_dw_wgrad((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, C, L.d.cout, L.d.k,
-                                      L.d.stride, L.d.pad, o.h, o.w, &rows, s), "depthwise wgrad");
+                                      L.d.stride, L.d.pad, o.h, o.w, &rows, ws), "depthwise wgrad");
             mark(m, PH_CONV_WGRAD);
-            K_TRY(spk_launch_slab_reduce(slabs, t->gbuf + pw.off, (size_t)L.d.cout * L.d.k * L.d.k, rows, s),
+            K_TRY(spk_launch_slab_reduce(slabs, t->gbuf + pw.off, (size_t)L.d.cout * L.d.k * L.d.k, rows, ws),
                   "depthwise wgrad reduce");
+            if (side_on) {
+              HIP_TRY(hipEventRecord(t->ev_dy_free[slot], ws));
+              t->dy_busy[slot] = true;
+            }
             mark(m, PH_WGRAD_REDUCE);
           }
           break;
@@ -696,10 +702,16 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           float* gw = t->gbuf + pw.off;
           if (L.mode == CONV_MODE_STEM3) {
             int nbk = 0;
+            const hipStream_t ws3 = side_on ? t->side : s;
+            if (side_on) HIP_TRY(hipStreamWaitEvent(ws3, t->ev_dy_ready[slot], 0));
             K_TRY(spk_launch_stem3_wgrad((const bf16_t*)m->T(0), dy, slabs, n, in.h, w, in.w, L.d.cin, L.d.cout, C, o.h,
-                                         o.w, &nbk, s), "stem3 wgrad");
+                                         o.w, &nbk, ws3), "stem3 wgrad");
             mark(m, PH_CONV_WGRAD);
-            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)L.d.cout * 9 * L.d.cin, nbk, s), "stem3 wgrad reduce");
+            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)L.d.cout * 9 * L.d.cin, nbk, ws3), "stem3 wgrad reduce");
+            if (side_on) {
+              HIP_TRY(hipEventRecord(t->ev_dy_free[slot], ws3));
+              t->dy_busy[slot] = true;
+            }
             mark(m, PH_WGRAD_REDUCE);
             break;
           }
