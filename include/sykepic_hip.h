@@ -75,6 +75,8 @@ extern "C" {
 #define SPK_OPT_NADAM 6     /* momentum_decay 4e-3 */
 #define SPK_OPT_RADAM 7
 #define SPK_OPT_ADADELTA 8  /* rho 0.9, eps 1e-6 */
+#define SPK_OPT_ASGD 9      /* lambd 1e-4 (field lr_decay), alpha 0.75 (field alpha), t0 1e6; the averaged copy `ax` is not kept */
+#define SPK_OPT_RPROP 10    /* etas (0.5, 1.2) in beta1 / beta2, step sizes (1e-6, 50) in eps / alpha */
 
 typedef struct spk_model spk_model;
 

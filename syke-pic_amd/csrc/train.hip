@@ -825,8 +825,9 @@ static int grad_bucket_done(spk_model* m, int b) {
 
 extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
   if (!m || !opt) return tfail(SPK_ERR_ARG, "optim_step: bad arguments");
-  if (opt->kind < SPK_OPT_SGD || opt->kind > SPK_OPT_ADADELTA)
-    return tfail(SPK_ERR_UNSUPPORTED, "optimizer kind not supported (SGD, Adam, AdamW, RMSprop, Adagrad, Adamax, NAdam, RAdam, Adadelta)");
+  if (opt->kind < SPK_OPT_SGD || opt->kind > SPK_OPT_RPROP)
+    return tfail(SPK_ERR_UNSUPPORTED,
+                 "optimizer kind not supported (SGD, Adam, AdamW, RMSprop, Adagrad, Adamax, NAdam, RAdam, Adadelta, ASGD, Rprop)");
   if (!m->train) return tfail(SPK_ERR_STATE, "optim_step before any training step");
   HIP_TRY(hipSetDevice(m->device));
   TrainState* t = m->train;
@@ -864,6 +865,11 @@ extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
       p.mu_product *= mu;
       e.c0 = (float)((double)e.lr * (1.0 - mu) / (1.0 - p.mu_product));
       e.c1 = (float)((double)e.lr * mu_next / (1.0 - p.mu_product * mu_next));
+    } else if (opt->kind == SPK_OPT_ASGD) {
+      // torch.optim.ASGD: the step uses eta of the PREVIOUS step, eta_0 = lr, eta_t = lr / (1 + lambd lr t)^alpha
+      const double lam = opt->lr_decay, t1 = (double)(p.step - 1);
+      e.c0 = (float)((double)e.lr / std::pow(1.0 + lam * (double)e.lr * t1, (double)opt->alpha));
+      e.c1 = (float)lam;
     } else if (opt->kind == SPK_OPT_RADAM) {
       const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
       const double rho_t = rho_inf - 2.0 * (double)p.step * std::pow(b2, (double)p.step) / bc2;

@@ -503,6 +503,10 @@ __global__ void adam_multi_kernel(float* __restrict__ p, const float* __restrict
 //   6 NAdam     m, v as Adam;  den = sqrt(v)/bc2s + eps;  p -= c0 g/den + c1 m/den   c0 = lr(1-mu_t)/(1-prod), c1 = lr mu_next/(1-prod mu_next)
 //   7 RAdam     m, v as Adam;  c1 > 0 (rho_t > 5): p -= (m/bc1) c0 / (sqrt(v) + eps), c0 = lr rect sqrt(bc2);  else p -= lr m/bc1
 //   8 Adadelta  sq = rho sq + (1-rho) g^2;  d = sqrt(acc + eps)/sqrt(sq + eps) g;  acc = rho acc + (1-rho) d^2;  p -= lr d
+//   9 ASGD      p = p (1 - lambd eta) - eta g,  eta = lr / (1 + lambd lr (t-1))^alpha  (c0 = eta, c1 = lambd; the averaged
+//               copy `ax` torch keeps beside the parameters is never read by a training loop and is not kept)
+//  10 Rprop     s = g prev: > 0 step *= eta+, < 0 step *= eta-, g = 0;  step clamped to [min, max];  p -= sign(g) step;
+//               prev = g   (mm = prev, vv = step size, first step: step size = lr; b1 = eta-, b2 = eta+, eps / alpha = bounds)
 __global__ void opt_generic_kernel(int kind, float* __restrict__ p, const float* __restrict__ g,
                                    float* __restrict__ m, float* __restrict__ v, OptTable t, float b1, float b2,
                                    float eps, float wd, float momentum, float gscale, float alpha) {
@@ -515,8 +519,24 @@ __global__ void opt_generic_kernel(int kind, float* __restrict__ p, const float*
     float pi = pp[i];
     float gi = gg[i] * gscale;
     if (kind == 2) pi *= 1.f - e.lr * wd;
-    else gi += wd * pi;
+    else if (kind != 10) gi += wd * pi;
     switch (kind) {
+      case 9: {
+        pi = pi * (1.f - e.c1 * e.c0) - e.c0 * gi;
+        break;
+      }
+      case 10: {
+        const float prev = e.first ? 0.f : mm[i];
+        float ss = e.first ? e.lr : vv[i];
+        const float sg = gi * prev;
+        ss *= sg > 0.f ? b2 : (sg < 0.f ? b1 : 1.f);
+        ss = fminf(fmaxf(ss, eps), alpha);
+        if (sg < 0.f) gi = 0.f;
+        pi -= (gi > 0.f ? ss : (gi < 0.f ? -ss : 0.f));
+        mm[i] = gi;
+        vv[i] = ss;
+        break;
+      }
       case 2: {
         const float mi = b1 * mm[i] + (1.f - b1) * gi, vi = b2 * vv[i] + (1.f - b2) * gi * gi;
         mm[i] = mi; vv[i] = vi;

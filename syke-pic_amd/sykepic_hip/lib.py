@@ -49,6 +49,7 @@ class LayerTime(C.Structure):
 LAYOUT_NCHW, LAYOUT_NHWC = 0, 1
 DTYPE_F32, DTYPE_I64, DTYPE_U8 = 0, 1, 2
 OPT_SGD, OPT_ADAM, OPT_ADAMW, OPT_RMSPROP, OPT_ADAGRAD, OPT_ADAMAX, OPT_NADAM, OPT_RADAM, OPT_ADADELTA = range(9)
+OPT_ASGD, OPT_RPROP = 9, 10
 
 # every symbol include/sykepic_hip.h declares: (restype, argtypes)
 _P = C.c_void_p

@@ -19,17 +19,19 @@ _DEFAULTS = {
     "NAdam": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, momentum_decay=4e-3),
     "RAdam": dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
     "Adadelta": dict(rho=0.9, eps=1e-6, weight_decay=0.0),
+    "ASGD": dict(lambd=1e-4, alpha=0.75, t0=1e6, weight_decay=0.0),
+    "Rprop": dict(etas=(0.5, 1.2), step_sizes=(1e-6, 50.0)),
 }
 _KINDS = {"SGD": lib.OPT_SGD, "Adam": lib.OPT_ADAM, "AdamW": lib.OPT_ADAMW, "RMSprop": lib.OPT_RMSPROP,
           "Adagrad": lib.OPT_ADAGRAD, "Adamax": lib.OPT_ADAMAX, "NAdam": lib.OPT_NADAM, "RAdam": lib.OPT_RADAM,
-          "Adadelta": lib.OPT_ADADELTA}
+          "Adadelta": lib.OPT_ADADELTA, "ASGD": lib.OPT_ASGD, "Rprop": lib.OPT_RPROP}
 
 
 class HipOptimizer:
     def __init__(self, net, name, param_groups, **kw):
         if name not in _DEFAULTS:
             raise ValueError(f"optimizer {name!r} has no MI355X kernel (supported: {sorted(_DEFAULTS)}; LBFGS needs a "
-                             "closure the reference's loop does not pass, ASGD / Rprop / SparseAdam are not built)")
+                             "closure the reference's loop does not pass, SparseAdam needs sparse gradients)")
         self.net, self.name = net, name
         self.defaults = dict(_DEFAULTS[name])
         self.defaults.update(kw)
@@ -73,6 +75,14 @@ class HipOptimizer:
         d.momentum_decay = float(self.defaults.get("momentum_decay", 4e-3))
         d.lr_decay = float(self.defaults.get("lr_decay", 0.0))
         d.initial_accumulator_value = float(self.defaults.get("initial_accumulator_value", 0.0))
+        if self.name == "ASGD":      # lambd travels in lr_decay, the power alpha in alpha (include/sykepic_hip.h)
+            d.lr_decay = float(self.defaults["lambd"])
+            d.alpha = float(self.defaults["alpha"])
+            if float(self.defaults["t0"]) < 1e5:
+                raise ValueError("ASGD: the averaged parameters (t0) are not kept on the MI355X path")
+        elif self.name == "Rprop":   # etas in beta1 / beta2, step-size bounds in eps / alpha
+            d.beta1, d.beta2 = (float(v) for v in self.defaults["etas"])
+            d.eps, d.alpha = (float(v) for v in self.defaults["step_sizes"])
         self.net.optim_step(d)
 
     def __repr__(self):

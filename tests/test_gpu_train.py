@@ -353,7 +353,8 @@ def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
     assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == gold["group_sizes"].tolist()
 
 
-@pytest.mark.parametrize("name", ["SGD", "Adam", "AdamW", "RMSprop", "Adagrad", "Adamax", "NAdam", "RAdam", "Adadelta"])
+@pytest.mark.parametrize("name", ["SGD", "Adam", "AdamW", "RMSprop", "Adagrad", "Adamax", "NAdam", "RAdam", "Adadelta", "ASGD",
+                                  "Rprop"])
 def test_optimizers_match_torch_update_rule(name):
     """The reference builds `getattr(optim, name)(groups)` with nothing but `lr` (train.py:131-138): every
     first-order torch.optim class with its torch defaults has a fused multi-tensor kernel.  After each of 3 steps
