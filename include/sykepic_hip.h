@@ -176,6 +176,9 @@ int spk_model_calibrate_fp8(spk_model* m, const void* x_dev, int n, int h, int w
  * effect at the next spk_model_calibrate_fp8.  spk_model_num_fp8_blocks returns how many blocks qualify. */
 int spk_model_set_fp8_blocks(spk_model* m, const unsigned char* flags, int n_blocks);
 int spk_model_num_fp8_blocks(spk_model* m);
+/* BatchNorm2d(eps, momentum) of every BatchNorm in the graph: torch's defaults 1e-5 / 0.1 unless the model family says
+ * otherwise (torchvision's efficientnet_b5..b7 are built with eps 1e-3, momentum 0.01). */
+int spk_model_set_bn(spk_model* m, float eps, float momentum);
 /* Dropout mask seed for training steps. */
 int spk_model_set_seed(spk_model* m, uint64_t seed);
 

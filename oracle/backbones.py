@@ -112,9 +112,12 @@ def _make_divisible(v, divisor=8):
     return new_v
 
 
+_BN = {"eps": 1e-5, "momentum": 0.1}   # norm_layer of the EfficientNet being built (b5-b7: eps 1e-3, momentum 0.01)
+
+
 def _cna(cin, cout, k, stride=1, groups=1, act=True):
     """torchvision.ops.Conv2dNormActivation(norm=BatchNorm2d, activation=SiLU or None)."""
-    mods = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout)]
+    mods = [nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout, **_BN)]
     if act:
         mods.append(nn.SiLU(inplace=True))
     return nn.Sequential(*mods)
@@ -175,12 +178,15 @@ class EfficientNet(nn.Module):
         return self.classifier(self.avgpool(self.features(x)).flatten(1))
 
 
-_EFF = {  # width, depth, dropout (torchvision efficientnet_b0..b4; b5-b7 use a different BatchNorm eps)
+_EFF = {  # width, depth, dropout (torchvision efficientnet_b0..b7; b5-b7 are built with BatchNorm2d(eps=1e-3, momentum=0.01))
     "efficientnet_b0": (1.0, 1.0, 0.2),
     "efficientnet_b1": (1.0, 1.1, 0.2),
     "efficientnet_b2": (1.1, 1.2, 0.3),
     "efficientnet_b3": (1.2, 1.4, 0.3),
     "efficientnet_b4": (1.4, 1.8, 0.4),
+    "efficientnet_b5": (1.6, 2.2, 0.4),
+    "efficientnet_b6": (1.8, 2.6, 0.5),
+    "efficientnet_b7": (2.0, 3.1, 0.5),
 }
 
 _CFG = {
@@ -196,7 +202,12 @@ def make(name, weights=None):
     """Stand-in for ``torchvision.models.<name>(weights=...)``; pretrained
     weights cannot be fetched (no network), so ``weights`` is ignored."""
     if name in _EFF:
-        return EfficientNet(*_EFF[name])
+        big = name in ("efficientnet_b5", "efficientnet_b6", "efficientnet_b7")
+        _BN.update(eps=1e-3 if big else 1e-5, momentum=0.01 if big else 0.1)
+        try:
+            return EfficientNet(*_EFF[name])
+        finally:
+            _BN.update(eps=1e-5, momentum=0.1)
     block, depths = _CFG[name]
     return ResNet(block, depths)
 

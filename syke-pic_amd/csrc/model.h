@@ -134,6 +134,7 @@ struct spk_model {
   hipEvent_t grad_ev[3] = {nullptr, nullptr, nullptr};
 
   uint64_t seed = 0;
+  float bn_eps = 1e-5f, bn_momentum = 0.1f;   // BatchNorm2d(eps, momentum) of the graph (spk_model_set_bn)
   TrainState* train = nullptr;
 
   int img0 = 0;                 // first image of the chunk the eval executor is working on (prefix micro-batching)

@@ -452,6 +452,14 @@ extern "C" int spk_model_set_split_ops(spk_model* m, const unsigned char* flags,
   return SPK_OK;
 }
 
+extern "C" int spk_model_set_bn(spk_model* m, float eps, float momentum) {
+  if (!m || !(eps > 0.f) || !(momentum >= 0.f && momentum <= 1.f)) return fail(SPK_ERR_ARG, "set_bn: bad arguments");
+  m->bn_eps = eps;
+  m->bn_momentum = momentum;
+  m->dirty = true;   // the eval-BN fold depends on eps
+  return SPK_OK;
+}
+
 extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
   if (!m) return fail(SPK_ERR_ARG, "null model");
   m->seed = seed;
@@ -501,7 +509,7 @@ int spk_commit(spk_model* m) {
     float* bi = sc + L.cout_p;
     if (L.cout_p != L.d.cout)  // padded output channels: scale = shift = 0
       HIP_TRY(hipMemsetAsync(sc, 0, (size_t)2 * L.cout_p * 4, m->stream));
-    if (spk_launch_bn_fold(m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean), m->P(L.p_var), 1e-5f, sc, bi,
+    if (spk_launch_bn_fold(m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean), m->P(L.p_var), m->bn_eps, sc, bi,
                            L.d.cout, m->stream))
       return fail(SPK_ERR_HIP, "bn_fold launch failed");
     int r;

@@ -475,13 +475,13 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         if (!m->effnet) {
           K_TRY(spk_launch_bn_finalize(part, m_tiles, C, (double)M, m->P(L.p_g), m->P(L.p_b),
                                        m->P(L.p_mean), m->P(L.p_var), st, st + C, st + 2 * C, st + 3 * C,
-                                       1e-5f, 0.1f, tmp, s), "bn_finalize");
+                                       m->bn_eps, m->bn_momentum, tmp, s), "bn_finalize");
           K_TRY(spk_launch_bn_apply(t->RAW(i), st + 2 * C, st + 3 * C,
                                     L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr,
                                     (bf16_t*)m->T(L.d.dst), t->MASK(i), (size_t)M * C, C, L.d.relu, s), "bn_apply");
         } else {
           K_TRY(spk_launch_bna_finalize(part, m_tiles, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
-                                        m->P(L.p_var), st, 1e-5f, 0.1f, tmp, s), "bn_finalize");
+                                        m->P(L.p_var), st, m->bn_eps, m->bn_momentum, tmp, s), "bn_finalize");
           float* rs = nullptr;
           if (t->conv[i].rs_off) {   // StochasticDepth(p, "row") on the residual branch, train mode
             rs = (float*)((char*)t->arena + t->conv[i].rs_off);
@@ -506,7 +506,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         mark(m, PH_CONV_FWD);
         L.nbt += 1;
         K_TRY(spk_launch_bna_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
-                                      m->P(L.p_var), st, 1e-5f, 0.1f, tmp, s), "bn_finalize");
+                                      m->P(L.p_var), st, m->bn_eps, m->bn_momentum, tmp, s), "bn_finalize");
         K_TRY(spk_launch_bna_apply(t->RAW(i), st + 2 * C, st + 3 * C, nullptr, nullptr, (bf16_t*)m->T(L.d.dst), M, C,
                                    o.h * o.w, L.d.relu, s), "bn_apply");
         mark(m, PH_BN_FWD);

@@ -34,10 +34,19 @@ _EFFNETS = {
     "efficientnet_b2": (1.1, 1.2),
     "efficientnet_b3": (1.2, 1.4),
     "efficientnet_b4": (1.4, 1.8),
+    "efficientnet_b5": (1.6, 2.2),
+    "efficientnet_b6": (1.8, 2.6),
+    "efficientnet_b7": (2.0, 3.1),
 }
 # expand ratio, kernel, stride, input channels, output channels, layers (B0 baseline; Tan & Le 2019, table 1)
 _MBCONV = ((1, 3, 1, 32, 16, 1), (6, 3, 2, 16, 24, 2), (6, 5, 2, 24, 40, 2), (6, 3, 2, 40, 80, 3),
            (6, 5, 1, 80, 112, 3), (6, 5, 2, 112, 192, 4), (6, 3, 1, 192, 320, 1))
+
+
+# BatchNorm2d(eps, momentum) of the backbone: torch's defaults, except torchvision's efficientnet_b5..b7
+# (norm_layer = partial(nn.BatchNorm2d, eps=0.001, momentum=0.01))
+def bn_params(network):
+    return (1e-3, 0.01) if network in ("efficientnet_b5", "efficientnet_b6", "efficientnet_b7") else (1e-5, 0.1)
 
 
 def supported_networks():

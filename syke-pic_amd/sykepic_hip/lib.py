@@ -72,6 +72,7 @@ SYMBOLS = {
     "spk_model_set_split_ops": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "spk_model_set_fp8": (C.c_int, [_P, C.c_int]),
     "spk_model_calibrate_fp8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "spk_model_set_bn": (C.c_int, [_P, C.c_float, C.c_float]),
     "spk_model_set_fp8_blocks": (C.c_int, [_P, _P, C.c_int]),
     "spk_model_num_fp8_blocks": (C.c_int, [_P]),
     "spk_model_set_seed": (C.c_int, [_P, C.c_uint64]),

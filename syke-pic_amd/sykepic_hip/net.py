@@ -151,6 +151,9 @@ class HipNet:
         lib.check(self._lib.spk_model_create(descs, len(descs), self.graph.in_chans, self.num_classes,
                                              idx, C.byref(handle)))
         self._h = handle
+        eps, momentum = arch.bn_params(name)
+        if (eps, momentum) != (1e-5, 0.1):
+            lib.check(self._lib.spk_model_set_bn(self._h, eps, momentum))
         self.training = True
         self._params = OrderedDict()
         self._build_views()

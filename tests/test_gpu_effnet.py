@@ -191,3 +191,33 @@ def test_efficientnet_through_prob_workflow(tmp_path, golden_dir):
     assert np.abs(got - want).max() < 5e-3 and (got.argmax(1) == want.argmax(1)).all()
     back = net.state_dict()
     assert all(torch.equal(back[k].cpu(), v) for k, v in ref.state_dict().items())
+
+
+def test_efficientnet_b5_uses_its_own_batchnorm_eps():
+    """torchvision builds efficientnet_b5..b7 with BatchNorm2d(eps=1e-3, momentum=0.01); the eval-BN fold must use that
+    eps (`spk_model_set_bn`, set by HipNet from `arch.bn_params`).  Running variances are made SMALL here (x 1e-3), where
+    eps = 1e-3 against 1e-5 changes the folded scale by up to 30x: probabilities must follow the oracle module (which
+    carries eps in its BatchNorm2d layers) and NOT what eps = 1e-5 would give."""
+    from oracle import refnet
+    from sykepic_hip import arch
+    from sykepic_hip.net import HipNet
+    assert arch.bn_params("efficientnet_b5") == (1e-3, 0.01) and arch.bn_params("efficientnet_b4") == (1e-5, 0.1)
+    g = arch.build_graph("efficientnet_b5", 7, head=(32,))
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=4, logit_gain=4.0)
+    ref = refnet.load_numpy_state(refnet.RefNet("efficientnet_b5", 7, head=(32,)), sd)
+    xf = torch.from_numpy(synth.synth_images(4, 3, 96, 96, seed=8))
+    refnet.calibrate_bn(ref, xf)
+    sd = {k: v.numpy().copy() for k, v in ref.state_dict().items()}
+    net = HipNet("efficientnet_b5", 7, weights=None, head=(32,))
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    net.eval()
+    pr = refnet.probabilities(ref, xf).numpy()
+    pg = net.probabilities(xf.cuda()).cpu().numpy()
+    assert np.abs(pg - pr).max() < 4e-3, float(np.abs(pg - pr).max())     # the fresh-image bound of the family (above)
+    # the same weights through a module with torch's default eps: a different function
+    import torch.nn as nn
+    for mod in ref.modules():
+        if isinstance(mod, nn.BatchNorm2d):
+            mod.eps = 1e-5
+    p_wrong = refnet.probabilities(ref, xf).numpy()
+    assert np.abs(p_wrong - pr).max() > 5 * np.abs(pg - pr).max()

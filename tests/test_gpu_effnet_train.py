@@ -110,12 +110,15 @@ def test_backward_matches_teacher_forced_autograd(network, hw, n):
     assert not bad, bad[:8]
 
 
-def test_forward_train_mode_matches_oracle_layer_by_layer():
+@pytest.mark.parametrize("network", ["efficientnet_b0", "efficientnet_b5"])
+def test_forward_train_mode_matches_oracle_layer_by_layer(network):
     """Train-mode forward (batch statistics, SiLU, squeeze-excitation gates, residual adds) of every layer from the
-    GPU's own input: <= 6e-3 relative L2 (bf16 storage); running statistics after the step <= 1e-3."""
+    GPU's own input: <= 6e-3 relative L2 (bf16 storage); running statistics after the step <= 2e-3.  efficientnet_b5
+    stands for b5..b7, which torchvision builds with BatchNorm2d(eps=1e-3, momentum=0.01) (`spk_model_set_bn`)."""
     from oracle import graph_eval
     classes, n, hw = 10, 8, 64
-    g, specs, state, net = _net("efficientnet_b0", classes, seed=7)
+    eps, mom = arch.bn_params(network)
+    g, specs, state, net = _net(network, classes, seed=7)
     x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=3))
     y = torch.from_numpy(synth.synth_labels(n, classes, seed=4))
     net.train()
@@ -127,7 +130,7 @@ def test_forward_train_mode_matches_oracle_layer_by_layer():
         ins = {op.src: forced[op.src] if op.src else x.bfloat16().float()}
         if op.res >= 0:
             ins[op.res] = forced[op.res]
-        v = _layer(op, state, ins)
+        v = _layer(op, state, ins, eps)
         r = _rel(forced[op.dst], v)
         if r > worst[1]:
             worst = (op.name or str(op.kind), r)
@@ -142,22 +145,22 @@ def test_forward_train_mode_matches_oracle_layer_by_layer():
                                          groups=groups)
         mean = y32.mean((0, 2, 3))
         var = y32.var((0, 2, 3), unbiased=True)
-        rm = 0.9 * state[op.bn + ".running_mean"] + 0.1 * mean
-        rv = 0.9 * state[op.bn + ".running_var"] + 0.1 * var
+        rm = (1 - mom) * state[op.bn + ".running_mean"] + mom * mean
+        rv = (1 - mom) * state[op.bn + ".running_var"] + mom * var
         assert _rel(after[op.bn + ".running_mean"], rm) < 2e-3, op.bn
         assert _rel(after[op.bn + ".running_var"], rv) < 2e-3, op.bn
         assert int(after[op.bn + ".num_batches_tracked"]) == int(state[op.bn + ".num_batches_tracked"]) + 1
     print(f"worst layer forward {worst[1]:.3e} at {worst[0]}")
 
 
-def _layer(op, state, ins):
+def _layer(op, state, ins, eps=1e-5):
     """One op of the graph in torch fp32 from given inputs (train-mode BatchNorm)."""
     import torch.nn.functional as F
     a = ins[op.src]
     if op.kind in (arch.OP_CONV, arch.OP_DWCONV):
         groups = op.cin if op.kind == arch.OP_DWCONV else 1
         v = F.conv2d(a, state[op.name + ".weight"].bfloat16().float(), None, op.stride, op.pad, groups=groups)
-        v = F.batch_norm(v, None, None, state[op.bn + ".weight"], state[op.bn + ".bias"], True, 0.1, 1e-5)
+        v = F.batch_norm(v, None, None, state[op.bn + ".weight"], state[op.bn + ".bias"], True, 0.1, eps)
         if op.res >= 0:
             v = v + ins[op.res]
         act = int(op.relu)
