@@ -25,13 +25,13 @@ def test_state_dict_layout_matches_torch_module():
             assert sum(int(np.prod(s)) for k, s, kind in specs if not kind.startswith(("bn_mean", "bn_var", "bn_nbt"))) == nparams
     assert abs(arch.conv_flops_per_image(arch.build_graph("resnet50", 50), 224, 224) - 8.175e9) < 5e6
     with pytest.raises(ValueError):
-        arch.build_graph("efficientnet_b7", 50)   # BatchNorm eps 1e-3 variants are not built
+        arch.build_graph("efficientnet_v2_s", 50)   # not a family of the MI355X path
 
 
 def test_efficientnet_graph_matches_torch_module():
     """state_dict layout, MAC count (1.396 G dense + 0.1024 G depthwise for B4) and the
     block structure of the EfficientNet graphs."""
-    for network in ("efficientnet_b0", "efficientnet_b4"):
+    for network in ("efficientnet_b0", "efficientnet_b4", "efficientnet_b6"):
         g = arch.build_graph(network, 50)
         specs = arch.param_specs(g)
         ref = refnet.RefNet(network, 50).state_dict()
