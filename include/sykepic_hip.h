@@ -45,7 +45,7 @@ extern "C" {
 #define SPK_OP_GAVGPOOL 3  /* AdaptiveAvgPool2d(1) + flatten */
 #define SPK_OP_LINEAR 4    /* Linear with bias, no activation (head) */
 #define SPK_OP_DROPOUT 5   /* Dropout(p) in the head */
-/* EfficientNet (torchvision MBConv; eval path only):
+/* EfficientNet (torchvision MBConv; eval and, since round 3, training):
  *   DWCONV: depthwise Conv2d(C, C, k, stride, pad=(k-1)/2, groups=C, bias=False) + BatchNorm2d + activation
  *   SE:     SqueezeExcitation(C, squeeze = `k`): avgpool -> fc1 (1x1 conv, bias) -> SiLU -> fc2 -> Sigmoid -> x * s;
  *           `name` is the module prefix (name.fc1.weight ...), cin = cout = C. */
