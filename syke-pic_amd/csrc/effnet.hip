@@ -480,7 +480,7 @@ int spk_dw_chunks(int n, int hw, int c_p) {
 
 int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const float* bias, bf16_t* y, float* partial,
                       int n, int h, int wid, int c_p, int ho, int wo, int k, int stride, int act, int dt, hipStream_t s) {
-  if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || dt != DT_F16) return -2;
+  if ((k != 3 && k != 5) || (stride != 1 && stride != 2) || (dt != DT_F16 && dt != DT_BF16)) return -2;
   constexpr int PX = 4;
   const int groups = ho * ((wo + PX - 1) / PX);
   const int chunks = spk_dw_chunks(n, groups, c_p);
@@ -488,13 +488,17 @@ int spk_launch_dwconv(const bf16_t* x, const float* w, const float* scale, const
   const int tc = (c8 < 32 ? c8 : 32) * 8;
   const size_t lds = (size_t)std::max((k * k + 2) * tc, 256 / (tc / 8) * tc) * 4;
   const dim3 grid(ctiles, n * chunks);
-#define SPK_DW(K, S)                                                                                              \
-  hipLaunchKernelGGL((dwconv_kernel<DT_F16, K, S, PX>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, \
+  // bf16: the training step's depthwise forward (and its stride-1 data gradient, a correlation with the flipped window)
+#define SPK_DW(D, K, S)                                                                                            \
+  hipLaunchKernelGGL((dwconv_kernel<D, K, S, PX>), grid, dim3(256), lds, s, x, w, scale, bias, y, partial, h, wid, \
                      c_p, ho, wo, act, chunks)
-  if (k == 3 && stride == 1) SPK_DW(3, 1);
-  else if (k == 3) SPK_DW(3, 2);
-  else if (stride == 1) SPK_DW(5, 1);
-  else SPK_DW(5, 2);
+#define SPK_DW_ALL(D)                         \
+  if (k == 3 && stride == 1) SPK_DW(D, 3, 1); \
+  else if (k == 3) SPK_DW(D, 3, 2);           \
+  else if (stride == 1) SPK_DW(D, 5, 1);      \
+  else SPK_DW(D, 5, 2)
+  if (dt == DT_F16) { SPK_DW_ALL(DT_F16); } else { SPK_DW_ALL(DT_BF16); }
+#undef SPK_DW_ALL
 #undef SPK_DW
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

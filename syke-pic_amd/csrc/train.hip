@@ -40,7 +40,8 @@ struct ConvTrain {
   size_t wfwd_off = 0;      // bf16 [Cout][K] forward image
   size_t wdg_off = 0;       // bf16 [Cin][taps][Cout] dgrad image
   size_t dwt_off = 0;       // depthwise conv: fp32 tap-major weights [taps][C] (floats into TrainState::dwt)
-  size_t se_off = 0;        // squeeze-excitation: pooled [n][C], u1 [n][S], h1 [n][S], gate [n][C] floats kept for backward
+  size_t se_off = 0;        // squeeze-excitation: pooled [n][C], u1 [n][S], h1 [n][S], gate [n][C] floats kept for backward,
+                            // then du2 [n][C], du1 [n][S]: per layer, the side stream's weight-gradient kernel reads them
   size_t rs_off = 0;        // stochastic depth: per-image factor [n] floats (0: none)
 };
 
@@ -66,6 +67,8 @@ struct TrainState {
   bf16_t* wpack = nullptr; // bf16 forward + dgrad weight images
   float* stats = nullptr;  // per-conv mean/invstd/scale/shift
   float* dwt = nullptr;    // depthwise weights, tap-major (EfficientNet)
+  float* unit = nullptr;   // [unit_c] ones, [unit_c] zeros
+  size_t unit_c = 0;
   std::vector<ConvTrain> conv;  // indexed by layer
   bool weights_dirty = true;
   bool sgd_started = false;
@@ -85,6 +88,7 @@ struct TrainState {
   hipEvent_t ev_dy_ready[2] = {nullptr, nullptr};   // main: dy buffer written
   hipEvent_t ev_dy_free[2] = {nullptr, nullptr};    // side: wgrad has read the dy buffer
   hipEvent_t ev_side_done = nullptr;
+  hipEvent_t ev_se = nullptr;                       // main: gate gradients of a squeeze-excitation layer written
   bool dy_busy[2] = {false, false};
   int dy_slot = 0;
   size_t part_floats = 0, slab_floats = 0;
@@ -104,12 +108,14 @@ void spk_train_free(spk_model* m) {
   if (t->wpack) hipFree(t->wpack);
   if (t->stats) hipFree(t->stats);
   if (t->dwt) hipFree(t->dwt);
+  if (t->unit) hipFree(t->unit);
   if (t->side) hipStreamDestroy(t->side);
   for (int i = 0; i < 2; ++i) {
     if (t->ev_dy_ready[i]) hipEventDestroy(t->ev_dy_ready[i]);
     if (t->ev_dy_free[i]) hipEventDestroy(t->ev_dy_free[i]);
   }
   if (t->ev_side_done) hipEventDestroy(t->ev_side_done);
+  if (t->ev_se) hipEventDestroy(t->ev_se);
   delete t;
   m->train = nullptr;
 }
@@ -144,7 +150,7 @@ static int ensure_state(spk_model* m) {
   t->conv.resize(m->layers.size());
   // channel counts as the training plan lays them out: cout_p / cin_p (= the layer's own for the ResNets, whose widths
   // are multiples of 64; rounded up to 64 for the EfficientNets)
-  size_t w = 0, st = 0, dw = 0;
+  size_t w = 0, st = 0, dw = 0, unit_c = 0;
   for (size_t i = 0; i < m->layers.size(); ++i) {
     const Layer& L = m->layers[i];
     ConvTrain& c = t->conv[i];
@@ -152,7 +158,8 @@ static int ensure_state(spk_model* m) {
       c.stat_off = st;
       st += (size_t)4 * L.cout_p;
       c.dwt_off = dw;
-      dw += (size_t)L.d.k * L.d.k * L.cout_p;
+      dw += (size_t)2 * L.d.k * L.d.k * L.cout_p;   // + the flipped window (dw_pack_kernel)
+      unit_c = std::max(unit_c, (size_t)L.cout_p);
       continue;
     }
     if (L.d.kind != SPK_OP_CONV) continue;
@@ -166,6 +173,13 @@ static int ensure_state(spk_model* m) {
   HIP_TRY(hipMalloc((void**)&t->wpack, std::max<size_t>(w, 8) * 2));
   HIP_TRY(hipMalloc((void**)&t->stats, std::max<size_t>(st, 8) * 4));
   HIP_TRY(hipMalloc((void**)&t->dwt, std::max<size_t>(dw, 8) * 4));
+  if (unit_c) {   // [C] ones, [C] zeros: the depthwise kernel shared with the eval path applies a per-channel a*x + b
+    std::vector<float> unit(2 * unit_c, 0.f);
+    std::fill(unit.begin(), unit.begin() + unit_c, 1.f);
+    HIP_TRY(hipMalloc((void**)&t->unit, unit.size() * 4));
+    HIP_TRY(hipMemcpy(t->unit, unit.data(), unit.size() * 4, hipMemcpyHostToDevice));
+    t->unit_c = unit_c;
+  }
   static const bool side_wgrad = !getenv("SPK_WGRAD_STREAM") || atoi(getenv("SPK_WGRAD_STREAM")) != 0;
   if (side_wgrad) {
     {
@@ -182,6 +196,7 @@ static int ensure_state(spk_model* m) {
       HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_free[i], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&t->ev_side_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_se, hipEventDisableTiming));
   }
   return SPK_OK;
 }
@@ -239,10 +254,10 @@ static int plan_train(spk_model* m, int n, int h, int w) {
         total += al256((size_t)n * 4);
       }
     } else if (L.d.kind == SPK_OP_SE) {
-      const size_t fl = (size_t)n * (2 * o.c + 2 * L.d.k);
+      const size_t fl = (size_t)n * (3 * o.c + 3 * L.d.k);
       t->conv[i].se_off = total;
       total += al256(fl * 4);
-      // shared scratch: pool partials [n][chunks][C], dgate / du2 / dpool [n][C] each, dh1 / du1 [n][S] each
+      // shared scratch: pool partials [n][chunks][C], dpool [n][C]
       max_se = std::max(max_se, (size_t)n * ((size_t)(spk_se_chunks(o.h * o.w) + 3) * o.c + 2 * L.d.k));
     } else if (L.d.kind == SPK_OP_MAXPOOL) {
       t->idx_off = total;
@@ -266,7 +281,7 @@ static int plan_train(spk_model* m, int n, int h, int w) {
   for (size_t i = 0; i < m->layers.size(); ++i)   // pad columns of the gate pre-activations stay zero for good
     if (m->layers[i].d.kind == SPK_OP_SE) {
       const TDim& o = m->tdims[m->layers[i].d.dst];
-      HIP_TRY(hipMemsetAsync((char*)t->arena + t->conv[i].se_off, 0, (size_t)n * (2 * o.c + 2 * m->layers[i].d.k) * 4,
+      HIP_TRY(hipMemsetAsync((char*)t->arena + t->conv[i].se_off, 0, (size_t)n * (3 * o.c + 3 * m->layers[i].d.k) * 4,
                              m->stream));
     }
   t->cap_n = n; t->cap_h = h; t->cap_w = w;
@@ -444,6 +459,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   t->dy_slot = 0;
   unsigned char* pool_idx = (unsigned char*)((char*)t->arena + t->idx_off);
   const int nl = (int)m->layers.size();
+  int squeezed = -1;   // the squeeze-excitation layer whose pooled means the depthwise layer before it has written
 
   // ------------------------------ forward ------------------------------
   mark(m, -1);
@@ -500,15 +516,33 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         const int C = o.c, M = n * o.h * o.w;
         float* st = t->stats + t->conv[i].stat_off;
         int nbk = 0;
-        K_TRY(spk_launch_dw_train_fwd((const bf16_t*)m->T(L.d.src), t->dwt + t->conv[i].dwt_off, t->RAW(i), n, in.h, in.w,
-                                      C, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s), "depthwise fwd");
+        // the eval path's kernel (window weights in LDS, four adjacent outputs per thread) with a = 1, b = 0, no
+        // activation; -2: a window it does not have
+        int r = L.d.pad == (L.d.k - 1) / 2
+                    ? spk_launch_dwconv((const bf16_t*)m->T(L.d.src), t->dwt + t->conv[i].dwt_off, t->unit,
+                                        t->unit + t->unit_c, t->RAW(i), nullptr, n, in.h, in.w, C, o.h, o.w, L.d.k,
+                                        L.d.stride, 0, DT_BF16, s)
+                    : -2;
+        if (r == -2)
+          r = spk_launch_dw_train_fwd((const bf16_t*)m->T(L.d.src), t->dwt + t->conv[i].dwt_off, t->RAW(i), n, in.h, in.w,
+                                      C, L.d.k, L.d.stride, L.d.pad, o.h, o.w, s);
+        K_TRY(r, "depthwise fwd");
         K_TRY(spk_launch_col_stats(t->RAW(i), part, M, C, &nbk, s), "col_stats");
         mark(m, PH_CONV_FWD);
         L.nbt += 1;
         K_TRY(spk_launch_bna_finalize(part, nbk, C, L.d.cout, (double)M, m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean),
                                       m->P(L.p_var), st, m->bn_eps, m->bn_momentum, tmp, s), "bn_finalize");
-        K_TRY(spk_launch_bna_apply(t->RAW(i), st + 2 * C, st + 3 * C, nullptr, nullptr, (bf16_t*)m->T(L.d.dst), M, C,
-                                   o.h * o.w, L.d.relu, s), "bn_apply");
+        if (i + 1 < nl && m->layers[i + 1].d.kind == SPK_OP_SE && m->layers[i + 1].d.src == L.d.dst) {
+          // the squeeze of the layer behind rides on this pass (its pooled [n][C] is the head of that layer's block)
+          K_TRY(spk_launch_bna_apply_pool(t->RAW(i), st + 2 * C, st + 3 * C, (bf16_t*)m->T(L.d.dst),
+                                          (float*)((char*)t->arena + t->se_tmp_off),
+                                          (float*)((char*)t->arena + t->conv[i + 1].se_off), n, o.h * o.w, C, L.d.relu, s),
+                "bn_apply + squeeze");
+          squeezed = i + 1;
+        } else {
+          K_TRY(spk_launch_bna_apply(t->RAW(i), st + 2 * C, st + 3 * C, nullptr, nullptr, (bf16_t*)m->T(L.d.dst), M, C,
+                                     o.h * o.w, L.d.relu, s), "bn_apply");
+        }
         mark(m, PH_BN_FWD);
         break;
       }
@@ -521,7 +555,8 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* gate = h1 + (size_t)n * S;
         float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
-        K_TRY(spk_launch_pool_rows(a, nullptr, scratch, pooled, n, HW, C, 1.f / (float)HW, s), "se pool");
+        if (squeezed != i)
+          K_TRY(spk_launch_pool_rows(a, nullptr, scratch, pooled, n, HW, C, 1.f / (float)HW, s), "se pool");
         K_TRY(spk_launch_se_gate_fwd(pooled, m->P(L.p_w), m->P(L.p_b), m->P(L.p_w2), m->P(L.p_b2), u1, h1, gate, n, C, Cl, S,
                                      s), "se gates");
         K_TRY(spk_launch_se_scale(a, gate, (bf16_t*)m->T(L.d.dst), n, HW, C, s), "se scale");
@@ -669,8 +704,16 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         if (L.d.kind == SPK_OP_DWCONV) {
           const float* wt = t->dwt + t->conv[i].dwt_off;
           if (needs[L.d.src]) {
-            K_TRY(spk_launch_dw_dgrad(dy, wt, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n, in.h, in.w, C, L.d.k,
-                                      L.d.stride, L.d.pad, o.h, o.w, s), "depthwise dgrad");
+            // stride 1: dx = depthwise conv of dy with the flipped window (the forward kernel); else the gather kernel
+            int r = L.d.stride == 1 && !has_grad[L.d.src] && L.d.pad == (L.d.k - 1) / 2
+                        ? spk_launch_dwconv(dy, wt + (size_t)L.d.k * L.d.k * C, t->unit, t->unit + t->unit_c,
+                                            (bf16_t*)t->G(L.d.src), nullptr, n, o.h, o.w, C, in.h, in.w, L.d.k, 1, 0,
+                                            DT_BF16, s)
+                        : -2;
+            if (r == -2)
+              r = spk_launch_dw_dgrad(dy, wt, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n, in.h, in.w, C, L.d.k,
+                                      L.d.stride, L.d.pad, o.h, o.w, s);
+            K_TRY(r, "depthwise dgrad");
             mark(m, PH_CONV_DGRAD);
             has_grad[L.d.src] = 1;
           }
@@ -747,18 +790,24 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* h1 = u1 + (size_t)n * S;
         float* gate = h1 + (size_t)n * S;
         float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
-        float* dgate = scratch + (size_t)n * spk_se_chunks(HW) * C;   // becomes du2 in place
-        float* dpool = dgate + (size_t)n * C;
-        float* du1 = dpool + (size_t)n * C;
+        float* dgate = gate + (size_t)n * C;   // becomes du2 in place
+        float* du1 = dgate + (size_t)n * C;
+        float* dpool = scratch + (size_t)n * spk_se_chunks(HW) * C;
         const bf16_t* g = (const bf16_t*)t->G(L.d.dst);
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
         K_TRY(spk_launch_pool_rows(g, a, scratch, dgate, n, HW, C, 1.f, s), "se dgate");
         const Param &w1 = m->params[L.p_w], &b1 = m->params[L.p_b], &w2 = m->params[L.p_w2], &b2 = m->params[L.p_b2];
         K_TRY(spk_launch_se_gate_bwd(dgate, gate, u1, m->P(L.p_w), m->P(L.p_w2), du1, dpool, n, C, Cl, S, s), "se gates bwd");
+        hipStream_t ws = s;
+        if (side_on && (w1.requires_grad || b1.requires_grad || w2.requires_grad || b2.requires_grad)) {
+          ws = t->side;   // du2 / du1 are this layer's own: nothing on the main stream waits for the kernel
+          HIP_TRY(hipEventRecord(t->ev_se, s));
+          HIP_TRY(hipStreamWaitEvent(ws, t->ev_se, 0));
+        }
         K_TRY(spk_launch_se_wgrad(dgate, h1, du1, pooled, w1.requires_grad ? t->gbuf + w1.off : nullptr,
                                   b1.requires_grad ? t->gbuf + b1.off : nullptr,
                                   w2.requires_grad ? t->gbuf + w2.off : nullptr,
-                                  b2.requires_grad ? t->gbuf + b2.off : nullptr, n, C, Cl, S, s), "se wgrad");
+                                  b2.requires_grad ? t->gbuf + b2.off : nullptr, n, C, Cl, S, ws), "se wgrad");
         K_TRY(spk_launch_se_bwd_apply(g, gate, dpool, (bf16_t*)t->G(L.d.src), n, HW, C, s), "se bwd apply");
         mark(m, PH_BN_BWD);
         has_grad[L.d.src] = 1;

@@ -34,6 +34,8 @@ int spk_launch_dw_dgrad(const bf16_t* dy, const float* wt, bf16_t* dx, int accum
 int spk_dw_wgrad_rows(int M, int C);
 int spk_launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int C, int c_log,
                         int k, int stride, int pad, int ho, int wo, int* rows, hipStream_t s);
+int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part,
+                              float* pooled, int n, int HW, int C, int act, hipStream_t s);
 int spk_se_chunks(int HW);
 int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* out, int n, int HW, int C, float scale,
                          hipStream_t s);

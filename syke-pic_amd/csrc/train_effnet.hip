@@ -40,13 +40,19 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return act == SPK_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : 1.f;
 }
 
-// A thread owns 8-channel chunks (lane_c, lane_c + tpr, ...) and walks rows lane_r, lane_r + rif, ... of its block
+// A block owns rows [row0, row1) x the 8-channel groups [cb, ce) of channel tile `ct` of `cts`; a thread owns groups
+// cb + lane_c, cb + lane_c + tpr, ... and walks rows lane_r, lane_r + rif, ...  Wide tensors on few rows (the 7x7 and
+// 14x14 layers: 1152 channels x 6272 rows) are tiled along the channels: without tiles one thread per group walked all
+// the rows of its block one after the other, rif = 1, on 98 blocks - 40-60 us per pass whatever the tensor size.
 struct RowWalk {
-  int c8, tpr, rif, lane_c, lane_r, row0, row1;
+  int c8, tpr, rif, lane_c, lane_r, row0, row1, cb, ce;
   bool active;
-  __device__ RowWalk(int M, int C, int rows_per_block) {
+  __device__ RowWalk(int M, int C, int rows_per_block, int ct = 0, int cts = 1) {
     c8 = C >> 3;
-    tpr = c8 < 256 ? c8 : 256;
+    const int tile = (c8 + cts - 1) / cts;
+    cb = ct * tile;
+    ce = min(c8, cb + tile);
+    tpr = tile < 256 ? tile : 256;
     rif = 256 / tpr;
     lane_c = threadIdx.x % tpr;
     lane_r = threadIdx.x / tpr;
@@ -54,15 +60,29 @@ struct RowWalk {
     row0 = blockIdx.x * rows_per_block;
     row1 = min(M, row0 + rows_per_block);
   }
+  __device__ int tw() const { return ((c8 + (int)gridDim.y - 1) / (int)gridDim.y) * 8; }   // channels of a tile (grid.y tiles)
 };
+
+// rows in flight of a block [rif][2][TW] -> partials[block][2][C] (the tile's channels), fixed order
+__device__ __forceinline__ void walk_combine(const float* sm, float* __restrict__ partials, const RowWalk& w, int TW,
+                                             int C) {
+  const int nch = (w.ce - w.cb) * 8;
+  for (int i = threadIdx.x; i < 2 * nch; i += 256) {
+    const int which = i >= nch, col = i - which * nch;
+    float t = 0.f;
+    for (int r = 0; r < w.rif; ++r) t += sm[(r * 2 + which) * TW + col];
+    partials[((size_t)blockIdx.x * 2 + which) * C + w.cb * 8 + col] = t;
+  }
+}
 
 // ---- per-channel sum / sum of squares of a bf16 [M][C] tensor: partials[block][2][C] (the layout bn_finalize reads)
 __global__ __launch_bounds__(256) void col_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ partials,
                                                         int M, int C, int rows_per_block) {
-  extern __shared__ float sm[];  // [rif][2][C]
-  const RowWalk w(M, C, rows_per_block);
+  extern __shared__ float sm[];  // [rif][2][TW]
+  const RowWalk w(M, C, rows_per_block, blockIdx.y, gridDim.y);
+  const int TW = w.tw();
   if (w.active)
-    for (int cc = w.lane_c; cc < w.c8; cc += w.tpr) {
+    for (int cc = w.cb + w.lane_c; cc < w.ce; cc += w.tpr) {
       float s1[8], s2[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
@@ -74,16 +94,12 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const bf16_t* __restrict
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        sm[(w.lane_r * 2 + 0) * C + cc * 8 + j] = s1[j];
-        sm[(w.lane_r * 2 + 1) * C + cc * 8 + j] = s2[j];
+        sm[(w.lane_r * 2 + 0) * TW + (cc - w.cb) * 8 + j] = s1[j];
+        sm[(w.lane_r * 2 + 1) * TW + (cc - w.cb) * 8 + j] = s2[j];
       }
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    float t = 0.f;
-    for (int r = 0; r < w.rif; ++r) t += sm[r * 2 * C + i];
-    partials[(size_t)blockIdx.x * 2 * C + i] = t;
-  }
+  walk_combine(sm, partials, w, TW, C);
 }
 
 // ---- BatchNorm apply + activation (+ per-image factor) (+ shortcut): a = act(raw*scale + shift) * rs[img] + res
@@ -91,9 +107,9 @@ __global__ __launch_bounds__(256) void bna_apply_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ shift, const bf16_t* __restrict__ res,
                                                         const float* __restrict__ rowscale, bf16_t* __restrict__ out,
                                                         int M, int C, int HW, int act, int rows_per_block) {
-  const RowWalk w(M, C, rows_per_block);
+  const RowWalk w(M, C, rows_per_block, blockIdx.y, gridDim.y);
   if (!w.active) return;
-  for (int cc = w.lane_c; cc < w.c8; cc += w.tpr) {
+  for (int cc = w.cb + w.lane_c; cc < w.ce; cc += w.tpr) {
     float sc[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sc[j] = scale[cc * 8 + j]; sh[j] = shift[cc * 8 + j]; }
@@ -120,10 +136,11 @@ __global__ __launch_bounds__(256) void bna_bwd_reduce_kernel(
     const bf16_t* __restrict__ g, const bf16_t* __restrict__ raw, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ rowscale, float* __restrict__ partials, int M, int C, int HW, int act, int rows_per_block) {
-  extern __shared__ float sm[];  // [rif][2][C]
-  const RowWalk w(M, C, rows_per_block);
+  extern __shared__ float sm[];  // [rif][2][TW]
+  const RowWalk w(M, C, rows_per_block, blockIdx.y, gridDim.y);
+  const int TW = w.tw();
   if (w.active)
-    for (int cc = w.lane_c; cc < w.c8; cc += w.tpr) {
+    for (int cc = w.cb + w.lane_c; cc < w.ce; cc += w.tpr) {
       float s1[8], s2[8], sc[8], sh[8], mu[8], is[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -145,16 +162,12 @@ __global__ __launch_bounds__(256) void bna_bwd_reduce_kernel(
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        sm[(w.lane_r * 2 + 0) * C + cc * 8 + j] = s1[j];
-        sm[(w.lane_r * 2 + 1) * C + cc * 8 + j] = s2[j];
+        sm[(w.lane_r * 2 + 0) * TW + (cc - w.cb) * 8 + j] = s1[j];
+        sm[(w.lane_r * 2 + 1) * TW + (cc - w.cb) * 8 + j] = s2[j];
       }
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    float t = 0.f;
-    for (int r = 0; r < w.rif; ++r) t += sm[r * 2 * C + i];
-    partials[(size_t)blockIdx.x * 2 * C + i] = t;
-  }
+  walk_combine(sm, partials, w, TW, C);
 }
 
 // stage 3: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); the shortcut receives g itself
@@ -163,9 +176,9 @@ __global__ __launch_bounds__(256) void bna_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ coef, const float* __restrict__ rowscale, bf16_t* __restrict__ dy,
     bf16_t* __restrict__ g_res, int res_accumulate, int M, int C, int HW, int act, int rows_per_block) {
-  const RowWalk w(M, C, rows_per_block);
+  const RowWalk w(M, C, rows_per_block, blockIdx.y, gridDim.y);
   if (!w.active) return;
-  for (int cc = w.lane_c; cc < w.c8; cc += w.tpr) {
+  for (int cc = w.cb + w.lane_c; cc < w.ce; cc += w.tpr) {
     float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -309,6 +322,10 @@ __global__ void sd_rowscale_kernel(float* __restrict__ rs, int n, float p, unsig
 }
 
 // ---- 3x3 stride-2 pad-1 stem on the NHWC4 input: raw[p][co] = sum x[p@tap][ci] * bf16(w[co][tap][ci])
+// A thread owns 8 output channels of STEM_PX horizontally adjacent pixels: a weight read from LDS serves all of them and
+// the 2*STEM_PX+1 input columns of a row are loaded once (one pixel per thread re-read the 36 x 8 weights per pixel and
+// was bound by LDS reads: 412 us for 128 x 112 x 112 x 64).  Channel groups that are padding only store zeros.
+constexpr int STEM_PX = 4;
 __global__ __launch_bounds__(256) void stem3_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wgt,
                                                         bf16_t* __restrict__ y, int n, int h, int wd, int wstride,
                                                         int cin, int cout, int C, int ho, int wo) {
@@ -318,31 +335,59 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(const bf16_t* __restrict
     ws[i] = (co < cout && ci < cin) ? bf16_round(wgt[((size_t)co * 9 + tap) * cin + ci]) : 0.f;
   }
   __syncthreads();
-  const int c8 = C >> 3;
-  const size_t total = (size_t)n * ho * wo * c8;
+  constexpr int COLS = 2 * STEM_PX + 1;
+  const int c8 = C >> 3, c8l = (cout + 7) >> 3;
+  const int gpr = (wo + STEM_PX - 1) / STEM_PX;
+  const size_t total = (size_t)n * ho * gpr * c8;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cc = (int)(i % c8);
-    const size_t p = i / c8;
-    const int ow = (int)(p % wo), oh = (int)((p / wo) % ho), img = (int)(p / ((size_t)wo * ho));
-    float acc[8];
+    const size_t g = i / c8;
+    const int ow0 = (int)(g % gpr) * STEM_PX, oh = (int)((g / gpr) % ho), img = (int)(g / ((size_t)gpr * ho));
+    float acc[STEM_PX][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ih = oh * 2 + kh - 1;
-      if (ih < 0 || ih >= h) continue;
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iw = ow * 2 + kw - 1;
-        if (iw < 0 || iw >= wd) continue;
-        const uint2 xv = *(const uint2*)(x + (((size_t)img * h + ih) * wstride + iw) * 4);
-        const float xf[4] = {lo_f32<DT>(xv.x), hi_f32<DT>(xv.x), lo_f32<DT>(xv.y), hi_f32<DT>(xv.y)};
-        const float* wt = ws + (size_t)(kh * 3 + kw) * 4 * C + cc * 8;
+    for (int u = 0; u < STEM_PX; ++u)
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci)
+      for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
+    if (cc < c8l)
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 + kh - 1;
+        if (ih < 0 || ih >= h) continue;
+        uint2 raw[COLS];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += xf[ci] * wt[ci * C + j];
+        for (int col = 0; col < COLS; ++col) {
+          const int iw = ow0 * 2 - 1 + col;
+          const int iwc = min(max(iw, 0), wd - 1);
+          raw[col] = *(const uint2*)(x + (((size_t)img * h + ih) * wstride + iwc) * 4);
+          if ((unsigned)iw >= (unsigned)wd) raw[col] = make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float* wt = ws + (size_t)(kh * 3 + kw) * 4 * C + cc * 8;
+#pragma unroll
+          for (int ci = 0; ci < 3; ++ci) {
+            const float4 w0 = *(const float4*)(wt + ci * C), w1 = *(const float4*)(wt + ci * C + 4);
+#pragma unroll
+            for (int u = 0; u < STEM_PX; ++u) {
+              const uint2 q = raw[2 * u + kw];
+              const float xv = ci == 0 ? lo_f32<DT>(q.x) : (ci == 1 ? hi_f32<DT>(q.x) : lo_f32<DT>(q.y));
+              acc[u][0] += xv * w0.x; acc[u][1] += xv * w0.y; acc[u][2] += xv * w0.z; acc[u][3] += xv * w0.w;
+              acc[u][4] += xv * w1.x; acc[u][5] += xv * w1.y; acc[u][6] += xv * w1.z; acc[u][7] += xv * w1.w;
+            }
+          }
+          if (cin > 3) {
+            const float4 w0 = *(const float4*)(wt + 3 * C), w1 = *(const float4*)(wt + 3 * C + 4);
+#pragma unroll
+            for (int u = 0; u < STEM_PX; ++u) {
+              const float xv = hi_f32<DT>(raw[2 * u + kw].y);
+              acc[u][0] += xv * w0.x; acc[u][1] += xv * w0.y; acc[u][2] += xv * w0.z; acc[u][3] += xv * w0.w;
+              acc[u][4] += xv * w1.x; acc[u][5] += xv * w1.y; acc[u][6] += xv * w1.z; acc[u][7] += xv * w1.w;
+            }
+          }
+        }
       }
-    }
-    *(u32x4_t*)(y + p * C + cc * 8) = pack8(acc);
+#pragma unroll
+    for (int u = 0; u < STEM_PX; ++u)
+      if (ow0 + u < wo) *(u32x4_t*)(y + ((((size_t)img * ho + oh) * wo) + ow0 + u) * C + cc * 8) = pack8(acc[u]);
   }
 }
 
@@ -414,15 +459,22 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(const bf16_t* __restri
 
 // ---- depthwise conv ----
 // master [C_log][taps] fp32 -> tap-major [taps][C] rounded to bf16 values (zeros in the pad channels)
+// (+ the same with the window flipped, [taps][C] behind the first: the stride-1 data gradient is a depthwise conv of dy
+// with it)
 __global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int c_log, int C, int taps) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= taps * C) return;
   const int c = i % C, t = i / C;
-  wt[i] = c < c_log ? bf16_round(w[(size_t)c * taps + t]) : 0.f;
+  const float v = c < c_log ? bf16_round(w[(size_t)c * taps + t]) : 0.f;
+  wt[i] = v;
+  wt[(size_t)(2 * taps - 1 - t) * C + c] = v;
 }
 
+// Loads are unconditional (coordinates clamped into the image, the value zeroed by a select): the K loads of a window row
+// are in flight together.  With a branch around every tap each load was waited for before the next was issued.
+template <int K>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wt,
-                                                     bf16_t* __restrict__ y, int n, int h, int wd, int C, int k, int stride,
+                                                     bf16_t* __restrict__ y, int n, int h, int wd, int C, int stride,
                                                      int pad, int ho, int wo) {
   const int c8 = C >> 3;
   const size_t total = (size_t)n * ho * wo * c8;
@@ -430,19 +482,30 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const bf16_t* __restrict__ 
     const int cc = (int)(i % c8);
     const size_t p = i / c8;
     const int ow = (int)(p % wo), oh = (int)((p / wo) % ho), img = (int)(p / ((size_t)wo * ho));
+    const bf16_t* xi = x + (size_t)img * h * wd * C + cc * 8;
+    const float* wc = wt + cc * 8;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int kh = 0; kh < k; ++kh) {
+#pragma unroll(K == 3 ? 3 : 1)
+    for (int kh = 0; kh < K; ++kh) {
       const int ih = oh * stride + kh - pad;
-      if (ih < 0 || ih >= h) continue;
-      for (int kw = 0; kw < k; ++kw) {
+      const bool rowok = (unsigned)ih < (unsigned)h;
+      const int ihc = min(max(ih, 0), h - 1);
+      u32x4_t raw[K];
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
         const int iw = ow * stride + kw - pad;
-        if (iw < 0 || iw >= wd) continue;
+        const int iwc = min(max(iw, 0), wd - 1);
+        raw[kw] = *(const u32x4_t*)(xi + ((size_t)ihc * wd + iwc) * C);
+        if (!rowok || (unsigned)iw >= (unsigned)wd) raw[kw] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
         float xv[8];
-        unpack8(*(const u32x4_t*)(x + (((size_t)img * h + ih) * wd + iw) * C + cc * 8), xv);
-        const float4 w0 = *(const float4*)(wt + (size_t)(kh * k + kw) * C + cc * 8);
-        const float4 w1 = *(const float4*)(wt + (size_t)(kh * k + kw) * C + cc * 8 + 4);
+        unpack8(raw[kw], xv);
+        const float4 w0 = *(const float4*)(wc + (size_t)(kh * K + kw) * C);
+        const float4 w1 = *(const float4*)(wc + (size_t)(kh * K + kw) * C + 4);
         acc[0] += xv[0] * w0.x; acc[1] += xv[1] * w0.y; acc[2] += xv[2] * w0.z; acc[3] += xv[3] * w0.w;
         acc[4] += xv[4] * w1.x; acc[5] += xv[5] * w1.y; acc[6] += xv[6] * w1.z; acc[7] += xv[7] * w1.w;
       }
@@ -451,33 +514,50 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// dx[n,ih,iw,c] (+)= sum over taps with (ih + pad - kh) divisible by the stride of dy[.., (ih+pad-kh)/s, ..] * w[c][kh][kw]
+// dx[n,ih,iw,c] (+)= sum over taps with (ih + pad - kh) divisible by the stride of dy[.., (ih+pad-kh)/s, ..] * w[c][kh][kw]:
+// the taps of a pixel are kh0 + t*S with kh0 = (ih + pad) % S, visited in ascending order
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ wt,
                                                        bf16_t* __restrict__ dx, int accumulate, int n, int h, int wd, int C,
-                                                       int k, int stride, int pad, int ho, int wo) {
+                                                       int pad, int ho, int wo) {
+  constexpr int T = (K + S - 1) / S;
   const int c8 = C >> 3;
   const size_t total = (size_t)n * h * wd * c8;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int cc = (int)(i % c8);
     const size_t p = i / c8;
     const int iw = (int)(p % wd), ih = (int)((p / wd) % h), img = (int)(p / ((size_t)wd * h));
+    const bf16_t* gi = dy + (size_t)img * ho * wo * C + cc * 8;
+    const float* wc = wt + cc * 8;
+    const int a0 = ih + pad, b0 = iw + pad;
+    const int kh0 = a0 % S, kw0 = b0 % S;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int kh = 0; kh < k; ++kh) {
-      const int a = ih + pad - kh;
-      if (a < 0 || a % stride) continue;
-      const int oh = a / stride;
-      if (oh >= ho) continue;
-      for (int kw = 0; kw < k; ++kw) {
-        const int b = iw + pad - kw;
-        if (b < 0 || b % stride) continue;
-        const int ow = b / stride;
-        if (ow >= wo) continue;
+#pragma unroll(T <= 3 ? T : 1)
+    for (int t = 0; t < T; ++t) {
+      const int kh = kh0 + t * S, da = a0 - kh;
+      const int oh = da / S;
+      const bool rowok = kh < K && da >= 0 && oh < ho;
+      const int ohc = min(max(oh, 0), ho - 1), khc = min(kh, K - 1);
+      u32x4_t raw[T];
+      int kwc[T];
+#pragma unroll
+      for (int u = 0; u < T; ++u) {
+        const int kw = kw0 + u * S, db = b0 - kw;
+        const int ow = db / S;
+        const bool ok = rowok && kw < K && db >= 0 && ow < wo;
+        const int owc = min(max(ow, 0), wo - 1);
+        kwc[u] = min(kw, K - 1);
+        raw[u] = *(const u32x4_t*)(gi + ((size_t)ohc * wo + owc) * C);
+        if (!ok) raw[u] = u32x4_t{0u, 0u, 0u, 0u};
+      }
+#pragma unroll
+      for (int u = 0; u < T; ++u) {
         float gv[8];
-        unpack8(*(const u32x4_t*)(dy + (((size_t)img * ho + oh) * wo + ow) * C + cc * 8), gv);
-        const float4 w0 = *(const float4*)(wt + (size_t)(kh * k + kw) * C + cc * 8);
-        const float4 w1 = *(const float4*)(wt + (size_t)(kh * k + kw) * C + cc * 8 + 4);
+        unpack8(raw[u], gv);
+        const float4 w0 = *(const float4*)(wc + (size_t)(khc * K + kwc[u]) * C);
+        const float4 w1 = *(const float4*)(wc + (size_t)(khc * K + kwc[u]) * C + 4);
         acc[0] += gv[0] * w0.x; acc[1] += gv[1] * w0.y; acc[2] += gv[2] * w0.z; acc[3] += gv[3] * w0.w;
         acc[4] += gv[4] * w1.x; acc[5] += gv[5] * w1.y; acc[6] += gv[6] * w1.z; acc[7] += gv[7] * w1.w;
       }
@@ -493,20 +573,25 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const bf16_t* __restrict_
   }
 }
 
-// gw[c][kh][kw] = sum over output pixels of dy * x(shifted): blockIdx.y = kh; the rows-in-flight of a block are combined
-// through LDS in a fixed order, one partial row [c_log][taps] per block
-template <int K>
+// gw[c][kh][kw] = sum over output pixels of dy * x(shifted): blockIdx.y = kh.  A work item is DW_PX horizontally adjacent
+// output pixels x 8 channels: the (DW_PX-1)*S + K input columns they touch are loaded once (all loads of an item in
+// flight together, clamped and zeroed by selects), 2-3 vector loads per pixel and window row instead of K + 1.  The items
+// in flight of a block are combined through LDS in a fixed order, one partial row [c_log][taps] per block.
+constexpr int DW_PX = 4;
+template <int K, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                        float* __restrict__ partials, int n, int h, int wd, int C, int c_log,
-                                                       int stride, int pad, int ho, int wo, int rows_per_block) {
+                                                       int pad, int ho, int wo, int rows_per_block) {
+  constexpr int COLS = (DW_PX - 1) * S + K;
   extern __shared__ float sm[];   // [rif][tpr][K][8]
-  const int M = n * ho * wo;
-  const RowWalk w(M, C, rows_per_block);
+  const int gpr = (wo + DW_PX - 1) / DW_PX;
+  const int M = n * ho * gpr;     // items
+  const RowWalk w(M, C, rows_per_block, blockIdx.z, gridDim.z);
   const int kh = blockIdx.y;
   float* out = partials + (size_t)blockIdx.x * c_log * K * K;
-  for (int c0 = 0; c0 < w.c8; c0 += w.tpr) {     // uniform trip count: the barriers below are reached by every thread
+  for (int c0 = w.cb; c0 < w.ce; c0 += w.tpr) {     // uniform trip count: the barriers below are reached by every thread
     const int cc = c0 + w.lane_c;
-    const bool mine = w.active && cc < w.c8;
+    const bool mine = w.active && cc < w.ce;
     float acc[K][8];
 #pragma unroll
     for (int q = 0; q < K; ++q)
@@ -514,19 +599,34 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict_
       for (int j = 0; j < 8; ++j) acc[q][j] = 0.f;
     if (mine)
       for (int r = w.row0 + w.lane_r; r < w.row1; r += w.rif) {
-        const int ow = r % wo, oh = (r / wo) % ho, img = r / (wo * ho);
-        const int ih = oh * stride + kh - pad;
+        const int ow0 = (r % gpr) * DW_PX, oh = (r / gpr) % ho, img = r / (gpr * ho);
+        const int ih = oh * S + kh - pad;
         if (ih < 0 || ih >= h) continue;
-        float gv[8];
-        unpack8(*(const u32x4_t*)(dy + (size_t)r * C + cc * 8), gv);
+        const bf16_t* gp = dy + (((size_t)img * ho + oh) * wo) * C + cc * 8;
+        const bf16_t* xp = x + (((size_t)img * h + ih) * wd) * C + cc * 8;
+        u32x4_t graw[DW_PX], raw[COLS];
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-          const int iw = ow * stride + kw - pad;
-          if (iw < 0 || iw >= wd) continue;
-          float xv[8];
-          unpack8(*(const u32x4_t*)(x + (((size_t)img * h + ih) * wd + iw) * C + cc * 8), xv);
+        for (int u = 0; u < DW_PX; ++u) {
+          graw[u] = *(const u32x4_t*)(gp + (size_t)min(ow0 + u, wo - 1) * C);
+          if (ow0 + u >= wo) graw[u] = u32x4_t{0u, 0u, 0u, 0u};
+        }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[kw][j] += gv[j] * xv[j];
+        for (int col = 0; col < COLS; ++col) {
+          const int iw = ow0 * S - pad + col;
+          raw[col] = *(const u32x4_t*)(xp + (size_t)min(max(iw, 0), wd - 1) * C);
+          if ((unsigned)iw >= (unsigned)wd) raw[col] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < DW_PX; ++u) {
+          float gv[8];
+          unpack8(graw[u], gv);
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) {
+            float xv[8];
+            unpack8(raw[u * S + kw], xv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[kw][j] += gv[j] * xv[j];
+          }
         }
       }
     __syncthreads();
@@ -541,7 +641,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict_
     for (int i = threadIdx.x; i < w.tpr * K * 8; i += 256) {
       const int j = i & 7, q = (i >> 3) % K, lc = i / (8 * K);
       const int c = (c0 + lc) * 8 + j;
-      if (c0 + lc >= w.c8 || c >= c_log) continue;
+      if (c0 + lc >= w.ce || c >= c_log) continue;
       float t = 0.f;
       for (int r = 0; r < w.rif; ++r) t += sm[((size_t)r * w.tpr + lc) * K * 8 + q * 8 + j];
       out[(size_t)c * K * K + kh * K + q] = t;
@@ -591,6 +691,47 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
     o[i] = t;
   }
 }
+// BatchNorm apply + activation of a depthwise layer AND the squeeze of the squeeze-excitation layer behind it: the block
+// layout of pool_partial_kernel (one chunk of one image's rows), the sums taken over the rounded values it stores, in
+// pool_partial_kernel's order - the separate pooling pass over the tensor just written is gone.
+__global__ __launch_bounds__(256) void bna_apply_pool_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, bf16_t* __restrict__ out,
+                                                             float* __restrict__ part, int HW, int C, int act, int chunks) {
+  extern __shared__ float sm[];   // [rif][C]
+  const int img = blockIdx.x, chunk = blockIdx.y;
+  const int rows = (HW + chunks - 1) / chunks;
+  const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
+  const int c8 = C >> 3;
+  const int tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
+  const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
+  if (lane_r < rif)
+    for (int cc = lane_c; cc < c8; cc += tpr) {
+      float sc[8], sh[8], sum[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { sc[j] = scale[cc * 8 + j]; sh[j] = shift[cc * 8 + j]; sum[j] = 0.f; }
+      for (int r = r0 + lane_r; r < r1; r += rif) {
+        const size_t o = ((size_t)img * HW + r) * C + cc * 8;
+        float v[8], q[8];
+        unpack8(*(const u32x4_t*)(raw + o), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = act_fwd(v[j] * sc[j] + sh[j], act);
+        const u32x4_t pk = pack8(v);
+        *(u32x4_t*)(out + o) = pk;
+        unpack8(pk, q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += q[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sm[(size_t)lane_r * C + cc * 8 + j] = sum[j];
+    }
+  __syncthreads();
+  float* o = part + ((size_t)img * chunks + chunk) * C;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    float t = 0.f;
+    for (int r = 0; r < rif; ++r) t += sm[(size_t)r * C + i];
+    o[i] = t;
+  }
+}
 __global__ void pool_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int chunks, int C,
                                    float scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,35 +742,83 @@ __global__ void pool_finish_kernel(const float* __restrict__ part, float* __rest
   out[i] = t * scale;
 }
 
-// gates of one image per block: u1 = W1 pooled + b1, h1 = silu(u1), gate = sigmoid(W2 h1 + b2); fp32
+// rows of W2 [Cl][S] staged per pass through LDS (row stride S|1: conflict-free both ways), about 47 KB
+__host__ __device__ inline int se_tile_rows(int S) {
+  const int r = 12032 / (S | 1);
+  return r > 256 ? 256 : r;
+}
+
+// nrow rows of S floats (contiguous in global memory) -> tile rows of stride ld: flat coalesced loads, four in flight
+__device__ __forceinline__ void se_stage_rows(float* __restrict__ tile, const float* __restrict__ src, int nrow, int S,
+                                              int ld) {
+  const int total = nrow * S;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 1024) {
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + 256 * k < total ? src[i0 + 256 * k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = i0 + 256 * k;
+      if (i < total) {
+        const int r = i / S;
+        tile[r * ld + (i - r * S)] = v[k];
+      }
+    }
+  }
+}
+
+// gates of one image per block: u1 = W1 pooled + b1, h1 = silu(u1), gate = sigmoid(W2 h1 + b2); fp32.
+// W1 [S][Cl] is read with the lanes along Cl, four hidden units in flight per wave; W2 [Cl][S] is read through LDS
+// (coalesced loads of whole rows, then one row per thread) - a thread walking its own row in global memory touched 64
+// cache lines per wave and load.
 __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W1,
                                                           const float* __restrict__ b1, const float* __restrict__ W2,
                                                           const float* __restrict__ b2, float* __restrict__ u1,
                                                           float* __restrict__ h1, float* __restrict__ gate, int C, int Cl,
                                                           int S) {
-  extern __shared__ float sm[];   // pooled[Cl], h[S]
+  extern __shared__ float sm[];   // pooled[Cl], h[S], tile[R][S|1]
   float* sp = sm;
   float* shh = sm + Cl;
+  float* tile = shh + S;
   const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < Cl; c += 256) sp[c] = pooled[(size_t)img * C + c];
   __syncthreads();
-  for (int sidx = wave; sidx < S; sidx += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < Cl; c += 64) acc += W1[(size_t)sidx * Cl + c] * sp[c];
-    for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) {
-      const float u = acc + b1[sidx];
-      const float hv = u / (1.f + expf(-u));
-      u1[(size_t)img * S + sidx] = u;
-      h1[(size_t)img * S + sidx] = hv;
-      shh[sidx] = hv;
+  // first FC: a thread walks channels tid, tid + 256, ... for 16 hidden units at a time (16 independent loads in flight
+  // per channel, lanes along Cl: coalesced); wave sums by shuffles, the four waves through LDS in a fixed order
+  for (int s0 = 0; s0 < S; s0 += 16) {
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int c = threadIdx.x; c < Cl; c += 256) {
+      const float pv = sp[c];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += W1[(size_t)min(s0 + k, S - 1) * Cl + c] * pv;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      for (int d = 32; d; d >>= 1) acc[k] += __shfl_xor(acc[k], d);
+      if (lane == 0 && s0 + k < S) tile[wave * S + s0 + k] = acc[k];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < Cl; c += 256) {
-    float acc = b2[c];
-    for (int sidx = 0; sidx < S; ++sidx) acc += W2[(size_t)c * S + sidx] * shh[sidx];
-    gate[(size_t)img * C + c] = 1.f / (1.f + expf(-acc));
+  for (int sidx = threadIdx.x; sidx < S; sidx += 256) {
+    const float u = ((tile[sidx] + tile[S + sidx]) + tile[2 * S + sidx]) + tile[3 * S + sidx] + b1[sidx];
+    const float hv = u / (1.f + expf(-u));
+    u1[(size_t)img * S + sidx] = u;
+    h1[(size_t)img * S + sidx] = hv;
+    shh[sidx] = hv;
+  }
+  const int R = se_tile_rows(S), ld = S | 1;
+  for (int c0 = 0; c0 < Cl; c0 += R) {
+    const int nrow = min(R, Cl - c0);
+    __syncthreads();   // (first pass: shh complete; later passes: the tile has been read)
+    se_stage_rows(tile, W2 + (size_t)c0 * S, nrow, S, ld);
+    __syncthreads();
+    for (int r = threadIdx.x; r < nrow; r += 256) {
+      float acc = b2[c0 + r];
+      for (int sidx = 0; sidx < S; ++sidx) acc += tile[r * ld + sidx] * shh[sidx];
+      gate[(size_t)img * C + c0 + r] = 1.f / (1.f + expf(-acc));
+    }
   }
 }
 
@@ -639,9 +828,10 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(float* __restrict__ dg
                                                           const float* __restrict__ u1, const float* __restrict__ W1,
                                                           const float* __restrict__ W2, float* __restrict__ du1,
                                                           float* __restrict__ dpool, int C, int Cl, int S) {
-  extern __shared__ float sm[];   // du2[Cl], du1[S]
+  extern __shared__ float sm[];   // du2[Cl], du1[S], tile[R][S|1] (then the four row-group partials [4][S])
   float* s2 = sm;
   float* s1 = sm + Cl;
+  float* tile = s1 + S;
   const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < Cl; c += 256) {
     const float g = gate[(size_t)img * C + c];
@@ -649,55 +839,112 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(float* __restrict__ dg
     dgate[(size_t)img * C + c] = v;
     s2[c] = v;
   }
-  __syncthreads();
-  for (int sidx = wave; sidx < S; sidx += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < Cl; c += 64) acc += s2[c] * W2[(size_t)c * S + sidx];
-    for (int d = 32; d; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) {
-      const float z = u1[(size_t)img * S + sidx], sg = 1.f / (1.f + expf(-z));
-      const float v = acc * sg * (1.f + z * (1.f - sg));
-      du1[(size_t)img * S + sidx] = v;
-      s1[sidx] = v;
+  // a thread owns hidden units lane, lane + 64, lane + 128 (S <= 192) of the rows wave, wave + 4, ... of each tile
+  float part[3] = {0.f, 0.f, 0.f};
+  const int R = se_tile_rows(S), ld = S | 1;
+  for (int c0 = 0; c0 < Cl; c0 += R) {
+    const int nrow = min(R, Cl - c0);
+    __syncthreads();
+    se_stage_rows(tile, W2 + (size_t)c0 * S, nrow, S, ld);
+    __syncthreads();
+    for (int r = wave; r < nrow; r += 4) {
+      const float v = s2[c0 + r];
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (lane + 64 * q < S) part[q] += v * tile[r * ld + lane + 64 * q];
     }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (lane + 64 * q < S) tile[wave * S + lane + 64 * q] = part[q];
+  __syncthreads();
+  for (int sidx = threadIdx.x; sidx < S; sidx += 256) {
+    const float acc = ((tile[sidx] + tile[S + sidx]) + tile[2 * S + sidx]) + tile[3 * S + sidx];
+    const float z = u1[(size_t)img * S + sidx], sg = 1.f / (1.f + expf(-z));
+    const float v = acc * sg * (1.f + z * (1.f - sg));
+    du1[(size_t)img * S + sidx] = v;
+    s1[sidx] = v;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < Cl; c += 256) {
     float acc = 0.f;
+#pragma unroll 8
     for (int sidx = 0; sidx < S; ++sidx) acc += s1[sidx] * W1[(size_t)sidx * Cl + c];
     dpool[(size_t)img * C + c] = acc;
   }
 }
 
-// parameter gradients of the two 1x1 convs of the gate path (sums over the batch, fixed order); null: not wanted
-__global__ void se_wgrad_kernel(const float* __restrict__ du2, const float* __restrict__ h1, const float* __restrict__ du1,
-                                const float* __restrict__ pooled, float* __restrict__ gW1, float* __restrict__ gb1,
-                                float* __restrict__ gW2, float* __restrict__ gb2, int n, int C, int Cl, int S) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= Cl * S) return;
-  if (gW2) {   // [Cl][S]
-    const int c = i / S, sidx = i % S;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) acc += du2[(size_t)k * C + c] * h1[(size_t)k * S + sidx];
-    gW2[i] = acc;
+// parameter gradients of the two 1x1 convs of the gate path (sums over the batch in ascending order); null: not wanted.
+// Two small GEMMs G[c][s] = sum_k A[k][c] B[k][s]: blockIdx.y = 0: gW2 [Cl][S] from A = du2, B = h1 (+ gb2 = column sums
+// of A); 1: gW1 [S][Cl] from A = pooled, B = du1 (+ gb1 = column sums of B).  A block owns 64 channels x all S: the batch
+// is staged through LDS 32 images at a time, a thread keeps 4 channels x ceil(S/16) hidden units in registers (one
+// thread per output reading both operands from global memory took 85 us per layer).
+constexpr int SEW_KC = 32, SEW_SJ = 12;   // S <= 192
+__global__ __launch_bounds__(256) void se_wgrad_kernel(const float* __restrict__ du2, const float* __restrict__ h1,
+                                                       const float* __restrict__ du1, const float* __restrict__ pooled,
+                                                       float* __restrict__ gW1, float* __restrict__ gb1,
+                                                       float* __restrict__ gW2, float* __restrict__ gb2, int n, int C, int Cl,
+                                                       int S) {
+  extern __shared__ float sm[];   // As[KC][64], Bs[KC][S]
+  const int job = blockIdx.y;
+  const float* A = job == 0 ? du2 : pooled;
+  const float* B = job == 0 ? h1 : du1;
+  float* G = job == 0 ? gW2 : gW1;
+  float* gbA = job == 0 ? gb2 : nullptr;
+  float* gbB = job == 0 ? nullptr : gb1;
+  if (!G && !gbA && !gbB) return;
+  float* As = sm;
+  float* Bs = sm + SEW_KC * 64;
+  const int c0 = blockIdx.x * 64, tc = threadIdx.x & 15, ts = threadIdx.x >> 4;
+  const int sj = (S + 15) >> 4;
+  float acc[4][SEW_SJ], sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[SEW_SJ];
+#pragma unroll
+  for (int j = 0; j < SEW_SJ; ++j) {
+    sb[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i][j] = 0.f;
   }
-  if (gW1) {   // [S][Cl]
-    const int sidx = i / Cl, c = i % Cl;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) acc += du1[(size_t)k * S + sidx] * pooled[(size_t)k * C + c];
-    gW1[i] = acc;
+  for (int k0 = 0; k0 < n; k0 += SEW_KC) {
+    const int kc = min(SEW_KC, n - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kc * 64; i += 256) {
+      const int kk = i >> 6, c = c0 + (i & 63);
+      As[i] = c < Cl ? A[(size_t)(k0 + kk) * C + c] : 0.f;
+    }
+    for (int i = threadIdx.x; i < kc * S; i += 256) Bs[i] = B[(size_t)k0 * S + i];
+    __syncthreads();
+    for (int kk = 0; kk < kc; ++kk) {
+      const float4 a = *(const float4*)(As + kk * 64 + tc * 4);
+      sa[0] += a.x; sa[1] += a.y; sa[2] += a.z; sa[3] += a.w;
+#pragma unroll
+      for (int j = 0; j < SEW_SJ; ++j)
+        if (j < sj) {
+          const int sidx = ts + 16 * j;
+          const float bv = sidx < S ? Bs[kk * S + sidx] : 0.f;
+          sb[j] += bv;
+          acc[0][j] += a.x * bv; acc[1][j] += a.y * bv; acc[2][j] += a.z * bv; acc[3][j] += a.w * bv;
+        }
+    }
   }
-  if (gb2 && i < Cl) {
-    float acc = 0.f;
-    for (int k = 0; k < n; ++k) acc += du2[(size_t)k * C + i];
-    gb2[i] = acc;
+#pragma unroll
+  for (int j = 0; j < SEW_SJ; ++j) {
+    const int sidx = ts + 16 * j;
+    if (j >= sj || sidx >= S) continue;
+    if (gbB && blockIdx.x == 0 && tc == 0) gbB[sidx] = sb[j];
+    if (G) {
+      const float v[4] = {acc[0][j], acc[1][j], acc[2][j], acc[3][j]};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + tc * 4 + i;
+        if (c < Cl) G[job == 0 ? (size_t)c * S + sidx : (size_t)sidx * Cl + c] = v[i];
+      }
+    }
   }
-  if (gb1 && i < S) {
-    float acc = 0.f;
-    for (int k = 0; k < n; ++k) acc += du1[(size_t)k * S + i];
-    gb1[i] = acc;
+  if (gbA && ts == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c0 + tc * 4 + i < Cl) gbA[c0 + tc * 4 + i] = sa[i];
   }
 }
 
@@ -788,9 +1035,18 @@ inline int walk_rows(int M, int* rows_per_block) {
   *rows_per_block = rpb;
   return (M + rpb - 1) / rpb;
 }
+// channel tiles of about 256 channels once a tensor is wider than that
+inline int walk_ctiles(int C) { return (C / 8 + 31) / 32; }
 inline size_t walk_lds(int C) {
+  const int c8 = C / 8, cts = walk_ctiles(C), tile = (c8 + cts - 1) / cts, tpr = tile < 256 ? tile : 256;
+  return (size_t)(256 / tpr) * 2 * tile * 8 * sizeof(float);
+}
+inline size_t pool_lds(int C) {   // [rif][C] floats, rif = 256 / min(C / 8, 256)
   const int c8 = C / 8, tpr = c8 < 256 ? c8 : 256;
-  return (size_t)(256 / tpr) * 2 * C * sizeof(float);
+  return (size_t)(256 / tpr) * C * sizeof(float);
+}
+inline size_t se_gate_lds(int Cl, int S) {
+  return ((size_t)Cl + S + (size_t)std::max(se_tile_rows(S), 4) * (S | 1)) * sizeof(float);
 }
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -1)
 
@@ -801,7 +1057,7 @@ int spk_eff_stat_blocks(int M, int* rows_per_block) { return walk_rows(M, rows_p
 int spk_launch_col_stats(const bf16_t* x, float* partials, int M, int C, int* blocks, hipStream_t s) {
   int rpb;
   const int nb = walk_rows(M, &rpb);
-  hipLaunchKernelGGL(col_stats_kernel, dim3(nb), dim3(256), walk_lds(C), s, x, partials, M, C, rpb);
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nb, walk_ctiles(C)), dim3(256), walk_lds(C), s, x, partials, M, C, rpb);
   *blocks = nb;
   return LAUNCH_OK();
 }
@@ -810,7 +1066,7 @@ int spk_launch_bna_apply(const bf16_t* raw, const float* scale, const float* shi
                          const float* rowscale, bf16_t* out, int M, int C, int HW, int act, hipStream_t s) {
   int rpb;
   const int nb = walk_rows(M, &rpb);
-  hipLaunchKernelGGL(bna_apply_kernel, dim3(nb), dim3(256), 0, s, raw, scale, shift, res, rowscale, out, M, C, HW, act,
+  hipLaunchKernelGGL(bna_apply_kernel, dim3(nb, walk_ctiles(C)), dim3(256), 0, s, raw, scale, shift, res, rowscale, out, M, C, HW, act,
                      rpb);
   return LAUNCH_OK();
 }
@@ -820,7 +1076,7 @@ int spk_launch_bna_bwd_reduce(const bf16_t* g, const bf16_t* raw, const float* s
                               int C, int HW, int act, int* blocks, hipStream_t s) {
   int rpb;
   const int nb = walk_rows(M, &rpb);
-  hipLaunchKernelGGL(bna_bwd_reduce_kernel, dim3(nb), dim3(256), walk_lds(C), s, g, raw, scale, shift, mean, invstd,
+  hipLaunchKernelGGL(bna_bwd_reduce_kernel, dim3(nb, walk_ctiles(C)), dim3(256), walk_lds(C), s, g, raw, scale, shift, mean, invstd,
                      rowscale, partials, M, C, HW, act, rpb);
   *blocks = nb;
   return LAUNCH_OK();
@@ -832,7 +1088,7 @@ int spk_launch_bna_bwd_apply(const bf16_t* g, const bf16_t* raw, const float* sc
                              hipStream_t s) {
   int rpb;
   const int nb = walk_rows(M, &rpb);
-  hipLaunchKernelGGL(bna_bwd_apply_kernel, dim3(nb), dim3(256), 0, s, g, raw, scale, shift, mean, invstd, coef, rowscale,
+  hipLaunchKernelGGL(bna_bwd_apply_kernel, dim3(nb, walk_ctiles(C)), dim3(256), 0, s, g, raw, scale, shift, mean, invstd, coef, rowscale,
                      dy, g_res, res_accumulate, M, C, HW, act, rpb);
   return LAUNCH_OK();
 }
@@ -844,7 +1100,7 @@ int spk_launch_sd_rowscale(float* rs, int n, float p, unsigned long long seed, h
 
 int spk_launch_stem3_train_fwd(const bf16_t* x, const float* w, bf16_t* y, int n, int h, int wd, int wstride, int cin,
                                int cout, int C, int ho, int wo, hipStream_t s) {
-  const size_t total = (size_t)n * ho * wo * (C / 8);
+  const size_t total = (size_t)n * ho * ((wo + STEM_PX - 1) / STEM_PX) * (C / 8);
   hipLaunchKernelGGL(stem3_fwd_kernel, dim3(grid_of(total, 256)), dim3(256), (size_t)36 * C * 4, s, x, w, y, n, h, wd,
                      wstride, cin, cout, C, ho, wo);
   return LAUNCH_OK();
@@ -876,47 +1132,61 @@ int spk_launch_dw_pack(const float* w, float* wt, int c_log, int C, int taps, hi
 int spk_launch_dw_train_fwd(const bf16_t* x, const float* wt, bf16_t* y, int n, int h, int wd, int C, int k, int stride,
                             int pad, int ho, int wo, hipStream_t s) {
   const size_t total = (size_t)n * ho * wo * (C / 8);
-  hipLaunchKernelGGL(dw_fwd_kernel, dim3(grid_of(total, 256)), dim3(256), 0, s, x, wt, y, n, h, wd, C, k, stride, pad, ho,
-                     wo);
+  if (k == 3)
+    hipLaunchKernelGGL(dw_fwd_kernel<3>, dim3(grid_of(total, 256)), dim3(256), 0, s, x, wt, y, n, h, wd, C, stride, pad, ho,
+                       wo);
+  else if (k == 5)
+    hipLaunchKernelGGL(dw_fwd_kernel<5>, dim3(grid_of(total, 256)), dim3(256), 0, s, x, wt, y, n, h, wd, C, stride, pad, ho,
+                       wo);
+  else
+    return -1;
   return LAUNCH_OK();
 }
 
 int spk_launch_dw_dgrad(const bf16_t* dy, const float* wt, bf16_t* dx, int accumulate, int n, int h, int wd, int C, int k,
                         int stride, int pad, int ho, int wo, hipStream_t s) {
   const size_t total = (size_t)n * h * wd * (C / 8);
-  hipLaunchKernelGGL(dw_dgrad_kernel, dim3(grid_of(total, 256)), dim3(256), 0, s, dy, wt, dx, accumulate, n, h, wd, C, k,
-                     stride, pad, ho, wo);
+#define DW_DGRAD(K_, S_)                                                                                              \
+  hipLaunchKernelGGL((dw_dgrad_kernel<K_, S_>), dim3(grid_of(total, 256)), dim3(256), 0, s, dy, wt, dx, accumulate, n, h, \
+                     wd, C, pad, ho, wo)
+  if (k == 3 && stride == 1) DW_DGRAD(3, 1);
+  else if (k == 3 && stride == 2) DW_DGRAD(3, 2);
+  else if (k == 5 && stride == 1) DW_DGRAD(5, 1);
+  else if (k == 5 && stride == 2) DW_DGRAD(5, 2);
+  else return -1;
+#undef DW_DGRAD
   return LAUNCH_OK();
 }
 
 // partial rows the weight-gradient kernel writes for an [M][C] problem ([rows][c_log][k*k] floats): one per block
 static int dw_wgrad_blocks(int M, int* rows_per_block) {
   int rpb = 8192;
-  while (rpb > 256 && (M + rpb - 1) / rpb < 256) rpb >>= 1;
+  while (rpb > 64 && (M + rpb - 1) / rpb < 256) rpb >>= 1;
   *rows_per_block = rpb;
   return (M + rpb - 1) / rpb;
 }
-int spk_dw_wgrad_rows(int M, int C) {
+int spk_dw_wgrad_rows(int M, int C) {   // upper bound at planning time: the launch walks M / DW_PX or more items
   int rpb;
-  return dw_wgrad_blocks(M, &rpb);
+  return std::max(dw_wgrad_blocks(M, &rpb), std::min(512, (M + 63) / 64 + 1));
 }
 
 int spk_launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int C, int c_log,
                         int k, int stride, int pad, int ho, int wo, int* rows, hipStream_t s) {
   int rpb;
-  const int M = n * ho * wo;
+  const int M = n * ho * ((wo + DW_PX - 1) / DW_PX);
   const int nb = dw_wgrad_blocks(M, &rpb);
   *rows = nb;
-  const int c8 = C / 8, tpr = c8 < 256 ? c8 : 256;
+  const int c8 = C / 8, cts = walk_ctiles(C), tile = (c8 + cts - 1) / cts, tpr = tile < 256 ? tile : 256;
   const size_t lds = (size_t)(256 / tpr) * tpr * k * 8 * sizeof(float);
-  if (k == 3)
-    hipLaunchKernelGGL(dw_wgrad_kernel<3>, dim3(nb, 3), dim3(256), lds, s, x, dy, partials, n, h, wd, C, c_log, stride, pad,
-                       ho, wo, rpb);
-  else if (k == 5)
-    hipLaunchKernelGGL(dw_wgrad_kernel<5>, dim3(nb, 5), dim3(256), lds, s, x, dy, partials, n, h, wd, C, c_log, stride, pad,
-                       ho, wo, rpb);
-  else
-    return -1;
+#define DW_WGRAD(K_, S_)                                                                                          \
+  hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_>), dim3(nb, K_, cts), dim3(256), lds, s, x, dy, partials, n, h, wd, C, \
+                     c_log, pad, ho, wo, rpb)
+  if (k == 3 && stride == 1) DW_WGRAD(3, 1);
+  else if (k == 3 && stride == 2) DW_WGRAD(3, 2);
+  else if (k == 5 && stride == 1) DW_WGRAD(5, 1);
+  else if (k == 5 && stride == 2) DW_WGRAD(5, 2);
+  else return -1;
+#undef DW_WGRAD
   return LAUNCH_OK();
 }
 
@@ -926,8 +1196,19 @@ int spk_se_chunks(int HW) { return HW >= 3136 ? 16 : (HW >= 196 ? 4 : 1); }
 int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* out, int n, int HW, int C, float scale,
                          hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks), dim3(256), walk_lds(C) / 2, s, x, y, part, HW, C, chunks);
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks), dim3(256), pool_lds(C), s, x, y, part, HW, C, chunks);
   hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, out, n, chunks, C, scale);
+  return LAUNCH_OK();
+}
+
+// a = act(raw*scale + shift) and pooled[n][C] = mean over HW of a (the squeeze of the layer behind)
+int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part,
+                              float* pooled, int n, int HW, int C, int act, hipStream_t s) {
+  const int chunks = spk_se_chunks(HW);
+  hipLaunchKernelGGL(bna_apply_pool_kernel, dim3(n, chunks), dim3(256), pool_lds(C), s, raw, scale, shift, out, part,
+                     HW, C, act, chunks);
+  hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, pooled, n, chunks, C,
+                     1.f / (float)HW);
   return LAUNCH_OK();
 }
 
@@ -996,14 +1277,16 @@ int spk_launch_pack_train_padded(const float* w, bf16_t* out, int cout, int taps
 
 int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
                            float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s) {
-  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(n), dim3(256), (size_t)(Cl + S) * 4, s, pooled, W1, b1, W2, b2, u1, h1, gate,
+  if (S > 192) return -1;
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(n), dim3(256), se_gate_lds(Cl, S), s, pooled, W1, b1, W2, b2, u1, h1, gate,
                      C, Cl, S);
   return LAUNCH_OK();
 }
 
 int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, const float* W1, const float* W2, float* du1,
                            float* dpool, int n, int C, int Cl, int S, hipStream_t s) {
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(n), dim3(256), (size_t)(Cl + S) * 4, s, dgate, gate, u1, W1, W2, du1, dpool,
+  if (S > 192) return -1;
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(n), dim3(256), se_gate_lds(Cl, S), s, dgate, gate, u1, W1, W2, du1, dpool,
                      C, Cl, S);
   return LAUNCH_OK();
 }
@@ -1011,7 +1294,8 @@ int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, con
 int spk_launch_se_wgrad(const float* du2, const float* h1, const float* du1, const float* pooled, float* gW1, float* gb1,
                         float* gW2, float* gb2, int n, int C, int Cl, int S, hipStream_t s) {
   if (!gW1 && !gb1 && !gW2 && !gb2) return 0;
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3((Cl * S + 255) / 256), dim3(256), 0, s, du2, h1, du1, pooled, gW1, gb1, gW2, gb2,
-                     n, C, Cl, S);
+  if (S > 16 * SEW_SJ) return -1;
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3((Cl + 63) / 64, 2), dim3(256), (size_t)SEW_KC * (64 + S) * sizeof(float), s, du2,
+                     h1, du1, pooled, gW1, gb1, gW2, gb2, n, C, Cl, S);
   return LAUNCH_OK();
 }
