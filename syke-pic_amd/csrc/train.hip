@@ -257,8 +257,9 @@ static int plan_train(spk_model* m, int n, int h, int w) {
       const size_t fl = (size_t)n * (3 * o.c + 3 * L.d.k);
       t->conv[i].se_off = total;
       total += al256(fl * 4);
-      // shared scratch: pool partials [n][chunks][C], dpool [n][C]
-      max_se = std::max(max_se, (size_t)n * ((size_t)(spk_se_chunks(o.h * o.w) + 3) * o.c + 2 * L.d.k));
+      // shared scratch: pool partials [n][chunks][C], dpool [n][C], hidden-gradient partials [n][gate tiles][S]
+      max_se = std::max(max_se, (size_t)n * ((size_t)(spk_se_chunks(o.h * o.w) + 1) * o.c +
+                                             (size_t)spk_se_gate_tiles(L.d.cout, L.d.k) * L.d.k));
     } else if (L.d.kind == SPK_OP_MAXPOOL) {
       t->idx_off = total;
       total += al256((size_t)n * o.h * o.w * o.c);
@@ -797,7 +798,8 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
         K_TRY(spk_launch_pool_rows(g, a, scratch, dgate, n, HW, C, 1.f, s), "se dgate");
         const Param &w1 = m->params[L.p_w], &b1 = m->params[L.p_b], &w2 = m->params[L.p_w2], &b2 = m->params[L.p_b2];
-        K_TRY(spk_launch_se_gate_bwd(dgate, gate, u1, m->P(L.p_w), m->P(L.p_w2), du1, dpool, n, C, Cl, S, s), "se gates bwd");
+        K_TRY(spk_launch_se_gate_bwd(dgate, gate, u1, m->P(L.p_w), m->P(L.p_w2), du1, dpool, dpool + (size_t)n * C, n, C, Cl,
+                                     S, s), "se gates bwd");
         hipStream_t ws = s;
         if (side_on && (w1.requires_grad || b1.requires_grad || w2.requires_grad || b2.requires_grad)) {
           ws = t->side;   // du2 / du1 are this layer's own: nothing on the main stream waits for the kernel

@@ -654,15 +654,17 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const bf16_t* __restrict_
 // the block works (8-channel chunk x row in flight); the rows in flight are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ y,
                                                            float* __restrict__ part, int HW, int C, int chunks) {
-  extern __shared__ float sm[];   // [rif][C]
+  extern __shared__ float sm[];   // [rif][TW]
   const int img = blockIdx.x, chunk = blockIdx.y;
   const int rows = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   const int c8 = C >> 3;
-  const int tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
+  const int tile = (c8 + (int)gridDim.z - 1) / (int)gridDim.z;   // channel tile blockIdx.z (as RowWalk)
+  const int cb = blockIdx.z * tile, ce = min(c8, cb + tile), TW = tile * 8;
+  const int tpr = tile < 256 ? tile : 256, rif = 256 / tpr;
   const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
   if (lane_r < rif)
-    for (int cc = lane_c; cc < c8; cc += tpr) {
+    for (int cc = cb + lane_c; cc < ce; cc += tpr) {
       float s[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] = 0.f;
@@ -681,13 +683,13 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
         }
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sm[(size_t)lane_r * C + cc * 8 + j] = s[j];
+      for (int j = 0; j < 8; ++j) sm[(size_t)lane_r * TW + (cc - cb) * 8 + j] = s[j];
     }
   __syncthreads();
-  float* o = part + ((size_t)img * chunks + chunk) * C;
-  for (int i = threadIdx.x; i < C; i += 256) {
+  float* o = part + ((size_t)img * chunks + chunk) * C + cb * 8;
+  for (int i = threadIdx.x; i < (ce - cb) * 8; i += 256) {
     float t = 0.f;
-    for (int r = 0; r < rif; ++r) t += sm[(size_t)r * C + i];
+    for (int r = 0; r < rif; ++r) t += sm[(size_t)r * TW + i];
     o[i] = t;
   }
 }
@@ -697,15 +699,17 @@ __global__ __launch_bounds__(256) void pool_partial_kernel(const bf16_t* __restr
 __global__ __launch_bounds__(256) void bna_apply_pool_kernel(const bf16_t* __restrict__ raw, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, bf16_t* __restrict__ out,
                                                              float* __restrict__ part, int HW, int C, int act, int chunks) {
-  extern __shared__ float sm[];   // [rif][C]
+  extern __shared__ float sm[];   // [rif][TW]
   const int img = blockIdx.x, chunk = blockIdx.y;
   const int rows = (HW + chunks - 1) / chunks;
   const int r0 = chunk * rows, r1 = min(HW, r0 + rows);
   const int c8 = C >> 3;
-  const int tpr = c8 < 256 ? c8 : 256, rif = 256 / tpr;
+  const int tile = (c8 + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int cb = blockIdx.z * tile, ce = min(c8, cb + tile), TW = tile * 8;
+  const int tpr = tile < 256 ? tile : 256, rif = 256 / tpr;
   const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
   if (lane_r < rif)
-    for (int cc = lane_c; cc < c8; cc += tpr) {
+    for (int cc = cb + lane_c; cc < ce; cc += tpr) {
       float sc[8], sh[8], sum[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { sc[j] = scale[cc * 8 + j]; sh[j] = shift[cc * 8 + j]; sum[j] = 0.f; }
@@ -722,13 +726,13 @@ __global__ __launch_bounds__(256) void bna_apply_pool_kernel(const bf16_t* __res
         for (int j = 0; j < 8; ++j) sum[j] += q[j];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sm[(size_t)lane_r * C + cc * 8 + j] = sum[j];
+      for (int j = 0; j < 8; ++j) sm[(size_t)lane_r * TW + (cc - cb) * 8 + j] = sum[j];
     }
   __syncthreads();
-  float* o = part + ((size_t)img * chunks + chunk) * C;
-  for (int i = threadIdx.x; i < C; i += 256) {
+  float* o = part + ((size_t)img * chunks + chunk) * C + cb * 8;
+  for (int i = threadIdx.x; i < (ce - cb) * 8; i += 256) {
     float t = 0.f;
-    for (int r = 0; r < rif; ++r) t += sm[(size_t)r * C + i];
+    for (int r = 0; r < rif; ++r) t += sm[(size_t)r * TW + i];
     o[i] = t;
   }
 }
@@ -767,112 +771,136 @@ __device__ __forceinline__ void se_stage_rows(float* __restrict__ tile, const fl
   }
 }
 
-// gates of one image per block: u1 = W1 pooled + b1, h1 = silu(u1), gate = sigmoid(W2 h1 + b2); fp32.
-// W1 [S][Cl] is read with the lanes along Cl, four hidden units in flight per wave; W2 [Cl][S] is read through LDS
-// (coalesced loads of whole rows, then one row per thread) - a thread walking its own row in global memory touched 64
-// cache lines per wave and load.
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled, const float* __restrict__ W1,
-                                                          const float* __restrict__ b1, const float* __restrict__ W2,
-                                                          const float* __restrict__ b2, float* __restrict__ u1,
-                                                          float* __restrict__ h1, float* __restrict__ gate, int C, int Cl,
-                                                          int S) {
-  extern __shared__ float sm[];   // pooled[Cl], h[S], tile[R][S|1]
+// Gates of the squeeze-excitation layer, fp32: u1 = W1 pooled + b1, h1 = silu(u1), gate = sigmoid(W2 h1 + b2).
+// Two launches, both (image x tile) grids: with one block per image the block walked both matrices by itself - a chain of
+// dependent L2 round trips, 60-150 us for the 2688-channel layers of B4 however little arithmetic that is.
+// fc1: block = (image, 16 hidden units); W1 [S][Cl] read with the lanes along Cl, 64 loads in flight per thread.
+__global__ __launch_bounds__(256) void se_fc1_train_kernel(const float* __restrict__ pooled, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, float* __restrict__ u1,
+                                                           float* __restrict__ h1, int C, int Cl, int S) {
+  extern __shared__ float sm[];   // pooled[Cl], red[4][16]
   float* sp = sm;
-  float* shh = sm + Cl;
-  float* tile = shh + S;
-  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* red = sm + Cl;
+  const int img = blockIdx.x, s0 = blockIdx.y * 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < Cl; c += 256) sp[c] = pooled[(size_t)img * C + c];
   __syncthreads();
-  // first FC: a thread walks channels tid, tid + 256, ... for 16 hidden units at a time (16 independent loads in flight
-  // per channel, lanes along Cl: coalesced); wave sums by shuffles, the four waves through LDS in a fixed order
-  for (int s0 = 0; s0 < S; s0 += 16) {
-    float acc[16];
+  float acc[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
-    for (int c = threadIdx.x; c < Cl; c += 256) {
-      const float pv = sp[c];
+  for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+  for (int c0 = threadIdx.x; c0 < Cl; c0 += 1024) {
+    float wv[4][16], pv[4];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc[k] += W1[(size_t)min(s0 + k, S - 1) * Cl + c] * pv;
+    for (int q = 0; q < 4; ++q) {
+      const int c = min(c0 + 256 * q, Cl - 1);
+      pv[q] = c0 + 256 * q < Cl ? sp[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) wv[q][k] = W1[(size_t)min(s0 + k, S - 1) * Cl + c];
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      for (int d = 32; d; d >>= 1) acc[k] += __shfl_xor(acc[k], d);
-      if (lane == 0 && s0 + k < S) tile[wave * S + s0 + k] = acc[k];
-    }
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += wv[q][k] * pv[q];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    for (int d = 32; d; d >>= 1) acc[k] += __shfl_xor(acc[k], d);
+    if (lane == 0) red[wave * 16 + k] = acc[k];
   }
   __syncthreads();
-  for (int sidx = threadIdx.x; sidx < S; sidx += 256) {
-    const float u = ((tile[sidx] + tile[S + sidx]) + tile[2 * S + sidx]) + tile[3 * S + sidx] + b1[sidx];
-    const float hv = u / (1.f + expf(-u));
+  if (threadIdx.x < 16 && s0 + threadIdx.x < S) {
+    const int sidx = s0 + threadIdx.x;
+    const float u = ((red[threadIdx.x] + red[16 + threadIdx.x]) + red[32 + threadIdx.x]) + red[48 + threadIdx.x] + b1[sidx];
     u1[(size_t)img * S + sidx] = u;
-    h1[(size_t)img * S + sidx] = hv;
-    shh[sidx] = hv;
-  }
-  const int R = se_tile_rows(S), ld = S | 1;
-  for (int c0 = 0; c0 < Cl; c0 += R) {
-    const int nrow = min(R, Cl - c0);
-    __syncthreads();   // (first pass: shh complete; later passes: the tile has been read)
-    se_stage_rows(tile, W2 + (size_t)c0 * S, nrow, S, ld);
-    __syncthreads();
-    for (int r = threadIdx.x; r < nrow; r += 256) {
-      float acc = b2[c0 + r];
-      for (int sidx = 0; sidx < S; ++sidx) acc += tile[r * ld + sidx] * shh[sidx];
-      gate[(size_t)img * C + c0 + r] = 1.f / (1.f + expf(-acc));
-    }
+    h1[(size_t)img * S + sidx] = u / (1.f + expf(-u));
   }
 }
 
-// backward of the gate path of one image per block.  in: dgate[img][c] = sum_hw g*a; out (in place): du2 = dgate*s(1-s);
-// du1[img][s] = silu'(u1) * sum_c du2[c] W2[c][s];  dpool[img][c] = sum_s du1[s] W1[s][c]
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(float* __restrict__ dgate, const float* __restrict__ gate,
-                                                          const float* __restrict__ u1, const float* __restrict__ W1,
-                                                          const float* __restrict__ W2, float* __restrict__ du1,
-                                                          float* __restrict__ dpool, int C, int Cl, int S) {
-  extern __shared__ float sm[];   // du2[Cl], du1[S], tile[R][S|1] (then the four row-group partials [4][S])
-  float* s2 = sm;
-  float* s1 = sm + Cl;
-  float* tile = s1 + S;
-  const int img = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < Cl; c += 256) {
-    const float g = gate[(size_t)img * C + c];
-    const float v = dgate[(size_t)img * C + c] * g * (1.f - g);
-    dgate[(size_t)img * C + c] = v;
-    s2[c] = v;
+// fc2: block = (image, tile of R channels): the tile's rows of W2 [Cl][S] go through LDS (coalesced loads of whole rows,
+// then one row per thread; a thread walking its own row in global memory touches 64 cache lines per wave and load)
+__global__ __launch_bounds__(256) void se_fc2_train_kernel(const float* __restrict__ h1, const float* __restrict__ W2,
+                                                           const float* __restrict__ b2, float* __restrict__ gate, int C,
+                                                           int Cl, int S, int R) {
+  extern __shared__ float sm[];   // h[S], tile[R][S|1]
+  float* shh = sm;
+  float* tile = sm + S;
+  const int img = blockIdx.x, c0 = blockIdx.y * R, nrow = min(R, Cl - c0), ld = S | 1;
+  for (int i = threadIdx.x; i < S; i += 256) shh[i] = h1[(size_t)img * S + i];
+  se_stage_rows(tile, W2 + (size_t)c0 * S, nrow, S, ld);
+  __syncthreads();
+  for (int r = threadIdx.x; r < nrow; r += 256) {
+    float acc = b2[c0 + r];
+    for (int sidx = 0; sidx < S; ++sidx) acc += tile[r * ld + sidx] * shh[sidx];
+    gate[(size_t)img * C + c0 + r] = 1.f / (1.f + expf(-acc));
   }
-  // a thread owns hidden units lane, lane + 64, lane + 128 (S <= 192) of the rows wave, wave + 4, ... of each tile
-  float part[3] = {0.f, 0.f, 0.f};
-  const int R = se_tile_rows(S), ld = S | 1;
-  for (int c0 = 0; c0 < Cl; c0 += R) {
-    const int nrow = min(R, Cl - c0);
-    __syncthreads();
-    se_stage_rows(tile, W2 + (size_t)c0 * S, nrow, S, ld);
-    __syncthreads();
-    for (int r = wave; r < nrow; r += 4) {
-      const float v = s2[c0 + r];
+}
+
+// Backward of the gate path.  in: dgate[img][c] = sum_hw g*a.
+// bwd1: block = (image, tile of R channels): du2 = dgate*s(1-s) in place, and the tile's share of W2^T du2:
+// part[img][tile][s] = sum_{c in tile} du2[c] W2[c][s] (lanes along s, the four waves take rows r, r+4, ...)
+__global__ __launch_bounds__(256) void se_bwd1_kernel(float* __restrict__ dgate, const float* __restrict__ gate,
+                                                      const float* __restrict__ W2, float* __restrict__ part, int C, int Cl,
+                                                      int S, int R) {
+  extern __shared__ float sm[];   // du2[R], tile[R][S|1] (then the four row-group partials [4][S])
+  float* s2 = sm;
+  float* tile = sm + R;
+  const int img = blockIdx.x, c0 = blockIdx.y * R, nrow = min(R, Cl - c0), ld = S | 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = threadIdx.x; r < nrow; r += 256) {
+    const float g = gate[(size_t)img * C + c0 + r];
+    const float v = dgate[(size_t)img * C + c0 + r] * g * (1.f - g);
+    dgate[(size_t)img * C + c0 + r] = v;
+    s2[r] = v;
+  }
+  se_stage_rows(tile, W2 + (size_t)c0 * S, nrow, S, ld);
+  __syncthreads();
+  float acc[3] = {0.f, 0.f, 0.f};   // hidden units lane, lane + 64, lane + 128 (S <= 192)
+  for (int r = wave; r < nrow; r += 4) {
+    const float v = s2[r];
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-        if (lane + 64 * q < S) part[q] += v * tile[r * ld + lane + 64 * q];
-    }
+    for (int q = 0; q < 3; ++q)
+      if (lane + 64 * q < S) acc[q] += v * tile[r * ld + lane + 64 * q];
   }
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 3; ++q)
-    if (lane + 64 * q < S) tile[wave * S + lane + 64 * q] = part[q];
+    if (lane + 64 * q < S) tile[wave * S + lane + 64 * q] = acc[q];
   __syncthreads();
+  float* o = part + ((size_t)img * gridDim.y + blockIdx.y) * S;
+  for (int sidx = threadIdx.x; sidx < S; sidx += 256)
+    o[sidx] = ((tile[sidx] + tile[S + sidx]) + tile[2 * S + sidx]) + tile[3 * S + sidx];
+}
+
+// bwd2: block = (image, 1024 channels): du1[s] = silu'(u1[s]) * sum over the tiles of part (every block, block 0 stores
+// it), dpool[c] = sum_s du1[s] W1[s][c] for the block's channels (lanes along Cl, 16 loads in flight)
+__global__ __launch_bounds__(256) void se_bwd2_kernel(const float* __restrict__ part, int tiles, const float* __restrict__ u1,
+                                                      const float* __restrict__ W1, float* __restrict__ du1,
+                                                      float* __restrict__ dpool, int C, int Cl, int S) {
+  extern __shared__ float s1[];   // du1[S]
+  const int img = blockIdx.x;
   for (int sidx = threadIdx.x; sidx < S; sidx += 256) {
-    const float acc = ((tile[sidx] + tile[S + sidx]) + tile[2 * S + sidx]) + tile[3 * S + sidx];
+    float acc = 0.f;
+    for (int t = 0; t < tiles; ++t) acc += part[((size_t)img * tiles + t) * S + sidx];
     const float z = u1[(size_t)img * S + sidx], sg = 1.f / (1.f + expf(-z));
     const float v = acc * sg * (1.f + z * (1.f - sg));
-    du1[(size_t)img * S + sidx] = v;
     s1[sidx] = v;
+    if (blockIdx.y == 0) du1[(size_t)img * S + sidx] = v;
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < Cl; c += 256) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int sidx = 0; sidx < S; ++sidx) acc += s1[sidx] * W1[(size_t)sidx * Cl + c];
-    dpool[(size_t)img * C + c] = acc;
+  const int cbase = blockIdx.y * 1024 + threadIdx.x;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cq[q] = min(cbase + 256 * q, Cl - 1);
+#pragma unroll 4
+  for (int sidx = 0; sidx < S; ++sidx) {
+    const float v = s1[sidx];
+    const float* wr = W1 + (size_t)sidx * Cl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += v * wr[cq[q]];
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (cbase + 256 * q < Cl) dpool[(size_t)img * C + cbase + 256 * q] = acc[q];
 }
 
 // parameter gradients of the two 1x1 convs of the gate path (sums over the batch in ascending order); null: not wanted.
@@ -1041,13 +1069,7 @@ inline size_t walk_lds(int C) {
   const int c8 = C / 8, cts = walk_ctiles(C), tile = (c8 + cts - 1) / cts, tpr = tile < 256 ? tile : 256;
   return (size_t)(256 / tpr) * 2 * tile * 8 * sizeof(float);
 }
-inline size_t pool_lds(int C) {   // [rif][C] floats, rif = 256 / min(C / 8, 256)
-  const int c8 = C / 8, tpr = c8 < 256 ? c8 : 256;
-  return (size_t)(256 / tpr) * C * sizeof(float);
-}
-inline size_t se_gate_lds(int Cl, int S) {
-  return ((size_t)Cl + S + (size_t)std::max(se_tile_rows(S), 4) * (S | 1)) * sizeof(float);
-}
+inline size_t pool_lds(int C) { return walk_lds(C) / 2; }   // [rif][TW] floats
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -1)
 
 }  // namespace
@@ -1196,7 +1218,7 @@ int spk_se_chunks(int HW) { return HW >= 3136 ? 16 : (HW >= 196 ? 4 : 1); }
 int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* out, int n, int HW, int C, float scale,
                          hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
-  hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks), dim3(256), pool_lds(C), s, x, y, part, HW, C, chunks);
+  hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks, walk_ctiles(C)), dim3(256), pool_lds(C), s, x, y, part, HW, C, chunks);
   hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, out, n, chunks, C, scale);
   return LAUNCH_OK();
 }
@@ -1205,7 +1227,7 @@ int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* o
 int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part,
                               float* pooled, int n, int HW, int C, int act, hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
-  hipLaunchKernelGGL(bna_apply_pool_kernel, dim3(n, chunks), dim3(256), pool_lds(C), s, raw, scale, shift, out, part,
+  hipLaunchKernelGGL(bna_apply_pool_kernel, dim3(n, chunks, walk_ctiles(C)), dim3(256), pool_lds(C), s, raw, scale, shift, out, part,
                      HW, C, act, chunks);
   hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, pooled, n, chunks, C,
                      1.f / (float)HW);
@@ -1275,19 +1297,31 @@ int spk_launch_pack_train_padded(const float* w, bf16_t* out, int cout, int taps
   return LAUNCH_OK();
 }
 
+int spk_se_gate_tiles(int Cl, int S) {
+  const int R = se_tile_rows(S);
+  return (Cl + R - 1) / R;
+}
+
 int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
                            float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s) {
   if (S > 192) return -1;
-  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(n), dim3(256), se_gate_lds(Cl, S), s, pooled, W1, b1, W2, b2, u1, h1, gate,
-                     C, Cl, S);
+  const int R = se_tile_rows(S);
+  hipLaunchKernelGGL(se_fc1_train_kernel, dim3(n, (S + 15) / 16), dim3(256), (size_t)(Cl + 64) * 4, s, pooled, W1, b1, u1,
+                     h1, C, Cl, S);
+  hipLaunchKernelGGL(se_fc2_train_kernel, dim3(n, spk_se_gate_tiles(Cl, S)), dim3(256),
+                     ((size_t)S + (size_t)R * (S | 1)) * 4, s, h1, W2, b2, gate, C, Cl, S, R);
   return LAUNCH_OK();
 }
 
+// part: [n][spk_se_gate_tiles(Cl, S)][S] floats of scratch
 int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, const float* W1, const float* W2, float* du1,
-                           float* dpool, int n, int C, int Cl, int S, hipStream_t s) {
+                           float* dpool, float* part, int n, int C, int Cl, int S, hipStream_t s) {
   if (S > 192) return -1;
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(n), dim3(256), se_gate_lds(Cl, S), s, dgate, gate, u1, W1, W2, du1, dpool,
-                     C, Cl, S);
+  const int R = se_tile_rows(S), tiles = spk_se_gate_tiles(Cl, S);
+  hipLaunchKernelGGL(se_bwd1_kernel, dim3(n, tiles), dim3(256), ((size_t)R + (size_t)std::max(R, 4) * (S | 1)) * 4, s,
+                     dgate, gate, W2, part, C, Cl, S, R);
+  hipLaunchKernelGGL(se_bwd2_kernel, dim3(n, (Cl + 1023) / 1024), dim3(256), (size_t)S * 4, s, part, tiles, u1, W1, du1,
+                     dpool, C, Cl, S);
   return LAUNCH_OK();
 }
 
