@@ -457,6 +457,80 @@ __global__ __launch_bounds__(256) void stem3_wgrad_kernel(const bf16_t* __restri
   }
 }
 
+// The same sums with a register tile: a thread owns 4 output channels x 1 tap (x the 4 input channels) of every G-th
+// pixel of the staged tile - one float4 of dy and one float4 of the patch from LDS feed 16 FMAs (the kernel above: 4 FMAs
+// per 20 bytes of LDS reads, and 288 items on 3 x 256 thread slots: 470 us for 128 x 112 x 112 x 32, all of it exposed at the
+// end of the step behind the last BatchNorm backward).  items = 9 * cout/4 <= 256, G = 256 / items pixel groups, combined
+// through LDS in a fixed order.
+__global__ __launch_bounds__(256) void stem3_wgrad_rt_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             float* __restrict__ partials, int n, int h, int wd,
+                                                             int wstride, int cin, int cout, int C, int ho, int wo,
+                                                             int pix_per_block) {
+  constexpr int P = 64;
+  extern __shared__ float sm[];  // dys[P][cout], xs[P][9][4]; then [G][items][16]
+  float* dys = sm;
+  float4* xs = (float4*)(sm + P * cout);
+  const int M = n * ho * wo;
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(M, p0 + pix_per_block);
+  const int cg = cout >> 2, items = 9 * cg, G = 256 / items;
+  const int item = threadIdx.x % items, pg = threadIdx.x / items;
+  const int tap = item / cg, cog = item - tap * cg;
+  const bool mine = pg < G;
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int pb = p0; pb < p1; pb += P) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < P * cout; i += 256) {
+      const int pp = pb + i / cout;
+      dys[i] = pp < p1 ? lo_f32<DT>((unsigned)dy[(size_t)pp * C + i % cout]) : 0.f;
+    }
+    for (int i = threadIdx.x; i < P * 9; i += 256) {
+      const int pp = pb + i / 9, tp = i % 9;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pp < p1) {
+        const int ow = pp % wo, oh = (pp / wo) % ho, img = pp / (wo * ho);
+        const int ih = oh * 2 + tp / 3 - 1, iw = ow * 2 + tp % 3 - 1;
+        if (ih >= 0 && ih < h && iw >= 0 && iw < wd) {
+          const uint2 q = *(const uint2*)(x + (((size_t)img * h + ih) * wstride + iw) * 4);
+          v = make_float4(lo_f32<DT>(q.x), hi_f32<DT>(q.x), lo_f32<DT>(q.y), hi_f32<DT>(q.y));
+        }
+      }
+      xs[i] = v;
+    }
+    __syncthreads();
+    if (mine)
+#pragma unroll 4
+      for (int pp = pg; pp < P; pp += G) {
+        const float4 g = *(const float4*)(dys + pp * cout + cog * 4);
+        const float4 v = xs[pp * 9 + tap];
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          acc[a][0] += gg[a] * v.x; acc[a][1] += gg[a] * v.y; acc[a][2] += gg[a] * v.z; acc[a][3] += gg[a] * v.w;
+        }
+      }
+  }
+  __syncthreads();
+  if (mine)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sm[((size_t)pg * items + item) * 16 + a * 4 + b] = acc[a][b];
+  __syncthreads();
+  float* out = partials + (size_t)blockIdx.x * cout * 9 * cin;
+  for (int i = threadIdx.x; i < items * 16; i += 256) {
+    const int it = i >> 4, a = (i >> 2) & 3, b = i & 3;
+    if (b >= cin) continue;
+    float t = 0.f;
+    for (int g = 0; g < G; ++g) t += sm[((size_t)g * items + it) * 16 + a * 4 + b];
+    const int tp = it / cg, co = (it - tp * cg) * 4 + a;
+    out[((size_t)co * 9 + tp) * cin + b] = t;
+  }
+}
+
 // ---- depthwise conv ----
 // master [C_log][taps] fp32 -> tap-major [taps][C] rounded to bf16 values (zeros in the pad channels)
 // (+ the same with the window flipped, [taps][C] behind the first: the stride-1 data gradient is a depthwise conv of dy
@@ -1140,6 +1214,14 @@ int spk_launch_stem3_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, i
   if (cout * 9 > 768 || cin > 4) return -1;
   int ppb;
   const int nb = spk_stem3_wgrad_blocks(n * ho * wo, &ppb);
+  if (cout % 4 == 0 && 9 * (cout / 4) <= 256) {
+    const int items = 9 * (cout / 4), G = 256 / items;
+    const size_t lds = (size_t)std::max(64 * cout + 64 * 36, G * items * 16) * 4;
+    hipLaunchKernelGGL(stem3_wgrad_rt_kernel, dim3(nb), dim3(256), lds, s, x, dy, partials, n, h, wd, wstride, cin, cout, C,
+                       ho, wo, ppb);
+    *blocks = nb;
+    return LAUNCH_OK();
+  }
   hipLaunchKernelGGL(stem3_wgrad_kernel, dim3(nb), dim3(256), (size_t)(64 * C + 64 * 36) * 4, s, x, dy, partials, n, h,
                      wd, wstride, cin, cout, C, ho, wo, ppb);
   *blocks = nb;
