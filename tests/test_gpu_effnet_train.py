@@ -255,3 +255,41 @@ def test_training_reduces_the_loss_and_round_trips_the_state():
     net.train()
     net.forward_backward(x, y)   # and back to the padded training plan
     assert np.isfinite(net.read_stats()[0])
+
+
+@pytest.mark.parametrize("network", ["efficientnet_b0", "resnet18"])
+def test_gradients_do_not_depend_on_what_else_is_frozen(network):
+    """The reference's unfreeze schedule (network.py:133-187: BatchNorm + head first, then the last two base modules, then
+    everything) changes WHICH gradients a step computes, never their values: the gradient of a parameter that is trainable
+    in a phase must equal the one the all-trainable step gives it (the backward pass skips work nothing trainable depends
+    on, and chooses other kernels - overwrite instead of accumulate, second-stream weight gradients - on the way)."""
+    classes, n, hw = 10, 8, 64
+    g, specs, state, net = _net(network, classes, seed=7)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=20)).cuda()
+    y = torch.from_numpy(synth.synth_labels(n, classes, seed=21)).cuda()
+    net.train()
+    params = dict(net.named_parameters())
+    kinds = {k: kind for k, _, kind in specs}
+    shapes = {k: tuple(shape) for k, shape, _ in specs}
+
+    def grads(trainable):
+        for k, p in params.items():
+            p.requires_grad = k in trainable
+        net.reset_stats()
+        net.forward_backward(x, y)
+        return {k: net._read_grad(k, shapes[k]).clone() for k in trainable}
+
+    everything = set(params)
+    bn_head = {k for k in params if kinds[k].startswith("bn_") or k.startswith("head.")}
+    base_mods = sorted({k.split(".")[1] if network.startswith("resnet") else ".".join(k.split(".")[1:3])
+                        for k in params if k.startswith("base.")}, key=lambda s: [int(t) for t in s.split(".")])
+    last_two = tuple("base." + mname + "." for mname in base_mods[-2:])
+    phase2 = bn_head | {k for k in params if k.startswith(last_two)}
+    full = grads(everything)
+    for name, subset in (("BatchNorm + head", bn_head), ("+ the last two base modules", phase2)):
+        assert 0 < len(subset) < len(everything)
+        part = grads(subset)
+        worst = max((_rel(part[k], full[k]), k) for k in subset)
+        print(f"{network}, {name}: {len(subset)} of {len(everything)} tensors trainable, worst difference {worst[0]:.2e} "
+              f"at {worst[1]}")
+        assert worst[0] < 1e-5, worst
