@@ -158,7 +158,7 @@ static int ensure_state(spk_model* m) {
       c.stat_off = st;
       st += (size_t)4 * L.cout_p;
       c.dwt_off = dw;
-      dw += (size_t)2 * L.d.k * L.d.k * L.cout_p;   // + the flipped window (dw_pack_kernel)
+      dw += (size_t)2 * L.d.k * L.d.k * L.cout_p;   // + the flipped window (pack_padded_multi_kernel)
       unit_c = std::max(unit_c, (size_t)L.cout_p);
       continue;
     }
@@ -301,19 +301,31 @@ static int repack_weights(spk_model* m) {
     tab.count = 0;
     return r;
   };
+  PadPackTable ptab;   // EfficientNet: channel-padded GEMM images and depthwise windows, 48 tensors per launch
+  ptab.count = 0;
+  auto pflush = [&]() -> int {
+    const int r = spk_launch_pack_padded_multi(m->pbuf, t->wpack, t->dwt, ptab, m->stream);
+    ptab.count = 0;
+    return r;
+  };
+  auto padd = [&](size_t src, size_t dst, int cout, int taps, int cin, int cout_p, int cin_p, int kind) -> int {
+    PadPackEntry& e = ptab.e[ptab.count++];
+    e.src = src; e.dst = dst;
+    e.cout = (unsigned)cout; e.taps = (unsigned)taps; e.cin = (unsigned)cin;
+    e.cout_p = (unsigned)cout_p; e.cin_p = (unsigned)cin_p; e.kind = (unsigned)kind;
+    return ptab.count == 48 ? pflush() : 0;
+  };
   for (size_t i = 0; i < m->layers.size(); ++i) {
     const Layer& L = m->layers[i];
     if (L.d.kind == SPK_OP_DWCONV) {
-      K_TRY(spk_launch_dw_pack(m->P(L.p_w), t->dwt + t->conv[i].dwt_off, L.d.cout, L.cout_p, L.d.k * L.d.k, m->stream),
-            "dw_pack");
+      K_TRY(padd(m->params[L.p_w].off, t->conv[i].dwt_off, L.d.cout, L.d.k * L.d.k, 0, L.cout_p, 0, 2), "dw_pack");
       continue;
     }
     if (L.d.kind != SPK_OP_CONV || L.mode == CONV_MODE_STEM3) continue;   // the 3x3 stem reads the master weights
     if (m->effnet) {   // channel-padded GEMM images, zeros outside the layer's own widths
       for (int kind = 0; kind < 2; ++kind)
-        K_TRY(spk_launch_pack_train_padded(m->P(L.p_w), t->wpack + (kind ? t->conv[i].wdg_off : t->conv[i].wfwd_off),
-                                           L.d.cout, L.d.k * L.d.k, L.d.cin, L.cout_p, L.cin_p, kind, m->stream),
-              "pack_train_padded");
+        K_TRY(padd(m->params[L.p_w].off, kind ? t->conv[i].wdg_off : t->conv[i].wfwd_off, L.d.cout, L.d.k * L.d.k, L.d.cin,
+                   L.cout_p, L.cin_p, kind), "pack_train_padded");
       continue;
     }
     if (L.mode == CONV_MODE_STEM) {
@@ -331,6 +343,7 @@ static int repack_weights(spk_model* m) {
     }
   }
   K_TRY(flush(), "pack_multi");
+  K_TRY(pflush(), "pack_padded_multi");
   t->weights_dirty = false;
   return SPK_OK;
 }

@@ -26,7 +26,6 @@ int spk_launch_stem3_train_fwd(const bf16_t* x, const float* w, bf16_t* y, int n
 int spk_stem3_wgrad_blocks(int M, int* pix_per_block);
 int spk_launch_stem3_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int wstride,
                            int cin, int cout, int C, int ho, int wo, int* blocks, hipStream_t s);
-int spk_launch_dw_pack(const float* w, float* wt, int c_log, int C, int taps, hipStream_t s);
 int spk_launch_dw_train_fwd(const bf16_t* x, const float* wt, bf16_t* y, int n, int h, int wd, int C, int k, int stride,
                             int pad, int ho, int wo, hipStream_t s);
 int spk_launch_dw_dgrad(const bf16_t* dy, const float* wt, bf16_t* dx, int accumulate, int n, int h, int wd, int C, int k,
@@ -46,8 +45,18 @@ int spk_launch_ew(int mode, const float* a, const float* b, float* out, size_t n
 int spk_launch_colsum_strided(const float* dy, float* db, int n, int c, int stride, hipStream_t s);
 int spk_launch_slab_reduce_sub(const float* slabs, float* out, int cout, int taps, int cin, int cout_p, int cin_p,
                                int splits, hipStream_t s);
-int spk_launch_pack_train_padded(const float* w, bf16_t* out, int cout, int taps, int cin, int cout_p, int cin_p,
-                                 int kind, hipStream_t s);
+// Every weight image of an EfficientNet training step in a few launches: entries of kind 0 / 1 are the forward / data-gradient
+// GEMM images of a conv (bf16, channel-padded, offsets in elements into pbuf / wpack), kind 2 the tap-major depthwise
+// window and its flipped copy (floats, offset into dwt; cin unused, cout_p = the padded channel count)
+struct PadPackEntry {
+  size_t src, dst;
+  unsigned cout, taps, cin, cout_p, cin_p, kind;
+};
+struct PadPackTable {
+  PadPackEntry e[48];
+  int count;
+};
+int spk_launch_pack_padded_multi(const float* pbuf, bf16_t* wpack, float* dwt, const PadPackTable& t, hipStream_t s);
 int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
                            float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s);
 int spk_se_gate_tiles(int Cl, int S);

@@ -296,20 +296,36 @@ __global__ __launch_bounds__(1024) void bna_bwd_finalize_kernel(
   coef[2 * C + c] = gamma[c] * invstd[c];
 }
 
-// master [cout][taps][cin] fp32 -> bf16 images of the channel-padded GEMM: kind 0 forward [cout_p][taps][cin_p],
-// kind 1 data gradient [cin_p][taps][cout_p]; zeros outside the logical ranges
-__global__ void pack_train_padded_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout, int taps,
-                                         int cin, int cout_p, int cin_p, int kind) {
+// One launch for up to 48 weight images of the step (blockIdx.y = table entry).  kind 0 / 1: master [cout][taps][cin] fp32 ->
+// bf16 image of the channel-padded GEMM, forward [cout_p][taps][cin_p] / data gradient [cin_p][taps][cout_p], zeros outside
+// the logical ranges; kind 2: depthwise master [C_log][taps] -> tap-major [taps][C] floats rounded to bf16 values (zeros in
+// the pad channels) and, behind it, the same with the window flipped (the stride-1 data gradient is a depthwise conv of dy
+// with it)
+__global__ void pack_padded_multi_kernel(const float* __restrict__ pbuf, bf16_t* __restrict__ wpack, float* __restrict__ dwt,
+                                         PadPackTable t) {
+  const PadPackEntry e = t.e[blockIdx.y];
+  const float* w = pbuf + e.src;
+  const int cout = (int)e.cout, taps = (int)e.taps, cin = (int)e.cin, cout_p = (int)e.cout_p, cin_p = (int)e.cin_p;
+  if (e.kind == 2) {   // dw_pack_kernel
+    float* wt = dwt + e.dst;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < taps * cout_p; i += gridDim.x * blockDim.x) {
+      const int c = i % cout_p, tp = i / cout_p;
+      const float v = c < cout ? bf16_round(w[(size_t)c * taps + tp]) : 0.f;
+      wt[i] = v;
+      wt[(size_t)(2 * taps - 1 - tp) * cout_p + c] = v;
+    }
+    return;
+  }
+  bf16_t* out = wpack + e.dst;   // pack_train_padded_kernel
   const size_t n = (size_t)cout_p * taps * cin_p;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    int co, t, ci;
-    if (kind == 0) { ci = (int)(i % cin_p); t = (int)((i / cin_p) % taps); co = (int)(i / ((size_t)cin_p * taps)); }
-    else { co = (int)(i % cout_p); t = (int)((i / cout_p) % taps); ci = (int)(i / ((size_t)cout_p * taps)); }
-    out[i] = (co < cout && ci < cin) ? to_h16<DT>(w[((size_t)co * taps + t) * cin + ci]) : (bf16_t)0;
+    int co, tp, ci;
+    if (e.kind == 0) { ci = (int)(i % cin_p); tp = (int)((i / cin_p) % taps); co = (int)(i / ((size_t)cin_p * taps)); }
+    else { co = (int)(i % cout_p); tp = (int)((i / cout_p) % taps); ci = (int)(i / ((size_t)cout_p * taps)); }
+    out[i] = (co < cout && ci < cin) ? to_h16<DT>(w[((size_t)co * taps + tp) * cin + ci]) : (bf16_t)0;
   }
 }
 
-// ---- stochastic depth ("row" mode, torchvision.ops.StochasticDepth): rs[img] = bernoulli(1-p) / (1-p)
 __global__ void sd_rowscale_kernel(float* __restrict__ rs, int n, float p, unsigned long long seed) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -532,17 +548,8 @@ __global__ __launch_bounds__(256) void stem3_wgrad_rt_kernel(const bf16_t* __res
 }
 
 // ---- depthwise conv ----
-// master [C_log][taps] fp32 -> tap-major [taps][C] rounded to bf16 values (zeros in the pad channels)
-// (+ the same with the window flipped, [taps][C] behind the first: the stride-1 data gradient is a depthwise conv of dy
-// with it)
-__global__ void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wt, int c_log, int C, int taps) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= taps * C) return;
-  const int c = i % C, t = i / C;
-  const float v = c < c_log ? bf16_round(w[(size_t)c * taps + t]) : 0.f;
-  wt[i] = v;
-  wt[(size_t)(2 * taps - 1 - t) * C + c] = v;
-}
+// (the tap-major depthwise windows [taps][C], rounded to bf16 values with zeros in the pad channels, and their flipped
+// copies come from pack_padded_multi_kernel)
 
 // Loads are unconditional (coordinates clamped into the image, the value zeroed by a select): the K loads of a window row
 // are in flight together.  With a branch around every tap each load was waited for before the next was issued.
@@ -1228,11 +1235,6 @@ int spk_launch_stem3_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, i
   return LAUNCH_OK();
 }
 
-int spk_launch_dw_pack(const float* w, float* wt, int c_log, int C, int taps, hipStream_t s) {
-  hipLaunchKernelGGL(dw_pack_kernel, dim3((taps * C + 255) / 256), dim3(256), 0, s, w, wt, c_log, C, taps);
-  return LAUNCH_OK();
-}
-
 int spk_launch_dw_train_fwd(const bf16_t* x, const float* wt, bf16_t* y, int n, int h, int wd, int C, int k, int stride,
                             int pad, int ho, int wo, hipStream_t s) {
   const size_t total = (size_t)n * ho * wo * (C / 8);
@@ -1372,10 +1374,9 @@ int spk_launch_bna_bwd_finalize(const float* partials, int count, int C, int c_l
   return LAUNCH_OK();
 }
 
-int spk_launch_pack_train_padded(const float* w, bf16_t* out, int cout, int taps, int cin, int cout_p, int cin_p,
-                                 int kind, hipStream_t s) {
-  hipLaunchKernelGGL(pack_train_padded_kernel, dim3(grid_of((size_t)cout_p * taps * cin_p, 256)), dim3(256), 0, s, w, out,
-                     cout, taps, cin, cout_p, cin_p, kind);
+int spk_launch_pack_padded_multi(const float* pbuf, bf16_t* wpack, float* dwt, const PadPackTable& t, hipStream_t s) {
+  if (t.count == 0) return 0;
+  hipLaunchKernelGGL(pack_padded_multi_kernel, dim3(64, t.count), dim3(256), 0, s, pbuf, wpack, dwt, t);
   return LAUNCH_OK();
 }
 
