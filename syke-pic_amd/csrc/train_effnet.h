@@ -57,10 +57,12 @@ struct PadPackTable {
   int count;
 };
 int spk_launch_pack_padded_multi(const float* pbuf, bf16_t* wpack, float* dwt, const PadPackTable& t, hipStream_t s);
-int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
-                           float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s);
+int spk_launch_se_gate_fwd(const float* part, int chunks, float scale, float* pooled, const float* W1, const float* b1,
+                           const float* W2, const float* b2, float* u1, float* h1, float* gate, int n, int C, int Cl, int S,
+                           hipStream_t s);
 int spk_se_gate_tiles(int Cl, int S);
-int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, const float* W1, const float* W2, float* du1,
-                           float* dpool, float* part, int n, int C, int Cl, int S, hipStream_t s);
+int spk_launch_se_gate_bwd(const float* pool_part, int chunks, float* dgate, const float* gate, const float* u1,
+                           const float* W1, const float* W2, float* du1, float* dpool, float* part, int n, int C, int Cl,
+                           int S, hipStream_t s);
 int spk_launch_se_wgrad(const float* du2, const float* h1, const float* du1, const float* pooled, float* gW1, float* gb1,
                         float* gW2, float* gb2, int n, int C, int Cl, int S, hipStream_t s);

@@ -856,14 +856,23 @@ __device__ __forceinline__ void se_stage_rows(float* __restrict__ tile, const fl
 // Two launches, both (image x tile) grids: with one block per image the block walked both matrices by itself - a chain of
 // dependent L2 round trips, 60-150 us for the 2688-channel layers of B4 however little arithmetic that is.
 // fc1: block = (image, 16 hidden units); W1 [S][Cl] read with the lanes along Cl, 64 loads in flight per thread.
-__global__ __launch_bounds__(256) void se_fc1_train_kernel(const float* __restrict__ pooled, const float* __restrict__ W1,
+__global__ __launch_bounds__(256) void se_fc1_train_kernel(const float* __restrict__ part, int chunks, float scale,
+                                                           float* __restrict__ pooled, const float* __restrict__ W1,
                                                            const float* __restrict__ b1, float* __restrict__ u1,
                                                            float* __restrict__ h1, int C, int Cl, int S) {
   extern __shared__ float sm[];   // pooled[Cl], red[4][16]
   float* sp = sm;
   float* red = sm + Cl;
   const int img = blockIdx.x, s0 = blockIdx.y * 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < Cl; c += 256) sp[c] = pooled[(size_t)img * C + c];
+  // the squeeze: mean over HW from the per-chunk channel sums of the pooling pass (every block; block 0 keeps it for the
+  // backward pass)
+  for (int c = threadIdx.x; c < Cl; c += 256) {
+    float t = 0.f;
+    for (int k = 0; k < chunks; ++k) t += part[((size_t)img * chunks + k) * C + c];
+    t *= scale;
+    sp[c] = t;
+    if (blockIdx.y == 0) pooled[(size_t)img * C + c] = t;
+  }
   __syncthreads();
   float acc[16];
 #pragma unroll
@@ -915,10 +924,11 @@ __global__ __launch_bounds__(256) void se_fc2_train_kernel(const float* __restri
   }
 }
 
-// Backward of the gate path.  in: dgate[img][c] = sum_hw g*a.
-// bwd1: block = (image, tile of R channels): du2 = dgate*s(1-s) in place, and the tile's share of W2^T du2:
+// Backward of the gate path.  in: pool_part[img][chunk][c], the per-chunk sums over HW of g*a.
+// bwd1: block = (image, tile of R channels): du2 = (sum of the chunks)*s(1-s) -> dgate, and the tile's share of W2^T du2:
 // part[img][tile][s] = sum_{c in tile} du2[c] W2[c][s] (lanes along s, the four waves take rows r, r+4, ...)
-__global__ __launch_bounds__(256) void se_bwd1_kernel(float* __restrict__ dgate, const float* __restrict__ gate,
+__global__ __launch_bounds__(256) void se_bwd1_kernel(const float* __restrict__ pool_part, int chunks,
+                                                      float* __restrict__ dgate, const float* __restrict__ gate,
                                                       const float* __restrict__ W2, float* __restrict__ part, int C, int Cl,
                                                       int S, int R) {
   extern __shared__ float sm[];   // du2[R], tile[R][S|1] (then the four row-group partials [4][S])
@@ -928,7 +938,9 @@ __global__ __launch_bounds__(256) void se_bwd1_kernel(float* __restrict__ dgate,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int r = threadIdx.x; r < nrow; r += 256) {
     const float g = gate[(size_t)img * C + c0 + r];
-    const float v = dgate[(size_t)img * C + c0 + r] * g * (1.f - g);
+    float dg = 0.f;   // sum over HW of g*a from the per-chunk sums of the pooling pass
+    for (int k = 0; k < chunks; ++k) dg += pool_part[((size_t)img * chunks + k) * C + c0 + r];
+    const float v = dg * g * (1.f - g);
     dgate[(size_t)img * C + c0 + r] = v;
     s2[r] = v;
   }
@@ -1303,7 +1315,8 @@ int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* o
                          hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
   hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks, walk_ctiles(C)), dim3(256), pool_lds(C), s, x, y, part, HW, C, chunks);
-  hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, out, n, chunks, C, scale);
+  if (out)   // (the squeeze-excitation kernels sum the chunks themselves)
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, out, n, chunks, C, scale);
   return LAUNCH_OK();
 }
 
@@ -1313,8 +1326,9 @@ int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float
   const int chunks = spk_se_chunks(HW);
   hipLaunchKernelGGL(bna_apply_pool_kernel, dim3(n, chunks, walk_ctiles(C)), dim3(256), pool_lds(C), s, raw, scale, shift, out, part,
                      HW, C, act, chunks);
-  hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, pooled, n, chunks, C,
-                     1.f / (float)HW);
+  if (pooled)
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, pooled, n, chunks, C,
+                       1.f / (float)HW);
   return LAUNCH_OK();
 }
 
@@ -1385,24 +1399,28 @@ int spk_se_gate_tiles(int Cl, int S) {
   return (Cl + R - 1) / R;
 }
 
-int spk_launch_se_gate_fwd(const float* pooled, const float* W1, const float* b1, const float* W2, const float* b2,
-                           float* u1, float* h1, float* gate, int n, int C, int Cl, int S, hipStream_t s) {
+// part: [n][chunks][C] channel sums of the pooling pass (spk_launch_pool_rows / spk_launch_bna_apply_pool with out = null),
+// pooled = scale * their sum is stored for the backward pass
+int spk_launch_se_gate_fwd(const float* part, int chunks, float scale, float* pooled, const float* W1, const float* b1,
+                           const float* W2, const float* b2, float* u1, float* h1, float* gate, int n, int C, int Cl, int S,
+                           hipStream_t s) {
   if (S > 192) return -1;
   const int R = se_tile_rows(S);
-  hipLaunchKernelGGL(se_fc1_train_kernel, dim3(n, (S + 15) / 16), dim3(256), (size_t)(Cl + 64) * 4, s, pooled, W1, b1, u1,
-                     h1, C, Cl, S);
+  hipLaunchKernelGGL(se_fc1_train_kernel, dim3(n, (S + 15) / 16), dim3(256), (size_t)(Cl + 64) * 4, s, part, chunks, scale,
+                     pooled, W1, b1, u1, h1, C, Cl, S);
   hipLaunchKernelGGL(se_fc2_train_kernel, dim3(n, spk_se_gate_tiles(Cl, S)), dim3(256),
                      ((size_t)S + (size_t)R * (S | 1)) * 4, s, h1, W2, b2, gate, C, Cl, S, R);
   return LAUNCH_OK();
 }
 
 // part: [n][spk_se_gate_tiles(Cl, S)][S] floats of scratch
-int spk_launch_se_gate_bwd(float* dgate, const float* gate, const float* u1, const float* W1, const float* W2, float* du1,
-                           float* dpool, float* part, int n, int C, int Cl, int S, hipStream_t s) {
+int spk_launch_se_gate_bwd(const float* pool_part, int chunks, float* dgate, const float* gate, const float* u1,
+                           const float* W1, const float* W2, float* du1, float* dpool, float* part, int n, int C, int Cl,
+                           int S, hipStream_t s) {
   if (S > 192) return -1;
   const int R = se_tile_rows(S), tiles = spk_se_gate_tiles(Cl, S);
   hipLaunchKernelGGL(se_bwd1_kernel, dim3(n, tiles), dim3(256), ((size_t)R + (size_t)std::max(R, 4) * (S | 1)) * 4, s,
-                     dgate, gate, W2, part, C, Cl, S, R);
+                     pool_part, chunks, dgate, gate, W2, part, C, Cl, S, R);
   hipLaunchKernelGGL(se_bwd2_kernel, dim3(n, (Cl + 1023) / 1024), dim3(256), (size_t)S * 4, s, part, tiles, u1, W1, du1,
                      dpool, C, Cl, S);
   return LAUNCH_OK();
