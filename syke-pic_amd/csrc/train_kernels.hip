@@ -129,14 +129,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ g, const unsigned char* __restrict__ mask, const bf16_t* __restrict__ y,
     const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ partials,
     int M, int C, int relu, int rows_per_block) {
-  extern __shared__ float sm[];  // [rows_in_flight][2][C]
+  // A block owns rows x one channel tile (blockIdx.y of gridDim.y, <= 256 channels each): on the 7x7 / 14x14 layers
+  // (2048 channels x 12544 rows) a thread used to walk ALL rows of its block for one 8-channel group, one row in flight,
+  // on 196 blocks - latency-bound at a third of the rate of the apply pass.
+  extern __shared__ float sm[];  // [rows_in_flight][2][TW]
   const int c8 = C >> 3;
-  const int tpr = c8 < 256 ? c8 : 256;       // threads per row
+  const int tile = (c8 + (int)gridDim.y - 1) / (int)gridDim.y, TW = tile * 8;
+  const int cb = blockIdx.y * tile, ce = min(c8, cb + tile);
+  const int tpr = tile < 256 ? tile : 256;   // threads per row
   const int rif = 256 / tpr;                 // rows in flight
   const int lane_c = threadIdx.x % tpr, lane_r = threadIdx.x / tpr;
   const int row0 = blockIdx.x * rows_per_block;
   const int row1 = min(M, row0 + rows_per_block);
-  for (int cc = lane_c; cc < c8; cc += tpr) {
+  for (int cc = cb + lane_c; cc < ce && lane_r < rif; cc += tpr) {
     float s1[8], s2[8], mu[8], is[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = s2[j] = 0.f; mu[j] = mean[cc * 8 + j]; is[j] = invstd[cc * 8 + j]; }
@@ -155,15 +160,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      sm[(lane_r * 2 + 0) * C + cc * 8 + j] = s1[j];
-      sm[(lane_r * 2 + 1) * C + cc * 8 + j] = s2[j];
+      sm[(lane_r * 2 + 0) * TW + (cc - cb) * 8 + j] = s1[j];
+      sm[(lane_r * 2 + 1) * TW + (cc - cb) * 8 + j] = s2[j];
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+  const int nch = (ce - cb) * 8;
+  for (int i = threadIdx.x; i < 2 * nch; i += 256) {
+    const int which = i >= nch, col = i - which * nch;
     float t = 0.f;
-    for (int r = 0; r < rif; ++r) t += sm[r * 2 * C + i];
-    partials[(size_t)blockIdx.x * 2 * C + i] = t;
+    for (int r = 0; r < rif; ++r) t += sm[(r * 2 + which) * TW + col];
+    partials[((size_t)blockIdx.x * 2 + which) * C + cb * 8 + col] = t;
   }
 }
 
@@ -681,10 +688,11 @@ int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* a, const bf16_t* y, 
                       int C, int relu, float* tmp, hipStream_t s) {
   int rpb;
   int nb = spk_bn_bwd_blocks(M, C, &rpb);
-  const int c8 = C / 8;
-  const int tpr = c8 < 256 ? c8 : 256;
-  const size_t lds = (size_t)(256 / tpr) * 2 * C * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), lds, s, g, a, y, mean, invstd, partials,
+  static const bool tiled = !getenv("SPK_BN_CTILES") || atoi(getenv("SPK_BN_CTILES")) != 0;   // 0: one tile (round 2)
+  const int c8 = C / 8, cts = tiled ? (c8 + 31) / 32 : 1, tile = (c8 + cts - 1) / cts;
+  const int tpr = tile < 256 ? tile : 256;
+  const size_t lds = (size_t)(256 / tpr) * 2 * tile * 8 * sizeof(float);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, cts), dim3(256), lds, s, g, a, y, mean, invstd, partials,
                      M, C, relu, rpb);
   const float* fin = presum(partials, &nb, C, tmp, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, fin, nb, C,
