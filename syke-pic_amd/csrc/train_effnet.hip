@@ -28,7 +28,9 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return v;
 }
 __device__ __forceinline__ float bf16_round(float f) { return lo_f32<DT>(pack2<DT>(f, 0.f)); }
-__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (v_div_scale x2, v_rcp, 4 FMAs, v_div_fmas, v_div_fixup per
+// element): the BatchNorm + SiLU passes are as much VALU- as HBM-bound
+__device__ __forceinline__ float sigmoidf_(float z) { return __builtin_amdgcn_rcpf(1.f + __expf(-z)); }
 __device__ __forceinline__ float act_fwd(float z, int act) {
   return act == SPK_ACT_SILU ? z * sigmoidf_(z) : (act == SPK_ACT_RELU ? fmaxf(z, 0.f) : z);
 }
