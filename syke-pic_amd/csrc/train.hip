@@ -550,7 +550,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           // the squeeze of the layer behind rides on this pass (per-chunk channel sums into the shared scratch; that
           // layer's first gate kernel turns them into its pooled means)
           K_TRY(spk_launch_bna_apply_pool(t->RAW(i), st + 2 * C, st + 3 * C, (bf16_t*)m->T(L.d.dst),
-                                          (float*)((char*)t->arena + t->se_tmp_off), nullptr, n, o.h * o.w, C, L.d.relu, s),
+                                          (float*)((char*)t->arena + t->se_tmp_off), n, o.h * o.w, C, L.d.relu, s),
                 "bn_apply + squeeze");
           squeezed = i + 1;
         } else {
@@ -570,7 +570,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* scratch = (float*)((char*)t->arena + t->se_tmp_off);
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
         if (squeezed != i)
-          K_TRY(spk_launch_pool_rows(a, nullptr, scratch, nullptr, n, HW, C, 1.f, s), "se pool");
+          K_TRY(spk_launch_pool_rows(a, nullptr, scratch, n, HW, C, s), "se pool");
         K_TRY(spk_launch_se_gate_fwd(scratch, spk_se_chunks(HW), 1.f / (float)HW, pooled, m->P(L.p_w), m->P(L.p_b), m->P(L.p_w2), m->P(L.p_b2), u1, h1, gate, n, C, Cl, S,
                                      s), "se gates");
         K_TRY(spk_launch_se_scale(a, gate, (bf16_t*)m->T(L.d.dst), n, HW, C, s), "se scale");
@@ -809,7 +809,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         float* dpool = scratch + (size_t)n * spk_se_chunks(HW) * C;
         const bf16_t* g = (const bf16_t*)t->G(L.d.dst);
         const bf16_t* a = (const bf16_t*)m->T(L.d.src);
-        K_TRY(spk_launch_pool_rows(g, a, scratch, nullptr, n, HW, C, 1.f, s), "se dgate");
+        K_TRY(spk_launch_pool_rows(g, a, scratch, n, HW, C, s), "se dgate");
         const Param &w1 = m->params[L.p_w], &b1 = m->params[L.p_b], &w2 = m->params[L.p_w2], &b2 = m->params[L.p_b2];
         K_TRY(spk_launch_se_gate_bwd(scratch, spk_se_chunks(HW), dgate, gate, u1, m->P(L.p_w), m->P(L.p_w2), du1, dpool, dpool + (size_t)n * C, n, C, Cl,
                                      S, s), "se gates bwd");

@@ -2,9 +2,7 @@
 #pragma once
 #include "spk_common.h"
 
-enum { SPK_EW_SILU = 0, SPK_EW_SIGMOID = 1, SPK_EW_SILU_BWD = 2, SPK_EW_SIGMOID_BWD = 3 };
 
-int spk_eff_stat_blocks(int M, int* rows_per_block);
 int spk_launch_col_stats(const bf16_t* x, float* partials, int M, int C, int* blocks, hipStream_t s);
 int spk_launch_bna_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
                             const float* beta, float* rmean, float* rvar, float* st, float eps, float momentum,
@@ -33,16 +31,13 @@ int spk_launch_dw_dgrad(const bf16_t* dy, const float* wt, bf16_t* dx, int accum
 int spk_dw_wgrad_rows(int M, int C);
 int spk_launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int C, int c_log,
                         int k, int stride, int pad, int ho, int wo, int* rows, hipStream_t s);
-int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part,
-                              float* pooled, int n, int HW, int C, int act, hipStream_t s);
+int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part, int n,
+                              int HW, int C, int act, hipStream_t s);
 int spk_se_chunks(int HW);
-int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* out, int n, int HW, int C, float scale,
-                         hipStream_t s);
+int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, int n, int HW, int C, hipStream_t s);
 int spk_launch_se_scale(const bf16_t* a, const float* gate, bf16_t* out, int n, int HW, int C, hipStream_t s);
 int spk_launch_se_bwd_apply(const bf16_t* g, const float* gate, const float* dpool, bf16_t* da, int n, int HW, int C,
                             hipStream_t s);
-int spk_launch_ew(int mode, const float* a, const float* b, float* out, size_t n, hipStream_t s);
-int spk_launch_colsum_strided(const float* dy, float* db, int n, int c, int stride, hipStream_t s);
 int spk_launch_slab_reduce_sub(const float* slabs, float* out, int cout, int taps, int cin, int cout_p, int cin_p,
                                int splits, hipStream_t s);
 // Every weight image of an EfficientNet training step in a few launches: entries of kind 0 / 1 are the forward / data-gradient

@@ -819,15 +819,6 @@ __global__ __launch_bounds__(256) void bna_apply_pool_kernel(const bf16_t* __res
     o[i] = t;
   }
 }
-__global__ void pool_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int n, int chunks, int C,
-                                   float scale) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * C) return;
-  const int img = i / C, c = i % C;
-  float t = 0.f;
-  for (int k = 0; k < chunks; ++k) t += part[((size_t)img * chunks + k) * C + c];
-  out[i] = t * scale;
-}
 
 // rows of W2 [Cl][S] staged per pass through LDS (row stride S|1: conflict-free both ways), about 47 KB
 __host__ __device__ inline int se_tile_rows(int S) {
@@ -1106,34 +1097,6 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
-// small element-wise maps on the [n][squeeze] / [n][C] vectors
-constexpr int EW_SILU = SPK_EW_SILU, EW_SIGMOID = SPK_EW_SIGMOID, EW_SILU_BWD = SPK_EW_SILU_BWD;
-__global__ void ew_kernel(int mode, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                          size_t n) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float x = a[i];
-  float r;
-  if (mode == EW_SILU) r = x / (1.f + expf(-x));
-  else if (mode == EW_SIGMOID) r = 1.f / (1.f + expf(-x));
-  else if (mode == EW_SILU_BWD) {                      // a: gradient, b: pre-activation
-    const float z = b[i], s = 1.f / (1.f + expf(-z));
-    r = x * s * (1.f + z * (1.f - s));
-  } else {                                             // a: gradient, b: sigmoid output
-    const float s = b[i];
-    r = x * s * (1.f - s);
-  }
-  out[i] = r;
-}
-// db[j] = sum_i dy[i*stride + j]
-__global__ void colsum_strided_kernel(const float* __restrict__ dy, float* __restrict__ db, int n, int c, int stride) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= c) return;
-  float t = 0.f;
-  for (int i = 0; i < n; ++i) t += dy[(size_t)i * stride + j];
-  db[j] = t;
-}
-
 // wgrad slabs of a channel-padded GEMM [splits][cout_p][taps*cin_p] -> gradient [cout][taps][cin], fixed order
 __global__ void slab_reduce_sub_kernel(const float* __restrict__ slabs, float* __restrict__ out, int cout, int taps,
                                        int cin, int cout_p, int cin_p, int splits) {
@@ -1168,8 +1131,6 @@ inline size_t pool_lds(int C) { return walk_lds(C) / 2; }   // [rif][TW] floats
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -1)
 
 }  // namespace
-
-int spk_eff_stat_blocks(int M, int* rows_per_block) { return walk_rows(M, rows_per_block); }
 
 int spk_launch_col_stats(const bf16_t* x, float* partials, int M, int C, int* blocks, hipStream_t s) {
   int rpb;
@@ -1312,25 +1273,19 @@ int spk_launch_dw_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int 
 
 int spk_se_chunks(int HW) { return HW >= 3136 ? 16 : (HW >= 196 ? 4 : 1); }
 
-// out[n][C] = scale * sum over HW of x (* y)
-int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, float* out, int n, int HW, int C, float scale,
-                         hipStream_t s) {
+// part[n][chunks][C] = per-chunk sums over HW of x (* y); the squeeze-excitation gate kernels sum the chunks themselves
+int spk_launch_pool_rows(const bf16_t* x, const bf16_t* y, float* part, int n, int HW, int C, hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
   hipLaunchKernelGGL(pool_partial_kernel, dim3(n, chunks, walk_ctiles(C)), dim3(256), pool_lds(C), s, x, y, part, HW, C, chunks);
-  if (out)   // (the squeeze-excitation kernels sum the chunks themselves)
-    hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, out, n, chunks, C, scale);
   return LAUNCH_OK();
 }
 
-// a = act(raw*scale + shift) and pooled[n][C] = mean over HW of a (the squeeze of the layer behind)
-int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part,
-                              float* pooled, int n, int HW, int C, int act, hipStream_t s) {
+// a = act(raw*scale + shift) and part[n][chunks][C] = per-chunk sums over HW of a (the squeeze of the layer behind)
+int spk_launch_bna_apply_pool(const bf16_t* raw, const float* scale, const float* shift, bf16_t* out, float* part, int n,
+                              int HW, int C, int act, hipStream_t s) {
   const int chunks = spk_se_chunks(HW);
   hipLaunchKernelGGL(bna_apply_pool_kernel, dim3(n, chunks, walk_ctiles(C)), dim3(256), pool_lds(C), s, raw, scale, shift, out, part,
                      HW, C, act, chunks);
-  if (pooled)
-    hipLaunchKernelGGL(pool_finish_kernel, dim3((n * C + 255) / 256), dim3(256), 0, s, part, pooled, n, chunks, C,
-                       1.f / (float)HW);
   return LAUNCH_OK();
 }
 
@@ -1344,16 +1299,6 @@ int spk_launch_se_bwd_apply(const bf16_t* g, const float* gate, const float* dpo
                             hipStream_t s) {
   hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(grid_of((size_t)n * HW * (C / 8), 256)), dim3(256), 0, s, g, gate, dpool,
                      da, n, HW, C, 1.f / (float)HW);
-  return LAUNCH_OK();
-}
-
-int spk_launch_ew(int mode, const float* a, const float* b, float* out, size_t n, hipStream_t s) {
-  hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, mode, a, b, out, n);
-  return LAUNCH_OK();
-}
-
-int spk_launch_colsum_strided(const float* dy, float* db, int n, int c, int stride, hipStream_t s) {
-  hipLaunchKernelGGL(colsum_strided_kernel, dim3((c + 63) / 64), dim3(64), 0, s, dy, db, n, c, stride);
   return LAUNCH_OK();
 }
 
@@ -1401,7 +1346,7 @@ int spk_se_gate_tiles(int Cl, int S) {
   return (Cl + R - 1) / R;
 }
 
-// part: [n][chunks][C] channel sums of the pooling pass (spk_launch_pool_rows / spk_launch_bna_apply_pool with out = null),
+// part: [n][chunks][C] channel sums of the pooling pass (spk_launch_pool_rows / spk_launch_bna_apply_pool),
 // pooled = scale * their sum is stored for the backward pass
 int spk_launch_se_gate_fwd(const float* part, int chunks, float scale, float* pooled, const float* W1, const float* b1,
                            const float* W2, const float* b2, float* u1, float* h1, float* gate, int n, int C, int Cl, int S,
