@@ -42,6 +42,21 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return act == SPK_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : 1.f;
 }
 
+// two channels at a time: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 issue two lanes' worth of fp32 work per instruction,
+// and the BatchNorm + SiLU passes are as much VALU- as HBM-bound
+typedef __attribute__((ext_vector_type(2))) float f2_t;
+__device__ __forceinline__ f2_t fma2(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2_t act_grad2(f2_t z, int act) {
+  if (act == SPK_ACT_SILU) {
+    const f2_t e = {__expf(-z[0]), __expf(-z[1])};
+    const f2_t d = e + 1.f;
+    const f2_t s = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return s * fma2(z, 1.f - s, (f2_t)1.f);
+  }
+  if (act == SPK_ACT_RELU) return f2_t{z[0] > 0.f ? 1.f : 0.f, z[1] > 0.f ? 1.f : 0.f};
+  return (f2_t)1.f;
+}
+
 // A block owns rows [row0, row1) x the 8-channel groups [cb, ce) of channel tile `ct` of `cts`; a thread owns groups
 // cb + lane_c, cb + lane_c + tpr, ... and walks rows lane_r, lane_r + rif, ...  Wide tensors on few rows (the 7x7 and
 // 14x14 layers: 1152 channels x 6272 rows) are tiled along the channels: without tiles one thread per group walked all
@@ -143,11 +158,13 @@ __global__ __launch_bounds__(256) void bna_bwd_reduce_kernel(
   const int TW = w.tw();
   if (w.active)
     for (int cc = w.cb + w.lane_c; cc < w.ce; cc += w.tpr) {
-      float s1[8], s2[8], sc[8], sh[8], mu[8], is[8];
+      f2_t s1[4], s2[4], sc[4], sh[4], mu[4], is[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s1[j] = s2[j] = 0.f;
-        sc[j] = scale[cc * 8 + j]; sh[j] = shift[cc * 8 + j]; mu[j] = mean[cc * 8 + j]; is[j] = invstd[cc * 8 + j];
+      for (int j = 0; j < 4; ++j) {
+        const int c = cc * 8 + 2 * j;
+        s1[j] = s2[j] = (f2_t)0.f;
+        sc[j] = f2_t{scale[c], scale[c + 1]}; sh[j] = f2_t{shift[c], shift[c + 1]};
+        mu[j] = f2_t{mean[c], mean[c + 1]}; is[j] = f2_t{invstd[c], invstd[c + 1]};
       }
       for (int r = w.row0 + w.lane_r; r < w.row1; r += w.rif) {
         const size_t o = (size_t)r * C + cc * 8;
@@ -156,16 +173,17 @@ __global__ __launch_bounds__(256) void bna_bwd_reduce_kernel(
         unpack8(*(const u32x4_t*)(raw + o), yv);
         const float rs = rowscale ? rowscale[r / HW] : 1.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float dz = gv[j] * rs * act_grad(yv[j] * sc[j] + sh[j], act);
+        for (int j = 0; j < 4; ++j) {
+          const f2_t y2 = {yv[2 * j], yv[2 * j + 1]}, g2 = {gv[2 * j], gv[2 * j + 1]};
+          const f2_t dz = g2 * rs * act_grad2(fma2(y2, sc[j], sh[j]), act);
           s1[j] += dz;
-          s2[j] += dz * (yv[j] - mu[j]) * is[j];
+          s2[j] = fma2(dz, (y2 - mu[j]) * is[j], s2[j]);
         }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        sm[(w.lane_r * 2 + 0) * TW + (cc - w.cb) * 8 + j] = s1[j];
-        sm[(w.lane_r * 2 + 1) * TW + (cc - w.cb) * 8 + j] = s2[j];
+        sm[(w.lane_r * 2 + 0) * TW + (cc - w.cb) * 8 + j] = s1[j >> 1][j & 1];
+        sm[(w.lane_r * 2 + 1) * TW + (cc - w.cb) * 8 + j] = s2[j >> 1][j & 1];
       }
     }
   __syncthreads();
@@ -181,12 +199,14 @@ __global__ __launch_bounds__(256) void bna_bwd_apply_kernel(
   const RowWalk w(M, C, rows_per_block, blockIdx.y, gridDim.y);
   if (!w.active) return;
   for (int cc = w.cb + w.lane_c; cc < w.ce; cc += w.tpr) {
-    float sc[8], sh[8], mu[8], is[8], k0[8], k1[8], k2[8];
+    f2_t sc[4], sh[4], mu[4], is[4], k0[4], k1[4], k2[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = cc * 8 + j;
-      sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
-      k0[j] = coef[c]; k1[j] = coef[C + c]; k2[j] = coef[2 * C + c];
+    for (int j = 0; j < 4; ++j) {
+      const int c = cc * 8 + 2 * j;
+      sc[j] = f2_t{scale[c], scale[c + 1]}; sh[j] = f2_t{shift[c], shift[c + 1]};
+      mu[j] = f2_t{mean[c], mean[c + 1]}; is[j] = f2_t{invstd[c], invstd[c + 1]};
+      k0[j] = f2_t{coef[c], coef[c + 1]}; k1[j] = f2_t{coef[C + c], coef[C + c + 1]};
+      k2[j] = f2_t{coef[2 * C + c], coef[2 * C + c + 1]};
     }
     for (int r = w.row0 + w.lane_r; r < w.row1; r += w.rif) {
       const size_t o = (size_t)r * C + cc * 8;
@@ -206,10 +226,13 @@ __global__ __launch_bounds__(256) void bna_bwd_apply_kernel(
       }
       const float rs = rowscale ? rowscale[r / HW] : 1.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float dz = gv[j] * rs * act_grad(yv[j] * sc[j] + sh[j], act);
-        const float xh = (yv[j] - mu[j]) * is[j];
-        ov[j] = k2[j] * (dz - k0[j] - xh * k1[j]);
+      for (int j = 0; j < 4; ++j) {
+        const f2_t y2 = {yv[2 * j], yv[2 * j + 1]}, g2 = {gv[2 * j], gv[2 * j + 1]};
+        const f2_t dz = g2 * rs * act_grad2(fma2(y2, sc[j], sh[j]), act);
+        const f2_t xh = (y2 - mu[j]) * is[j];
+        const f2_t o2 = k2[j] * (dz - k0[j] - xh * k1[j]);
+        ov[2 * j] = o2[0];
+        ov[2 * j + 1] = o2[1];
       }
       *(u32x4_t*)(dy + o) = pack8(ov);
     }
