@@ -679,16 +679,18 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const bf16_t* __restrict_
   }
 }
 
-// Stride 2, pad (K-1)/2: a thread owns 8 channels x 4 adjacent input pixels (iw0 a multiple of 4, so which (pixel, kw) pairs
-// meet - (u + pad - kw) even - and which of the four dy columns iw0/2 - 1 ... iw0/2 + 2 each pair reads are compile-time):
-// a window row's K weight vectors and 4 dy vectors are loaded once for the 4 pixels.  The gather kernel above re-reads 32
-// bytes of weights and 16 of dy per tap and pixel and is bound by those L1 requests (170-210 us on the 112 x 112 layers).
-// Taps are visited in the gather kernel's order: same sums.
-template <int K>
-__global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ wt,
+// Pad (K-1)/2: a thread owns 8 channels x 4 adjacent input pixels (iw0 a multiple of 4); a window row's K weight vectors
+// and the dy columns the four pixels touch are loaded once.  Stride 2: which (pixel, kw) pairs meet - (u + pad - kw) even -
+// and which of the four dy columns iw0/2 - 1 ... iw0/2 + 2 each pair reads are compile-time.  Stride 1 (only used when the
+// result accumulates into a trunk gradient; otherwise the forward kernel runs on dy): K + 3 columns from iw0 - pad.
+// The gather kernel above re-reads 32 bytes of weights and 16 of dy per tap and pixel and is bound by those L1 requests
+// (170-210 us on the 112 x 112 stride-2 layers, 400 us on B4's accumulating stage-1 layer).  Taps are visited in the
+// gather kernel's order: same sums.
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_px_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ wt,
                                                           bf16_t* __restrict__ dx, int accumulate, int n, int h, int wd,
                                                           int C, int ho, int wo) {
-  constexpr int PAD = (K - 1) / 2, T = (K + 1) / 2, PX = 4;
+  constexpr int PAD = (K - 1) / 2, T = S == 2 ? (K + 1) / 2 : K, PX = 4, COLS = S == 2 ? 4 : K + 3;
   const int c8 = C >> 3, gpr = (wd + PX - 1) / PX;
   const size_t total = (size_t)n * h * gpr * c8;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -697,19 +699,19 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const bf16_t* __restri
     const int iw0 = (int)(g % gpr) * PX, ih = (int)((g / gpr) % h), img = (int)(g / ((size_t)gpr * h));
     const bf16_t* gi = dy + (size_t)img * ho * wo * C + cc * 8;
     const float* wc = wt + cc * 8;
-    const int a0 = ih + PAD, kh0 = a0 & 1, owb = (iw0 >> 1) - 1;
+    const int a0 = ih + PAD, kh0 = S == 2 ? (a0 & 1) : 0, owb = S == 2 ? (iw0 >> 1) - 1 : iw0 - PAD;
     float acc[PX][8];
 #pragma unroll
     for (int u = 0; u < PX; ++u)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[u][j] = 0.f;
     for (int t = 0; t < T; ++t) {
-      const int kh = kh0 + 2 * t, da = a0 - kh;
-      const int oh = da >> 1;
+      const int kh = kh0 + S * t, da = a0 - kh;
+      const int oh = S == 2 ? da >> 1 : da;
       if (kh >= K || da < 0 || oh >= ho) continue;
-      u32x4_t raw[4];
+      u32x4_t raw[COLS];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < COLS; ++c) {
         const int ow = owb + c;
         raw[c] = *(const u32x4_t*)(gi + ((size_t)oh * wo + min(max(ow, 0), wo - 1)) * C);
         if ((unsigned)ow >= (unsigned)wo) raw[c] = u32x4_t{0u, 0u, 0u, 0u};
@@ -720,15 +722,15 @@ __global__ __launch_bounds__(256) void dw_dgrad_s2_kernel(const bf16_t* __restri
         w0[kw] = *(const float4*)(wc + (size_t)(kh * K + kw) * C);
         w1[kw] = *(const float4*)(wc + (size_t)(kh * K + kw) * C + 4);
       }
-      float gv[4][8];
+      float gv[COLS][8];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) unpack8(raw[c], gv[c]);
+      for (int c = 0; c < COLS; ++c) unpack8(raw[c], gv[c]);
 #pragma unroll
       for (int u = 0; u < PX; ++u)
 #pragma unroll
         for (int kw = 0; kw < K; ++kw)
-          if (((u + PAD - kw) & 1) == 0) {
-            const int c = (u + PAD - kw) / 2 + 1;   // compile-time after unrolling: 0 ... 3
+          if (S == 1 || ((u + PAD - kw) & 1) == 0) {
+            const int c = S == 2 ? (u + PAD - kw) / 2 + 1 : u + 2 * PAD - kw;   // compile-time after unrolling
             acc[u][0] += gv[c][0] * w0[kw].x; acc[u][1] += gv[c][1] * w0[kw].y;
             acc[u][2] += gv[c][2] * w0[kw].z; acc[u][3] += gv[c][3] * w0[kw].w;
             acc[u][4] += gv[c][4] * w1[kw].x; acc[u][5] += gv[c][5] * w1[kw].y;
@@ -1341,14 +1343,15 @@ int spk_launch_dw_dgrad(const bf16_t* dy, const float* wt, bf16_t* dx, int accum
 #define DW_DGRAD(K_, S_)                                                                                              \
   hipLaunchKernelGGL((dw_dgrad_kernel<K_, S_>), dim3(grid_of(total, 256)), dim3(256), 0, s, dy, wt, dx, accumulate, n, h, \
                      wd, C, pad, ho, wo)
-  if (stride == 2 && pad == (k - 1) / 2 && (k == 3 || k == 5)) {
-    const size_t items = (size_t)n * h * ((wd + 3) / 4) * (C / 8);
-    if (k == 3)
-      hipLaunchKernelGGL(dw_dgrad_s2_kernel<3>, dim3(grid_of(items, 256)), dim3(256), 0, s, dy, wt, dx, accumulate, n, h, wd,
-                         C, ho, wo);
-    else
-      hipLaunchKernelGGL(dw_dgrad_s2_kernel<5>, dim3(grid_of(items, 256)), dim3(256), 0, s, dy, wt, dx, accumulate, n, h, wd,
-                         C, ho, wo);
+  if ((stride == 1 || stride == 2) && pad == (k - 1) / 2 && (k == 3 || k == 5)) {
+    const dim3 grid(grid_of((size_t)n * h * ((wd + 3) / 4) * (C / 8), 256));
+#define DW_DGRAD_PX(K_, S_)                                                                                             \
+  hipLaunchKernelGGL((dw_dgrad_px_kernel<K_, S_>), grid, dim3(256), 0, s, dy, wt, dx, accumulate, n, h, wd, C, ho, wo)
+    if (k == 3 && stride == 1) DW_DGRAD_PX(3, 1);
+    else if (k == 3) DW_DGRAD_PX(3, 2);
+    else if (stride == 1) DW_DGRAD_PX(5, 1);
+    else DW_DGRAD_PX(5, 2);
+#undef DW_DGRAD_PX
     return LAUNCH_OK();
   }
   if (k == 3 && stride == 1) DW_DGRAD(3, 1);
