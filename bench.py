@@ -59,11 +59,10 @@ def parse():
     return ap.parse_args()
 
 
-# the sources the ResNet inference conv kernels (the roofline's dominant kernel) are built from, and the model code that
-# chooses their precision mode and tiles: the PMC traffic figure is re-taken when any of these changes
-# the sources the ResNet conv KERNELS are built from (not the executor: an EfficientNet / fp8 edit of model.hip no longer
-# stales the ResNet figure); tools/pmc_traffic.py carries the same list
-TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_pw.hip", "conv_c3.hip", "conv_stem.hip", "spk_common.h")
+# the sources the ResNet inference conv kernels (the roofline's dominant kernel) are built from AND the executor that
+# decides which of them run (shortcut fusion, pw / c3 routing, the split rule: all of these change the HBM bytes per
+# launch): the PMC traffic figure is re-taken when any of these changes; tools/pmc_traffic.py carries the same list
+TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_pw.hip", "conv_c3.hip", "conv_stem.hip", "spk_common.h", "model.hip", "model.h")
 CONV_KERNELS = "conv_pw_kernel + conv_c3_kernel + conv_igemm_kernel + conv_stem_kernel"
 
 
@@ -87,7 +86,8 @@ def train_traffic(args):
     return round(rec["traffic_bytes_per_launch"]) if rec.get("kernel_src_sha") == kernel_source_sha(TRAIN_SOURCES) else None
 
 
-TRAIN_SOURCES = ("conv_igemm.hip", "conv_wgrad.hip", "conv_stem.hip", "spk_common.h")
+TRAIN_SOURCES = ("conv_igemm.hip", "conv_wgrad.hip", "conv_stem.hip", "spk_common.h", "train.hip", "train_kernels.hip",
+                 "model.h")
 
 
 def cpu_model():
@@ -161,6 +161,36 @@ def cpu_baseline(network, classes, size, mode, budget_s):
                       f"({iters * bs} images, {dt:.1f} s)"}
 
 
+def device_id_string(dev):
+    """What tells two GPUs apart in the line: the device UUID where torch exposes it, else PCI bus id."""
+    pr = torch.cuda.get_device_properties(dev)
+    uuid = getattr(pr, "uuid", None)
+    if uuid is not None:
+        return str(uuid)
+    return f"{pr.name}/pci{getattr(pr, 'pci_bus_id', '?')}:{getattr(pr, 'pci_device_id', '?')}"
+
+
+def dist_record(dist, dev, rank, world):
+    """Who took part: the line itself shows whether RCCL saw N ranks on N different devices."""
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, device_id_string(dev) if dev.type == "cuda" else "cpu"))
+    return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+            "ranks_seen": [list(t) for t in sorted(seen)],
+            "distinct_devices": len({d for _, d in seen})}
+
+
+def replicas_equal(net, dist):
+    """True iff the sha256 of every rank's parameters is the same (one small object all-gather).  BatchNorm running
+    statistics are left out: they are rank-local between two `dp.sync_buffers` calls by design (local statistics)."""
+    h = hashlib.sha256()
+    for k, v in net.state_dict().items():
+        if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    digests = [None] * dist.get_world_size()
+    dist.all_gather_object(digests, h.hexdigest())
+    return len(set(digests)) == 1
+
+
 def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     """Times K steps of one mode; returns the result dict on rank 0."""
     if mode == "train":
@@ -173,11 +203,16 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
             {"params": [p for p in net.parameters()], "lr": 1e-4}, {"params": [], "lr": 0.0},
             {"params": [], "lr": 0.0}])
         sync = GradSync(net, dist) if world > 1 else None
+        ar_marks = []   # (before, after) events around the gradient exchange of every step
 
         def step():
             net.forward_backward(x, y)
             if sync:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 sync.all_reduce(opt)
+                e1.record()
+                ar_marks.append((e0, e1))
             opt.step()
         dtype = "bf16"
     else:
@@ -209,6 +244,18 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)  # noqa: E731
     step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3)}
+    dist_rec = None
+    if dist is not None:
+        dist_rec = dist_record(dist, dev, rank, world)
+        if mode == "train":
+            ar = sorted(a.elapsed_time(b) for a, b in ar_marks[-args.steps:])
+            dist_rec.update({
+                "allreduce_bytes": int(sync.flat.numel() * sync.flat.element_size()),
+                # time the launch stream spends in the exchange (overlapped: only the wait for slices still in flight)
+                "allreduce_ms": round(ar[len(ar) // 2], 3) if ar else None,
+                "overlap": sync.overlapped,
+                # every replica must hold bit-identical parameters after the timed steps
+                "params_equal": replicas_equal(net, dist)})
     if mode == "train" and sync:
         sync.close()   # the per-phase profile below runs on rank 0 alone: no collectives from here on
     if dist is not None:
@@ -262,6 +309,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
         roof["step_frac"] = round(roof["step_achieved"] / MFMA_PEAK_TFLOPS, 4)
         roof["streams"] = int(os.environ.get("SPK_EVAL_STREAMS", "2")) if args.batch >= 64 else 1
         if args.network.startswith("efficientnet"):
+            streams = roof["streams"]
             # EfficientNet: 2/3 of the time is depthwise / squeeze-excitation / padded 1x1 passes that move bytes:
             # the bound is HBM, over all kernels of the forward
             all_by = sum(by for _, _, _, by in layers)
@@ -271,6 +319,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
                     "traffic": None, "launches": len(layers), "avg_launch_us": round(all_ms * 1e3 / len(layers), 2),
                     "algorithmic_bytes_per_launch": round(all_by / len(layers)),
                     "all_kernels_ms_per_step": round(all_ms, 3),
+                    "streams": streams,
                     "conv1x1_tflops": round(sum(fl for n, _, fl, _ in conv if ".block." in n or n.endswith("8.0")) / 1e12 /
                                             max(sum(ms for n, ms, _, _ in conv) * 1e-3, 1e-9), 1)}
         # HBM bytes per launch: PMC counters cannot be read from inside this process; the figure comes from the
@@ -282,6 +331,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
             if rec.get("kernel_src_sha") == kernel_source_sha():
                 roof["traffic"] = round(rec["traffic_bytes_per_launch"])
                 roof["traffic_source"] = str(cands[-1].relative_to(ROOT))
+                roof["traffic_taken_at"] = rec.get("taken_at")
             else:
                 roof["traffic_source"] = f"{cands[-1].name} is stale (taken on other kernel sources): not quoted"
         table = [{"layer": n, "ms": round(ms, 4), "gflop": round(fl / 1e9, 3), "mbytes": round(by / 1e6, 2),
@@ -307,6 +357,8 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
                    "parallelism": f"dp{world}"},
         "roofline": roof,
     }
+    if dist_rec is not None:
+        out["dist"] = dist_rec
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.network, args.classes, args.size, mode,
                                            args.cpu_seconds if mode == "infer" else args.cpu_seconds / 2)
@@ -382,6 +434,7 @@ def main():
     if args.network.startswith("efficientnet") and args.mode == "both":
         modes = ["infer"]   # BASELINE config 5 is an inference config; `--mode train` measures the MBConv training step
     results = []
+    failed = False
     for m in modes:
         if rank == 0:
             print(f"[bench] {m}: {args.warmup} warm-up + {args.steps} timed steps", file=sys.stderr, flush=True)
@@ -393,6 +446,7 @@ def main():
                 print(f"[bench] train leg failed: {exc!r}", file=sys.stderr, flush=True)
                 results.append({"metric": f"IFCB images/sec, {args.network} {args.size}x{args.size} train step", "value": None,
                                 "error": repr(exc)})
+                failed = True
             continue
         results.append(run_mode(m, args, net, x, y, dist, dev, rank, world))
     if rank == 0:
@@ -400,12 +454,14 @@ def main():
         if len(results) > 1:
             t = results[1]
             out["train"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
-                                              "error") if k in t}
+                                              "dist", "error") if k in t}
             if "cpu_baseline" in t:
                 out["train"]["cpu_baseline"] = t["cpu_baseline"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if failed:      # the headline line is out; the run still counts as failed
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -631,11 +631,8 @@ int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   const int kt = a.K / BKT;
   const size_t lds = DMA == 3 ? lds_full : (kt < stages ? kt : stages) * stage;  // hybrid: both stages are written
   auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA, PERSIST, BKT>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr;
+  (void)spk_lds_limit_once(attr, (const void*)k, (int)lds_full);
   int grid = m_tiles * n_tiles;
   if (PERSIST == 1) {
     // persistent: as many blocks as stay resident (LDS-limited, at most 4 per CU)

@@ -437,12 +437,10 @@ int launch_k(const PwConvArgs& a, hipStream_t s) {
   auto k = dual ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false, true>
                 : (a.res ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true>
                          : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false>);
-  static bool attr[3] = {false, false, false};
-  const int which = dual ? 2 : (a.res != nullptr);
-  if (!attr[which]) {
-    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
-    attr[which] = true;
-  }
+  // hipFuncSetAttribute applies to the CURRENT device only: one bit per (kernel flavour, device), so that a process
+  // holding models on several GPUs raises the dynamic-LDS limit on each of them (devices >= 64: set on every launch)
+  static std::atomic<unsigned long long> attr[3];
+  if (!spk_lds_limit_once(attr[dual ? 2 : (a.res != nullptr)], (const void*)k, 160 * 1024)) return -1;
   int grid;
   if (RESIDENT) {
     // persistent: as many blocks as stay resident, a multiple of 8 * n_tiles
@@ -642,8 +640,10 @@ int spk_conv1x1_launch(const ConvArgs& a, const PwConvArgs& q, hipStream_t s) {
               q.stride, q.nb, q.res != nullptr, choice < 0 ? "igemm" : "pw", choice, best * 1000.f / 3.f);
   }
   if (choice >= 0) {
-    const int r = spk_pw_launch(q, choice, s);
-    if (r != -3) return r;
+    // any failure of the chosen configuration (it does not fit this shape, or its launch was refused on this
+    // device) falls back to the implicit GEMM, which gives the same bits
+    if (spk_pw_launch(q, choice, s) == 0) return 0;
+    (void)hipGetLastError();
   }
   return spk_conv_launch(a, CONV_MODE_GENERIC, s, nullptr);
 }

@@ -329,11 +329,8 @@ int launch(const ConvArgs& a, hipStream_t s, int* m_tiles_out) {
     grid = n_tiles;
   }
   auto k = conv_stem_kernel<DT, SPLITW, POOL>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr;
+  (void)spk_lds_limit_once(attr, (const void*)k, (int)lds);
   if (m_tiles_out) *m_tiles_out = grid;
   hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, a, tiles_x, tiles_y, n_tiles);
   return hipGetLastError() == hipSuccess ? 0 : -1;

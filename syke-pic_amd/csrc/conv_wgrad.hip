@@ -242,11 +242,8 @@ int launch_nb(const WgradArgs& a, int splits, hipStream_t s) {
   const int k_tiles = (a.Ktot + BCI - 1) / BCI;
   const size_t lds = NBUF * (size_t)64 * (BCO + BCI) * 2;
   auto k = conv_wgrad_kernel<BCO, BCI, STEM, NBUF>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr;
+  (void)spk_lds_limit_once(attr, (const void*)k, (int)lds);
   hipLaunchKernelGGL(k, dim3(co_tiles * k_tiles, splits), dim3(256), lds, s, a, co_tiles);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -249,11 +249,8 @@ bool dw_plan(int et, int n, int wid, int c_p, int ho, int wo, int k, int s, DwPl
 template <int ET, int K, int S>
 int launch_dw(const DwArgs& a, const DwPlan& p, int n, hipStream_t s) {
   auto k = dwconv_lds_kernel<ET, K, S>;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr;
+  (void)spk_lds_limit_once(attr, (const void*)k, 64 * 1024);
   hipLaunchKernelGGL(k, dim3(p.ctiles, n * p.bands), dim3(256), p.lds, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -567,6 +567,10 @@ int spk_commit(spk_model* m) {
       (void)hipFree(wcat);
     }
   }
+  // new precision settings mean new tuner keys (nb, shortcut flags) for the same shapes: the next forward of every
+  // shape runs on ONE stream again so that candidates are timed on a quiet GPU
+  if (m->packed_dt != m->infer_dt || m->packed_split != (int)m->splitw || m->packed_epoch != m->split_epoch)
+    m->half_warm.clear();
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
   m->packed_epoch = m->split_epoch;
@@ -721,10 +725,13 @@ static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int spk_plan(spk_model* m, int n, int h, int w, bool pad) {
   // pad: the training layout of the EfficientNet graphs (channels of every conv output rounded up to 64, zeros in the
-  // pad); the eval kernels work on the tensors' own widths, so switching between the two re-plans
+  // pad); the eval kernels work on the tensors' own widths.  Switching between the two only re-addresses the arena
+  // (tensor dims and offsets) as long as the new layout fits the allocation - the per-epoch train -> validate -> train
+  // switches of `sykepic train` used to free and re-allocate the whole arena twice per epoch.
   if (n <= m->cap_n && h == m->cap_h && w == m->cap_w && pad == m->plan_pad) return SPK_OK;
   HIP_TRY(hipStreamSynchronize(m->stream));
-  free_acts(m);
+  const bool same_shape = n <= m->cap_n && h == m->cap_h && w == m->cap_w;
+  if (same_shape) n = m->cap_n;   // keep the capacity
   m->tdims.assign(m->n_tensors, TDim());
   const int wp = (w + 1) & ~1;
   m->tdims[0] = {h, wp, 4, true};
@@ -741,9 +748,11 @@ int spk_plan(spk_model* m, int n, int h, int w, bool pad) {
         o.c = pad ? (L.d.cout + 63) / 64 * 64 : L.d.cout;
         o.c_log = L.d.cout;
         o.bf16 = true;
-        if (o.h < 1 || o.w < 1) return fail(SPK_ERR_ARG, "image too small for the network");
-        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && (in.c_log > 0 ? in.c_log : in.c) != L.d.cin)
+        if (o.h < 1 || o.w < 1) { m->cap_n = 0; return fail(SPK_ERR_ARG, "image too small for the network"); }
+        if (L.d.kind != SPK_OP_MAXPOOL && L.d.src != 0 && (in.c_log > 0 ? in.c_log : in.c) != L.d.cin) {
+          m->cap_n = 0;
           return fail(SPK_ERR_ARG, std::string("channel mismatch at ") + L.d.name);
+        }
         break;
       }
       case SPK_OP_GAVGPOOL: o = {1, 1, in.c, false}; break;
@@ -776,22 +785,23 @@ int spk_plan(spk_model* m, int n, int h, int w, bool pad) {
       total += align256((size_t)d.h * d.w * d.c * 2 * n);
     }
   }
-  // squeeze-excitation scratch: pooled partial sums [n][chunks][c] + scales [n][c], largest layer
+  // squeeze-excitation scratch: pool partials [n][chunks][c] of whichever depthwise kernel runs (chunks <= 64 for all
+  // of them), scales [n][c], hidden units [n][squeeze]; largest layer
   size_t se_floats = 0;
   for (const Layer& L : m->layers) {
     if (L.d.kind != SPK_OP_SE) continue;
     const TDim& d = m->tdims[L.d.src];
-    // partials [n][chunks][c] (chunks(1) >= chunks(nb)), scales [n][c], hidden units [n][squeeze]
-    // pool partials [n][chunks][c] of whichever depthwise kernel runs (chunks <= 64 for all of them), scales [n][c],
-    // hidden units [n][squeeze]
     se_floats = std::max(se_floats, (size_t)n * ((64 + 1) * d.c + L.d.k));
   }
   m->se_off = total;
   total += align256(se_floats * 4);
   m->logits_off = total;
   total += align256((size_t)n * m->num_classes * 4);
-  HIP_TRY(hipMalloc((void**)&m->arena, total));
-  m->arena_bytes = total;
+  if (!(same_shape && m->arena && total <= m->arena_bytes)) {
+    free_acts(m);
+    HIP_TRY(hipMalloc((void**)&m->arena, total));
+    m->arena_bytes = total;
+  }
   m->cap_n = n;
   m->plan_pad = pad;
   m->cap_h = h;

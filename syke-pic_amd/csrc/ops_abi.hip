@@ -209,6 +209,9 @@ extern "C" int spk_op_conv1x1(const void* x, const float* w, const float* bn_sca
   if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
   hipStream_t s = (hipStream_t)stream;
   const int ho = (h - 1) / stride + 1, wo = (wd - 1) / stride + 1, M = n * ho * wo;
+  // 32-bit buffer offsets in both kernels: every operand below 2 GiB (the model executor micro-batches for this)
+  if ((size_t)n * h * wd * cin * 2 >= 0x80000000ull || (size_t)n * ho * wo * cout * 2 >= 0x80000000ull)
+    return ofail(SPK_ERR_UNSUPPORTED, "op_conv1x1: an operand of 2 GiB or more (split the batch)");
   Scratch sc;
   bf16_t* wp = sc.get<bf16_t>((size_t)2 * cout * cin);
   if (!wp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
@@ -253,6 +256,8 @@ extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* b
   if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
   hipStream_t s = (hipStream_t)stream;
   const int M = n * h * wd;
+  if ((size_t)n * h * wd * cin * 2 >= 0x80000000ull || (size_t)n * h * wd * cout * 2 >= 0x80000000ull)
+    return ofail(SPK_ERR_UNSUPPORTED, "op_conv3x3: an operand of 2 GiB or more (split the batch)");
   Scratch sc;
   bf16_t* wp = sc.get<bf16_t>((size_t)2 * cout * 9 * cin);
   if (!wp) return ofail(SPK_ERR_HIP, "hipMalloc failed");

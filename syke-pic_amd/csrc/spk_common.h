@@ -4,6 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
+
+// Raises a kernel's dynamic-LDS limit once per DEVICE (hipFuncSetAttribute applies to the current device only; a
+// process may hold model handles on several GPUs).  `mask`: one function-local static per kernel instantiation, one bit
+// per device; devices >= 64 set the attribute on every launch.  Returns false when the runtime refuses.
+static inline bool spk_lds_limit_once(std::atomic<unsigned long long>& mask, const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  const unsigned long long bit = dev >= 0 && dev < 64 ? 1ull << dev : 0ull;
+  if (mask.load(std::memory_order_acquire) & bit) return true;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  mask.fetch_or(bit, std::memory_order_release);
+  return true;
+}
 
 typedef unsigned short bf16_t;  // storage type of a bfloat16 value
 

@@ -122,6 +122,11 @@ class GradSync:
         self._cb = lib.GRAD_READY_FN(ready)   # keep the ctypes thunk alive as long as the handle may call it
         self.net.set_grad_ready_callback(self._cb, self._comm.cuda_stream, buckets)
 
+    @property
+    def overlapped(self):
+        """True while the slices are reduced underneath the backward pass (the library calls back per slice)."""
+        return self._cb is not None
+
     def close(self):
         if self._cb is not None:
             self.net.set_grad_ready_callback(None, 0, 0)

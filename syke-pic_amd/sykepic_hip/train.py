@@ -24,7 +24,7 @@ from pathlib import Path
 import torch
 
 from . import data, schedule
-from .config import get_img_shape, get_network, get_transforms
+from .config import Settings, get_network, get_transforms
 from . import dp
 from .dp import GradSync
 from .optim import HipOptimizer
@@ -34,9 +34,24 @@ def _dist():
     return dp.init_from_env()
 
 
+def _check_split(split):
+    """`[dataset] split` = fractions for train, validation and (optionally) test; the reference's two complaints."""
+    if sum(split) != 1.0:
+        raise ValueError(f"Dataset split does not add up to 1.0. Got {sum(split)}")
+    if len(split) < 2:
+        raise ValueError("Dataset split needs to cover at least train and validation")
+    return len(split) == 3
+
+
+def _png_path(name):
+    out = Path(name)
+    return out if out.suffix else out.with_suffix(".png")
+
+
 def main(args):
     config = ConfigParser()
     config.read(args.config)
+    cfg = Settings(config)          # config.KEYS: every key of train.ini, parsed on first use
     if not os.environ.get("SYKEPIC_HOST_TRANSFORMS"):
         # the helper process the PNG decode workers are forked from: up before RCCL / HIP exist in this process
         from . import gpu_augment
@@ -44,130 +59,96 @@ def main(args):
     dist, rank, world, local = _dist()
     chief = rank == 0
 
-    # [dataset]
-    dataset = Path(config.get("dataset", "path"))
-    split = tuple(float(i) for i in config.get("dataset", "split").split(","))
-    if (s := sum(split)) != 1.0:
-        raise ValueError(f"Dataset split does not add up to 1.0. Got {s}")
-    if len(split) < 2:
-        raise ValueError("Dataset split needs to cover at least train and validation")
-    test_split = len(split) == 3
-    min_N = config.get("dataset", "min_N")
-    min_N = int(min_N) if min_N else None
-    max_N = config.get("dataset", "max_N")
-    max_N = int(max_N) if max_N else None
-    exclude = [name.strip() for name in config.get("dataset", "exclude").split(",")]
-    random_seed = config.getint("dataset", "random_seed")
-    model_data = data.ModelData(dataset, split, min_N, max_N, exclude, random_seed)
+    ds, im, mo, tr = cfg.dataset, cfg.image, cfg.model, cfg.train
+    split, seed = ds.split, ds.random_seed
+    test_split = _check_split(split)
+    model_data = data.ModelData(ds.path, split, ds.min_N, ds.max_N, ds.exclude, seed)
 
+    # side outputs of the CLI that end the run before any training (`--save-images` only copies)
     if getattr(args, "save_images", None):
-        root = Path(args.save_images)
-        for name, paths in (("train", model_data.train_x), ("val", model_data.val_x),
-                            ("test", model_data.test_x if test_split else [])):
+        parts = {"train": model_data.train_x, "val": model_data.val_x, "test": model_data.test_x if test_split else []}
+        for name, paths in parts.items():
             if paths:
-                (root / name).mkdir(exist_ok=True, parents=True)
+                (Path(args.save_images) / name).mkdir(exist_ok=True, parents=True)
                 for p in paths:
-                    shutil.copy(p, root / name / p.name)
+                    shutil.copy(p, Path(args.save_images) / name / p.name)
     if getattr(args, "dist", None):
         from . import plots
-        out_file = Path(args.dist)
-        out_file = out_file if out_file.suffix else out_file.with_suffix(".png")
-        plots.dataset_distribution(model_data, out_file)
-        print(f"[INFO] Distribution plot saved to {out_file}")
+        plots.dataset_distribution(model_data, _png_path(args.dist))
+        print(f"[INFO] Distribution plot saved to {_png_path(args.dist)}")
         return
 
-    if oversample_until := config.get("dataset", "oversample_until", fallback=""):
-        model_data.oversample(int(oversample_until), None)
-    elif oversample_with_decay := config.get("dataset", "oversample_with_decay", fallback=""):
-        model_data.oversample(None, float(oversample_with_decay))
+    if (until := ds.oversample_until) is not None:
+        model_data.oversample(until, None)
+    elif (decay := ds.oversample_with_decay) is not None:
+        model_data.oversample(None, decay)
 
-    # [image]
-    img_shape = get_img_shape(config)
-    batch_size = config.getint("image", "batch_size")
-    num_workers = config.getint("image", "num_workers")
+    img_shape = im.shape
     train_transform, eval_transform = get_transforms(config, img_shape)
     if getattr(args, "collage", None):
         from . import plots
-        height, width, out_file = int(args.collage[0]), int(args.collage[1]), Path(args.collage[2])
-        model_data.set_data_loaders(height * width, num_workers, train_transform, eval_transform, img_shape[0])
-        out_file = out_file if out_file.suffix else out_file.with_suffix(".png")
-        plots.view_batch(model_data.train_loader, height, width, out_file)
-        print(f"[INFO] Image collage saved to {out_file}")
+        rows, cols = int(args.collage[0]), int(args.collage[1])
+        model_data.set_data_loaders(rows * cols, im.num_workers, train_transform, eval_transform, img_shape[0])
+        plots.view_batch(model_data.train_loader, rows, cols, _png_path(args.collage[2]))
+        print(f"[INFO] Image collage saved to {_png_path(args.collage[2])}")
         return
     # transforms run batched on the GPU where the pipeline allows it (SYKEPIC_HOST_TRANSFORMS=1: host workers)
     gpu_tf = None if os.environ.get("SYKEPIC_HOST_TRANSFORMS") else torch.device("cuda", local)
-    model_data.set_data_loaders(batch_size, num_workers, train_transform, eval_transform, img_shape[0],
+    model_data.set_data_loaders(im.batch_size, im.num_workers, train_transform, eval_transform, img_shape[0],
                                 rank=rank, world=world, device=gpu_tf)
     num_classes = len(model_data.le.classes_)
-    external_test = config.get("dataset", "external_test", fallback="")
+    external_test = ds.external_test
     if external_test:
         extra_loader = data.extra_eval_dataloader(external_test, model_data, exclude=["Unclassified"])
 
-    # [model]
-    model_network = config.get("model", "network")
-    model_id = config.get("model", "id")
-    model_dir = Path(config.get("model", "path"))
+    # model directory <path>/<network>[_<id>]; id "auto" = next free number, picked by rank 0 for the whole job
+    # (another rank could already see the directory rank 0 has just made)
+    model_id = mo.id
     if model_id == "auto":
-        # one id for the whole job: rank 0 picks it (another rank could see the directory rank 0 has just made)
-        model_id = dp.broadcast_object(data.auto_id(model_network, model_dir) if chief else None, dist)
-    model_name = model_network + (f"_{model_id}" if model_id else "")
-    model_dir = model_dir / model_name
+        model_id = dp.broadcast_object(data.auto_id(mo.network, mo.path) if chief else None, dist)
+    model_dir = mo.path / (mo.network + (f"_{model_id}" if model_id else ""))
     if chief:
-        model_dir.mkdir(parents=True, exist_ok=config.getboolean("model", "exist_ok"))
+        model_dir.mkdir(parents=True, exist_ok=mo.exist_ok)
         model_data.save(model_dir)
         shutil.copy(args.config, model_dir / "config.ini")
     if dist is not None:
         dist.barrier()
 
-    # [train]
-    if not config.getboolean("train", "gpu"):
+    if not tr.gpu:
         raise RuntimeError("this build trains on the MI355X only; for `gpu = no` use the reference itself")
     device = torch.device("cuda", local)
-    max_epochs = config.getint("train", "max_epochs")
-    early_stop_patience = config.getint("train", "early_stop_patience")
-    lr = config.getfloat("train", "learning_rate")
-    optimizer_name = config.get("train", "optimizer")
-
     net = get_network(config, num_classes, device=device)
     # Dropout masks are a function of (seed, step, layer): give every rank its own stream, otherwise the j-th sample of
     # every shard draws the same mask at every step.  A run stays deterministic for a given random_seed and world size.
-    net.set_seed(random_seed * world + rank)
+    net.set_seed(seed * world + rank)
     dp.broadcast_state(net, dist)   # every replica starts from rank 0's (random / pretrained) tensors
     schedule.freeze(net.base)
     initial = [p for p in net.parameters() if p.requires_grad]
-    optimizer = HipOptimizer(net, optimizer_name, [{"params": initial, "lr": lr},
-                                                   {"params": [], "lr": 0.0}, {"params": [], "lr": 0.0}])
+    optimizer = HipOptimizer(net, tr.optimizer, [{"params": initial, "lr": tr.learning_rate},
+                                                 {"params": [], "lr": 0.0}, {"params": [], "lr": 0.0}])
     if chief:
         print("---- Network Head ----")
         print(net.head)
 
-    lr_warmup = None
-    if config.getboolean("lr_warmup", "use"):
-        lr_warmup = schedule.LRWarmup(
-            net, optimizer, config.getfloat("lr_warmup", "factor_1"), config.getfloat("lr_warmup", "factor_2"),
-            config.getint("lr_warmup", "step_1"), config.getint("lr_warmup", "step_2"),
-            config.getint("lr_warmup", "step_3"), config.getboolean("lr_warmup", "verbose") and chief)
-    lr_scheduler = None
-    if config.getboolean("lr_reduction", "use"):
+    lr_warmup = lr_scheduler = None
+    if (wu := cfg.lr_warmup).use:
+        lr_warmup = schedule.LRWarmup(net, optimizer, wu.factor_1, wu.factor_2, wu.step_1, wu.step_2, wu.step_3,
+                                      wu.verbose and chief)
+    if (red := cfg.lr_reduction).use:
         # quirk Q3: the reference passes `verbose` positionally into `threshold`
-        lr_scheduler = schedule.ReduceLROnPlateau(
-            optimizer, "min", config.getfloat("lr_reduction", "factor"), config.getint("lr_reduction", "patience"),
-            config.getboolean("lr_reduction", "verbose"))
+        lr_scheduler = schedule.ReduceLROnPlateau(optimizer, "min", red.factor, red.patience, red.verbose)
 
-    best_state = train_net(net, model_data.train_loader, model_data.val_loader, optimizer, None, max_epochs,
-                           early_stop_patience, model_dir, device, lr_scheduler, lr_warmup, dist=dist)
+    best_state = train_net(net, model_data.train_loader, model_data.val_loader, optimizer, None, tr.max_epochs,
+                           tr.early_stop_patience, model_dir, device, lr_scheduler, lr_warmup, dist=dist)
     if dist is not None:
         dist.barrier()
     net.load_state_dict(torch.load(best_state, map_location="cpu"))
-    if chief and test_split:
-        report = test_net(net, model_data.test_loader, model_data.le.classes_, device)
+    tests = ([(None, model_data.test_loader)] if test_split else []) + \
+            ([(Path(external_test).name, extra_loader)] if external_test else [])
+    for name, loader in tests if chief else []:
+        report = test_net(net, loader, model_data.le.classes_, device, test_name=name)
         print(report)
-        (model_dir / "test_report.txt").write_text(report)
-    if chief and external_test:
-        name = Path(external_test).name
-        report = test_net(net, extra_loader, model_data.le.classes_, device, test_name=name)
-        print(report)
-        (model_dir / f"test_report_{name}.txt").write_text(report)
+        (model_dir / (f"test_report_{name}.txt" if name else "test_report.txt")).write_text(report)
 
 
 def train_net(net, train_dataloader, val_dataloader, optimizer, loss_fn, max_epochs, early_stop_patience,

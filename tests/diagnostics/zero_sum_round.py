@@ -1,0 +1,180 @@
+"""Data-free zero-sum weight rounding: how many of the hi+lo split layers does it free?
+
+fp16(w) = w - dw loses sum_k dw_ok x_k per output.  Most of that error is its MEAN over the data, sum_k dw_ok E[x_k]
+(folding the calibrated mean into the BatchNorm shift took the plain fp16 mode from 1.50e-3 to 7.6e-4).
+Here the mean is removed WITHOUT data: every cout row is rounded to nearest, and then the few weights closest to a
+rounding midpoint are rounded the other way until sum_k mu_k dw_ok is within half an ulp of zero - the squared rounding
+error of the row barely changes (a flipped weight was ~0.5 ulp off either way), its weighted sum vanishes.
+mu_k: 'uniform' (all ones), 'bn' (rectified-Gaussian mean of the producer's BatchNorm output where the input IS
+ReLU(BN(.)), uniform elsewhere), 'calib' (per-channel means of the fp32 oracle on 16 images: the upper bound).
+
+The rounded weights are loaded as the model's weights (they are exactly representable in fp16, so the library's own
+packing is exact) and the probabilities are compared with the fp32 oracle holding the ORIGINAL weights.
+Run with SPK_FUSE_DS=0 (the fused shortcut conv rounds scale-folded weights, which the host cannot pre-round).
+"""
+import math
+import os
+import sys
+from pathlib import Path
+os.environ.setdefault("SPK_FUSE_DS", "0")
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
+import numpy as np, torch
+from oracle import refnet, graph_eval
+from sykepic_hip import arch, synth
+from sykepic_hip.net import HipNet
+torch.set_num_threads(16)
+network = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
+hw = int(sys.argv[2]) if len(sys.argv) > 2 else 224
+n_img = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+seeds = [int(s) for s in sys.argv[4].split(",")] if len(sys.argv) > 4 else [-2, 2, 7]
+g = arch.build_graph(network, 50)
+convs = [op for op in g.ops if op.kind == arch.OP_CONV]
+gold = np.load(ROOT / "tests/golden/net_pass.npz")
+
+
+def zero_sum_round_taps(w, mu):
+    """zero-sum separately for every filter tap (the cin slice of one (kh, kw)): a border pixel, which sees only some
+    of the taps, keeps the cancellation"""
+    co, ci, kh, kw = w.shape
+    if kh * kw == 1 or ci < 32:
+        return zero_sum_round(w, mu)
+    w2 = np.ascontiguousarray(w.transpose(0, 2, 3, 1)).reshape(co * kh * kw, ci, 1, 1)
+    q = zero_sum_round(w2, mu)
+    return np.ascontiguousarray(q.reshape(co, kh, kw, ci).transpose(0, 3, 1, 2))
+
+
+def zero_sum_round(w, mu):
+    """w [cout, cin, kh, kw] fp32, mu [cin] -> fp32 values exactly representable in fp16, each within one fp16 ulp of w,
+    with |sum_k mu_k (q_k - w_k)| minimised greedily by re-rounding the weights nearest a midpoint."""
+    co = w.shape[0]
+    w2 = w.reshape(co, -1).astype(np.float64)
+    m2 = np.broadcast_to(mu[None, :, None, None], w.shape).reshape(co, -1).astype(np.float64)
+    q = w2.astype(np.float16).astype(np.float64)
+    up = np.nextafter(q.astype(np.float16), np.float16(np.inf)).astype(np.float64)
+    dn = np.nextafter(q.astype(np.float16), np.float16(-np.inf)).astype(np.float64)
+    d = q - w2                                   # rounding error of round-to-nearest
+    alt = np.where(d > 0, dn, up)                # the other neighbour
+    alt = np.where(d == 0, q, alt)
+    dalt = alt - w2
+    cost = dalt ** 2 - d ** 2                    # added squared error of the flip (>= 0)
+    step = m2 * (dalt - d)                       # change of the weighted sum
+    out = q.copy()
+    for r in range(co):
+        S = float((m2[r] * d[r]).sum())
+        st, cs = step[r], cost[r]
+        free = np.ones(st.shape, bool)
+        for _ in range(200):
+            # candidates: flips that move S towards zero without overshooting past -S
+            ok = free & (st * S < 0) & (np.abs(st) < 2 * abs(S))
+            if not ok.any():
+                break
+            gain = abs(S) - np.abs(S + st)
+            score = np.where(ok, cs / np.maximum(gain, 1e-300), np.inf)
+            k = int(np.argmin(score))
+            out[r, k] = alt[r, k]
+            S += st[k]
+            free[k] = False
+    return out.reshape(w.shape).astype(np.float32)
+
+
+def rect_gauss_mean(gamma, beta):
+    """E[ReLU(z)] for z ~ N(beta, gamma^2): what a BatchNorm + ReLU output averages to on the data it was fitted to."""
+    s = np.abs(gamma) + 1e-12
+    t = beta / s
+    phi = np.exp(-0.5 * t * t) / math.sqrt(2 * math.pi)
+    Phi = 0.5 * (1 + np.vectorize(math.erf)(t / math.sqrt(2)))
+    return beta * Phi + s * phi
+
+
+def producer_means(sd):
+    """mu per conv input tensor id from the BatchNorm parameters of the conv that wrote it (mid tensors only)."""
+    by_dst = {op.dst: op for op in convs}
+    out = {}
+    for op in convs:
+        p = by_dst.get(op.src)
+        if p is not None and p.res < 0 and p.relu == 1:
+            out[op.name] = rect_gauss_mean(np.asarray(sd[p.bn + ".weight"], np.float64), np.asarray(sd[p.bn + ".bias"], np.float64))
+    return out
+
+
+def shifted(x, kind):
+    """test images from ANOTHER distribution than the calibration batch"""
+    if kind == "same":
+        return x
+    if kind == "inverted":
+        return (1.0 - x).contiguous()
+    if kind == "lowcontrast":
+        return (torch.round((0.5 * x + 0.25) * 255) / 255).contiguous()
+    if kind == "ifcb":   # light grey background, one small dark blob per image, three identical channels
+        n, _, h, w = x.shape
+        g = 0.8 + 0.1 * (x[:, :1] - 0.5)
+        yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        for i in range(n):
+            cy, cx, r = 40 + (37 * i) % (h - 80), 40 + (53 * i) % (w - 80), 12 + (i % 5) * 6
+            g[i, 0][(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] *= 0.35
+        return (torch.round(g.expand(n, 3, h, w) * 255) / 255).contiguous()
+    raise ValueError(kind)
+
+
+for wseed in seeds:
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=abs(wseed))
+    if wseed < 0:
+        last = [k for k in sd if k.startswith("head.") and k.endswith(".bias")][-1]
+        sd[last] = sd[last] + gold[f"{network}_{hw}_bias_adj"]
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    ref = refnet.load_numpy_state(refnet.RefNet(network, 50), sd)
+    xcal = torch.from_numpy(synth.synth_images(16, 3, hw, hw, seed=9000))
+    with torch.no_grad():
+        acts = graph_eval.run(g, tsd, xcal)
+    calib = {op.name: acts[op.src].mean((0, 2, 3)).numpy().astype(np.float64) for op in convs}
+    del acts
+    ops = {op.name: op for op in convs}
+
+    def rounded(fn, only=None):
+        out = dict(sd)
+        for op in convs:
+            if only is not None and op.name not in only:
+                continue
+            w = np.asarray(sd[op.name + ".weight"], np.float32)
+            out[op.name + ".weight"] = fn(w, calib[op.name])
+        return out
+
+    names = [op.name for op in convs]
+    inner3 = {n for n in names if ops[n].k == 3 and ops[n].res < 0 and n != "base.0" and "downsample" not in n}
+    states = {"orig": sd, "row": rounded(zero_sum_round), "tap": rounded(zero_sum_round_taps),
+              "tap-not-stem": rounded(zero_sum_round_taps, set(names) - {"base.0"}),
+              "tap-inner3x3": rounded(zero_sum_round_taps, inner3)}
+    nets = {}
+    for tag, state in states.items():
+        net = HipNet(network, 50, weights=None)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        net.eval()
+        nets[tag] = net
+    cases = {"plain fp16 (nearest)": ("orig", set()), "zero-sum per row, no split": ("row", set()),
+             "zero-sum per tap, no split": ("tap", set()), "zero-sum per tap, stem split": ("tap-not-stem", {"base.0"}),
+             "mode 3 + zero-sum on its 16 unsplit convs": ("tap-inner3x3", set(names) - inner3),
+             "library default (mode 3)": ("orig", None), "every conv split": ("orig", set(names))}
+    for kind in ("same", "inverted", "lowcontrast", "ifcb"):
+        worst = {k: [] for k in cases}
+        rms = {k: [] for k in cases}
+        flips = {k: 0 for k in cases}
+        for s in range(n_img // 32):
+            x = shifted(torch.from_numpy(synth.synth_images(32, 3, hw, hw, seed=(200 if wseed < 0 else 500) + s)), kind)
+            lg = refnet.probabilities(ref, x, base=0).numpy()
+            pr = torch.softmax(torch.from_numpy(lg) * float(np.log(1.3)), 1).numpy()
+            for name, (tag, keep) in cases.items():
+                net = nets[tag]
+                net.set_precision(split_weights=3) if keep is None else net.set_split_ops(keep)
+                p = net.probabilities(x.cuda()).cpu().numpy()
+                z = net.forward(x.cuda()).cpu().numpy()
+                worst[name].extend(np.abs(p - pr).max(1).tolist())
+                rms[name].append(float(np.mean((z - lg) ** 2)))
+                flips[name] += int((p.argmax(1) != pr.argmax(1)).sum())
+        print(f"{network} weights seed {wseed}, {n_img} images, test distribution: {kind} (calibrated on 16 'same' images), "
+              f"pmax {pr.max(1).min():.2f}..{pr.max(1).max():.2f}")
+        for name in cases:
+            v = np.array(worst[name])
+            print(f"  {name:44s} logit rms {np.sqrt(np.mean(rms[name])):.2e}  max|dp| {v.max():.2e}  p99 {np.percentile(v, 99):.2e}  "
+                  f"median {np.median(v):.2e}  top-1 flips {flips[name]}", flush=True)
+    del nets

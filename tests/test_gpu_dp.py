@@ -106,6 +106,11 @@ def test_bench_two_ranks_like_the_driver(tmp_path):
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["config"]["global_batch"] == 32
     assert res["value"] > 0 and res["train"]["value"] > 0 and res["config"]["parallelism"] == "dp2"
+    # the line describes the job it measured: who took part, what was exchanged, and that the replicas still agree
+    d, t = res["dist"], res["train"]["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and [r for r, _ in d["ranks_seen"]] == [0, 1]
+    assert t["world_size"] == 2 and t["params_equal"] is True and t["overlap"] is False
+    assert t["allreduce_bytes"] == 4 * 11_347_186 and t["allreduce_ms"] > 0     # ResNet-18 + head, fp32 gradients
 
 
 def test_bench_two_ranks_efficientnet_training(tmp_path):

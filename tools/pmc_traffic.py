@@ -7,16 +7,21 @@ usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv 
 Takes the dispatches of ONE steady-state step (between the last two to_nhwc4_kernel launches: every step starts with
 the layout conversion of its input batch), so autotuning launches are excluded."""
 import csv
+import datetime
 import hashlib
 import json
+import os
+import subprocess
 import sys
 from pathlib import Path
 
-# as bench.py (TRAFFIC_SOURCES / TRAIN_SOURCES): the figure is quoted only for the kernel sources it was taken on
-SOURCES = {"infer": ("conv_igemm.hip", "conv_pw.hip", "conv_c3.hip", "conv_stem.hip", "spk_common.h"),
-           "train": ("conv_igemm.hip", "conv_wgrad.hip", "conv_stem.hip", "spk_common.h")}
-KERNELS = {"infer": ("conv_igemm_kernel", "conv_pw_kernel", "conv_c3_kernel", "conv_stem_kernel"),
-           "train": ("conv_igemm_kernel", "conv_wgrad_kernel", "conv_stem_kernel")}
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402  (TRAFFIC_SOURCES / TRAIN_SOURCES: the figure is quoted only for the sources it was taken on)
+
+SOURCES = {"infer": bench.TRAFFIC_SOURCES, "train": bench.TRAIN_SOURCES}
+KERNELS = {"infer": ("conv_igemm_kernel", "conv_pw_kernel", "conv_c3_kernel", "conv_stem_kernel", "bneck_kernel"),
+           "train": ("conv_igemm_kernel", "conv_wgrad_kernel", "conv_stem_kernel", "conv_pw_kernel", "conv_c3_kernel")}
 
 
 def kernel_source_sha(mode):
@@ -26,6 +31,14 @@ def kernel_source_sha(mode):
         h.update(name.encode())
         h.update(f.read_bytes())
     return h.hexdigest()[:16]
+
+
+def _git_head():
+    try:
+        return subprocess.check_output(["git", "-C", str(ROOT), "rev-parse", "--short", "HEAD"], text=True,
+                                       stderr=subprocess.DEVNULL).strip()
+    except Exception:   # noqa: BLE001  (the GPU box snapshot has no .git: pass SPK_COMMIT)
+        return None
 
 
 def one_pass(path):
@@ -58,6 +71,10 @@ def main():
         "kernel": " + ".join(KERNELS[mode]),
         "mode": mode,
         "kernel_src_sha": kernel_source_sha(mode),
+        "taken_at": {"date": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ"),
+                     "commit": os.environ.get("SPK_COMMIT") or _git_head(),
+                     "eval_streams": int(os.environ.get("SPK_EVAL_STREAMS", "2")),
+                     "wgrad_stream": int(os.environ.get("SPK_WGRAD_STREAM", "1"))},
         "launches_per_step": len(conv_f),
         "fetch_bytes_per_step": sum(conv_f) * 1024 * 2,
         "write_bytes_per_step": sum(conv_w) * 1024,
