@@ -46,8 +46,11 @@ def parse():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=50)
     ap.add_argument("--mode", default="both", choices=["both", "infer", "train"])
-    ap.add_argument("--precision", default="mixed", choices=["mixed", "precise", "balanced", "fast", "bf16", "fp8"],
-                    help="mixed (library default): fp16 + hi/lo split weights on every conv except the 3x3 convs "
+    ap.add_argument("--precision", default="mixed", choices=["calibrated", "mixed", "precise", "balanced", "fast", "bf16", "fp8"],
+                    help="calibrated: every conv but the stem as ONE fp16 product, weights zero-sum rounded against "
+                         "per-channel activation means measured on 32 calibration images that are not in the timed batch "
+                         "(csrc/zero_sum.hip; as accurate as `precise`: tests/test_gpu_calibrated.py); "
+                         "mixed (library default without means): fp16 + hi/lo split weights on every conv except the 3x3 convs "
                          "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tests/diagnostics/split_rules.py: "
                          "passes the 1e-3 parity tolerance); precise: split on every conv (5.9e-4); balanced: split "
                          "only the layers that write the residual trunk (1.3e-3 worst case); fast: plain fp16 "
@@ -414,6 +417,11 @@ def main():
         net.set_precision(split_weights=3)
     elif args.precision == "bf16":
         net.set_precision(split_weights=False, bf16=True)
+    elif args.precision == "calibrated":
+        # model preparation, outside the timed region: what `sykepic train` stores as act_means.pth next to best_state.pth
+        net.eval()
+        net.calibrate(torch.from_numpy(synth.synth_images(32, 3, args.size, args.size, seed=9000 + rank)).to(dev))
+        net.set_precision("calibrated")
     else:
         net.set_precision(split_weights={"mixed": 3, "precise": 1, "balanced": 2, "fast": 0}[args.precision])
     # the job's batch is world x per-GPU batch images (weak scaling); rank r holds the contiguous shard

@@ -159,6 +159,27 @@ int spk_model_set_precision(spk_model* m, int split_weights, int precise_residua
  * called again.  `tests/diagnostics/split_search.py` derives the cheapest mask that keeps
  * the reference's 1e-3 probability tolerance. */
 int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops);
+/* Calibrated single-pass mode (round 4): split_weights = 5 in spk_model_set_precision.
+ * An fp16 weight image loses dw = fp16(w) - w per weight and an output loses sum_k dw_k x_k; over the data that error has
+ * a mean, sum_k dw_k E[x_k], the same for every pixel of an output channel - and this systematic part is most of the
+ * logit error of a plain fp16 forward.  With per-channel means E[x_k] of every conv's input, each weight row (per filter
+ * tap) is rounded to nearest and then the weights nearest a rounding midpoint are re-rounded until sum_k E[x_k] dw_k ~ 0
+ * ("zero-sum rounding", csrc/zero_sum.hip): the mean error is gone at no run-time cost, the row's squared error grows
+ * by < 1 %.  Mode 5 runs every conv as ONE fp16 product (the 7x7 stem alone keeps hi + lo) and needs the means:
+ *   spk_model_calibrate_act_means - one batch of representative images (as spk_forward_infer takes them) through the
+ *     most accurate mode; per-channel means of every conv input, accumulated over calls (reset != 0 starts over);
+ *   spk_model_get_act_means / spk_model_set_act_means - the flat vector (spk_model_act_means_size floats: cin values
+ *     per conv other than the stem, graph order) to store with the model and restore (`act_means.pth` next to
+ *     `best_state.pth`); set with host == NULL forgets them;
+ *   spk_model_set_zero_sum - apply the rounding to the un-split convs of ANY split mode (diagnostics).
+ * A model's probabilities stay a function of (weights, means, image): nothing depends on the batch an image arrives in.
+ * spk_forward_infer in mode 5 without means fails with SPK_ERR_STATE.  Reference call site: `net(x)`,
+ * sykepic/compute/probability.py:189. */
+int64_t spk_model_act_means_size(spk_model* m);
+int spk_model_calibrate_act_means(spk_model* m, const void* x_dev, int n, int h, int w, int layout, int dtype, int reset);
+int spk_model_get_act_means(spk_model* m, float* host, int64_t numel);
+int spk_model_set_act_means(spk_model* m, const float* host, int64_t numel);
+int spk_model_set_zero_sum(spk_model* m, int on);
 /* fp8 (OCP e4m3) eval mode of the EfficientNet MBConv blocks — BASELINE config 5.  Inside a block (expand 1x1
  * conv -> depthwise conv -> squeeze-excitation -> project 1x1 conv) the expanded tensors are stored as e4m3
  * bytes with one scale per tensor, the 1x1 convs run on the fp8 MFMA with e4m3 weights (one scale per output
@@ -288,6 +309,11 @@ int spk_op_conv3x3(const void* x_dev, const float* w_dev, const float* bn_scale_
                    const void* res_dev, void* y_dev, int n, int h, int w, int cin, int cout, int relu, int split, int cfg,
                    void* hip_stream);
 int spk_op_conv3x3_num_configs(void);
+/* Zero-sum rounding (csrc/zero_sum.hip) of fp32 weight rows on caller-provided DEVICE buffers: w, out [rows][row_len],
+ * mu [mu_period] (element k weighted with mu[k % mu_period]) or NULL (all ones).  out[i] is fp16(w[i]) or the fp16
+ * neighbour on the other side of w[i]; per row sum_k mu_k (out_k - w_k) is driven to ~0.  Synchronises the stream. */
+int spk_op_zero_sum_round(const float* w_dev, const float* mu_dev, float* out_dev, int64_t rows, int row_len,
+                          int mu_period, void* stream);
 /* Depthwise Conv2d(C, C, k, stride, pad (k-1)/2, groups=C) + folded BatchNorm + activation (EfficientNet MBConv):
  * x [n,h,w,C] fp16 NHWC, w float32 [C][k*k], y [n,ho,wo,C] fp16; pool (optional) float32 [n][C] = per-image sums of
  * the outputs (squeeze-excitation numerator).  lds != 0: the LDS row-ring kernel, else the gather kernel. */

@@ -47,6 +47,7 @@ struct Layer {
   bool dual_ok = false;           // images packed for the current precision settings (spk_commit)
   size_t wdual_off = 0;           // fragment-ordered concatenated weights (elements into spk_model::wdual)
   size_t sdual_off = 0;           // [2^e per cout][summed shifts] (floats into spk_model::sdual)
+  size_t mu_off = 0;              // generic convs: offset of this layer's cin input-channel means in spk_model::act_mean
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)
@@ -95,7 +96,17 @@ struct spk_model {
   int infer_dt = DT_F16;       // 16-bit storage type of the eval path
   int packed_dt = -1;          // dtype the packed weights currently hold
   int packed_split = -1;
-  int splitw = 3;              // eval: hi+lo fp16 weights. 0 none, 1 every conv, 2 trunk writers only, 3 all but inner 3x3 (default), 4 per-op mask
+  int splitw = 3;              // eval: hi+lo fp16 weights. 0 none, 1 every conv, 2 trunk writers only, 3 all but inner 3x3 (default), 4 per-op mask,
+                               // 5 calibrated single pass: the stem only, every other conv zero-sum rounded (zero_sum.hip)
+  // zero-sum rounding of the un-split fp16 weights against per-channel activation means (spk_model_calibrate_act_means)
+  bool zero_sum = false;       // explicit switch (spk_model_set_zero_sum); splitw == 5 implies it
+  bool have_means = false;
+  size_t n_means = 0;          // sum of cin over the generic convs
+  std::vector<float> act_mean; // host copy, graph order
+  float* act_mean_dev = nullptr;
+  std::vector<double> cal_sum; // calibration accumulators: sum over rows per channel ...
+  std::vector<double> cal_rows;  // ... and rows seen, per generic conv (graph order)
+  int packed_zs = -1;
   std::vector<unsigned char> split_mask;  // splitw == 4: one flag per graph op
   int split_epoch = 0, packed_epoch = -1;  // bumps when the mask changes
   int act_dt = DT_F16;         // dtype of the activations now in the arena

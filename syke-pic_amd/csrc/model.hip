@@ -279,8 +279,15 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       sdual += (size_t)2 * L.d.cout;
     }
   }
+  // per-channel means of every generic conv's input (zero_sum.hip): one flat vector, graph order
+  for (Layer& L : m->layers) {
+    if (L.d.kind != SPK_OP_CONV || L.mode != CONV_MODE_GENERIC) continue;
+    L.mu_off = m->n_means;
+    m->n_means += (size_t)L.d.cin;
+  }
   m->stale.assign(m->n_tensors, 0);
-  if (hipMalloc((void**)&m->wpack, std::max<size_t>(wpack, 8) * 2) != hipSuccess ||
+  if (hipMalloc((void**)&m->act_mean_dev, std::max<size_t>(m->n_means, 8) * 4) != hipSuccess ||
+      hipMalloc((void**)&m->wpack, std::max<size_t>(wpack, 8) * 2) != hipSuccess ||
       hipMalloc((void**)&m->dwpack, std::max<size_t>(dwp, 8) * 4) != hipSuccess ||
       hipMalloc((void**)&m->wdual, std::max<size_t>(wdual, 8) * 2) != hipSuccess ||
       hipMalloc((void**)&m->sdual, std::max<size_t>(sdual, 8) * 4) != hipSuccess ||
@@ -311,6 +318,7 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->dwpack) hipFree(m->dwpack);
   if (m->wdual) hipFree(m->wdual);
   if (m->sdual) hipFree(m->sdual);
+  if (m->act_mean_dev) hipFree(m->act_mean_dev);
   if (m->w8pack) hipFree(m->w8pack);
   if (m->fp8_shadow) hipFree(m->fp8_shadow);
   if (m->s8) hipFree(m->s8);
@@ -435,7 +443,8 @@ extern "C" int spk_model_set_infer_dtype(spk_model* m, int bf16) {
 
 extern "C" int spk_model_set_precision(spk_model* m, int split_weights, int precise_residual) {
   if (!m) return fail(SPK_ERR_ARG, "null model");
-  m->splitw = split_weights < 0 ? 0 : (split_weights > 3 ? 3 : split_weights);  // (4 = mask: spk_model_set_split_ops)
+  // (4 = mask: spk_model_set_split_ops; 5 = calibrated single pass, needs activation means)
+  m->splitw = split_weights < 0 ? 0 : (split_weights == 5 ? 5 : (split_weights > 3 ? 3 : split_weights));
   if ((precise_residual != 0) != m->precise_res) {
     m->precise_res = precise_residual != 0;
     m->cap_n = 0;  // re-plan: remainder tensors appear / disappear
@@ -473,6 +482,9 @@ extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
 static int layer_split(const spk_model* m, const Layer& L) {
   if (m->infer_dt != DT_F16 || m->splitw == 0) return 0;
   if (m->splitw == 4) return m->split_mask[&L - m->layers.data()] ? 1 : 0;
+  // 5: only the stem (its input - raw pixels on a near-constant background - has hardly any variance around its mean,
+  // and its K = 147 gives zero-sum rounding the fewest weights to balance with); every other conv single pass
+  if (m->splitw == 5) return L.mode != CONV_MODE_GENERIC ? 1 : 0;
   // 3: every conv except the 3x3 conv in the middle of a BOTTLENECK block, i.e. a 3x3 conv that neither writes the
   // trunk nor reads it (tests/diagnostics/split_rules.py: its weight rounding adds the least logit error per MFMA
   // cycle a lo-product costs).  The first 3x3 conv of a basic block (ResNet-18/34) reads the trunk and stays split:
@@ -481,6 +493,12 @@ static int layer_split(const spk_model* m, const Layer& L) {
   // inner3x3(stages1-3)": +0.29 ms per forward and no gain on the class-standardised golden fixture.)
   if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 || !L.inner3x3 ? 1 : 0;
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;
+}
+
+// is this conv's single fp16 weight image zero-sum rounded against the calibrated input means?
+static bool layer_zero_sum(const spk_model* m, const Layer& L) {
+  return (m->zero_sum || m->splitw == 5) && m->have_means && m->infer_dt == DT_F16 && L.d.kind == SPK_OP_CONV &&
+         L.mode == CONV_MODE_GENERIC && !layer_split(m, L);
 }
 
 // 3x3 RGB stem: master [cout][3][3][cin<=3] -> fp32 [9 taps][4][cout_p] (host repack: 1.3k floats, once per load)
@@ -497,9 +515,19 @@ static int pack_stem3(spk_model* m, const Layer& L) {
 }
 
 int spk_commit(spk_model* m) {
+  const int zs_now = (m->zero_sum || m->splitw == 5) && m->have_means ? 1 : 0;
   if (!m->dirty && m->packed_dt == m->infer_dt && m->packed_split == (int)m->splitw &&
-      m->packed_epoch == m->split_epoch)
+      m->packed_epoch == m->split_epoch && m->packed_zs == zs_now)
     return SPK_OK;
+  // zero-sum rounded fp32 copy of one layer's weights at a time (the stream orders round -> pack -> next round)
+  float* wround = nullptr;
+  {
+    size_t need = 0;
+    for (const Layer& L : m->layers)
+      if (layer_zero_sum(m, L)) need = std::max(need, (size_t)L.d.cout * L.d.k * L.d.k * L.d.cin);
+    if (need) HIP_TRY(hipMalloc((void**)&wround, need * 4));
+  }
+  struct Free { float* p; hipStream_t s; ~Free() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } } } free_wround{wround, m->stream};
   for (Layer& L : m->layers) {
     if (L.d.kind == SPK_OP_SE &&
         spk_launch_pack_tapmajor(m->P(L.p_w2), m->dwpack + L.wpack_off, L.d.cout, L.d.k, L.d.cout, m->stream))
@@ -513,26 +541,36 @@ int spk_commit(spk_model* m) {
                            L.d.cout, m->stream))
       return fail(SPK_ERR_HIP, "bn_fold launch failed");
     int r;
+    // the weights every image of this layer is packed from: the fp32 master, or its zero-sum rounded copy (values that
+    // ARE fp16 numbers, so each pack kernel's own conversion is exact): master layout [cout][tap][cin], one balanced
+    // group per (cout, tap), weighted with the input-channel means
+    const float* wsrc = m->P(L.p_w);
+    if (layer_zero_sum(m, L)) {
+      if (spk_launch_zero_sum_round(wsrc, m->act_mean_dev + L.mu_off, wround, (size_t)L.d.cout * L.d.k * L.d.k, L.d.cin,
+                                    L.d.cin, m->stream))
+        return fail(SPK_ERR_HIP, std::string("zero-sum rounding launch failed for ") + L.d.name);
+      wsrc = wround;
+    }
     if (L.d.kind == SPK_OP_DWCONV)
       r = spk_launch_pack_tapmajor(m->P(L.p_w), m->dwpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.d.cout, m->stream);
     else if (L.mode == CONV_MODE_STEM3)  // master layout [cout][kh][kw][cin]: rows = taps x 4 (cin padded to 4)
       r = pack_stem3(m, L);
     else if (L.mode == CONV_MODE_GENERIC && (L.cin_p != L.d.cin || L.cout_p != L.d.cout))
-      r = spk_launch_pack_padded(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.d.cin, L.cout_p,
+      r = spk_launch_pack_padded(wsrc, m->wpack + L.wpack_off, L.d.cout, L.d.k * L.d.k, L.d.cin, L.cout_p,
                                  L.cin_p, m->infer_dt, layer_split(m, L), m->stream);
     else
-      r = spk_launch_pack_weights(m->P(L.p_w), m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
+      r = spk_launch_pack_weights(wsrc, m->wpack + L.wpack_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
                                   L.mode, m->infer_dt, layer_split(m, L), m->stream);
     if (r) return fail(SPK_ERR_HIP, "pack_weights launch failed");
     // 1x1 convs: second image in MFMA fragment order (conv_pw.hip).  The BatchNorm scale is NOT folded into it: a
     // small scale would push the 16-bit weights into fp16's subnormal range (measured on the calibrated-statistics
     // golden fixture: every conv split, max |dp| 5.9e-4 with the scale in the fp32 epilogue, 1.1e-3 folded)
     if (L.pw_ok && m->infer_dt == DT_F16 &&
-        spk_launch_pack_pw(m->P(L.p_w), nullptr, m->wpack + L.wpw_off, L.d.cout, L.d.cin, DT_F16, layer_split(m, L) ? 2 : 1,
+        spk_launch_pack_pw(wsrc, nullptr, m->wpack + L.wpw_off, L.d.cout, L.d.cin, DT_F16, layer_split(m, L) ? 2 : 1,
                            m->stream))
       return fail(SPK_ERR_HIP, "pack_pw launch failed");
     if (L.c3_ok && m->infer_dt == DT_F16 &&
-        spk_launch_pack_c3(m->P(L.p_w), m->wpack + L.wpw_off, L.d.cout, L.d.cin, layer_split(m, L) ? 2 : 1, m->stream))
+        spk_launch_pack_c3(wsrc, m->wpack + L.wpw_off, L.d.cout, L.d.cin, layer_split(m, L) ? 2 : 1, m->stream))
       return fail(SPK_ERR_HIP, "pack_c3 launch failed");
   }
   // fused (block-closing + shortcut) convs: K-concatenated weights with both eval-BN scales folded in, normalised per
@@ -547,7 +585,11 @@ int spk_commit(spk_model* m) {
       tmp_floats = std::max(tmp_floats, (size_t)L.d.cout * (L.d.cin + D.d.cin));
     }
     float* wcat = nullptr;
-    if (tmp_floats) HIP_TRY(hipMalloc((void**)&wcat, tmp_floats * 4));
+    float* mucat = nullptr;   // dual + zero-sum: the two sources' channel means side by side, then the rounded copy
+    bool dual_zs = false;
+    for (const Layer& L : m->layers) dual_zs |= L.dual_src >= 0 && layer_zero_sum(m, L) && layer_zero_sum(m, m->layers[L.dual_src]);
+    if (tmp_floats) HIP_TRY(hipMalloc((void**)&wcat, tmp_floats * 4 * (dual_zs ? 2 : 1) + (dual_zs ? 16384 * 4 : 0)));
+    if (dual_zs) mucat = wcat + 2 * tmp_floats;
     for (Layer& L : m->layers) {
       if (L.dual_src < 0 || m->infer_dt != DT_F16) continue;
       const Layer& D = m->layers[L.dual_src];
@@ -557,7 +599,18 @@ int spk_commit(spk_model* m) {
       float* sd = m->sdual + L.sdual_off;
       int r = spk_launch_pw_dual_prep(m->P(L.p_w), m->P(D.p_w), sL, sD, sL + L.cout_p, sD + D.cout_p, wcat, sd,
                                       sd + L.d.cout, L.d.cout, L.d.cin, D.d.cin, m->stream);
-      if (!r) r = spk_launch_pack_pw(wcat, nullptr, m->wdual + L.wdual_off, L.d.cout, L.d.cin + D.d.cin, DT_F16,
+      const float* wc = wcat;
+      if (!r && mucat && layer_zero_sum(m, L) && layer_zero_sum(m, D) && L.d.cin + D.d.cin <= 16384) {
+        // the fused GEMM rounds the scale-folded concatenated rows: balance THOSE, against [means of y2 | means of x]
+        const int K = L.d.cin + D.d.cin;
+        if (hipMemcpyAsync(mucat, m->act_mean_dev + L.mu_off, (size_t)L.d.cin * 4, hipMemcpyDeviceToDevice, m->stream) != hipSuccess ||
+            hipMemcpyAsync(mucat + L.d.cin, m->act_mean_dev + D.mu_off, (size_t)D.d.cin * 4, hipMemcpyDeviceToDevice,
+                           m->stream) != hipSuccess)
+          r = -1;
+        if (!r) r = spk_launch_zero_sum_round(wcat, mucat, wcat + tmp_floats, (size_t)L.d.cout, K, K, m->stream);
+        wc = wcat + tmp_floats;
+      }
+      if (!r) r = spk_launch_pack_pw(wc, nullptr, m->wdual + L.wdual_off, L.d.cout, L.d.cin + D.d.cin, DT_F16,
                                      layer_split(m, L) ? 2 : 1, m->stream);
       if (r) { (void)hipFree(wcat); return fail(SPK_ERR_HIP, "dual-source weight packing failed"); }
       L.dual_ok = true;
@@ -571,6 +624,7 @@ int spk_commit(spk_model* m) {
   // shape runs on ONE stream again so that candidates are timed on a quiet GPU
   if (m->packed_dt != m->infer_dt || m->packed_split != (int)m->splitw || m->packed_epoch != m->split_epoch)
     m->half_warm.clear();
+  m->packed_zs = zs_now;
   m->packed_dt = m->infer_dt;
   m->packed_split = (int)m->splitw;
   m->packed_epoch = m->split_epoch;
@@ -1249,6 +1303,9 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
   if (!m || !x || n <= 0) return fail(SPK_ERR_ARG, "forward: bad arguments");
   if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return fail(SPK_ERR_ARG, "forward: dtype must be f32 or u8");
   HIP_TRY(hipSetDevice(m->device));
+  if (m->splitw == 5 && !m->have_means)
+    return fail(SPK_ERR_STATE, "the calibrated single-pass mode needs activation means first: spk_model_calibrate_act_means "
+                               "on representative images, or spk_model_set_act_means with stored ones");
   SPK_TRY(spk_commit(m));
   SPK_TRY(spk_plan(m, n, h, w));
   if (m->fp8 && !m->fp8_calibrated)
@@ -1325,6 +1382,125 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
                            (size_t)nb * m->num_classes * 4, hipMemcpyDeviceToDevice, m->stream));
   }
   return SPK_OK;
+}
+
+// ---------------------------------------------------------------------------
+// activation means for zero-sum weight rounding (zero_sum.hip)
+// ---------------------------------------------------------------------------
+extern "C" int64_t spk_model_act_means_size(spk_model* m) { return m ? (int64_t)m->n_means : 0; }
+
+extern "C" int spk_model_set_zero_sum(spk_model* m, int on) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  m->zero_sum = on != 0;
+  return SPK_OK;
+}
+
+extern "C" int spk_model_set_act_means(spk_model* m, const float* host, int64_t numel) {
+  if (!m) return fail(SPK_ERR_ARG, "null model");
+  if (!host || numel == 0) {   // forget them
+    m->have_means = false;
+    m->act_mean.clear();
+    m->packed_zs = -1;
+    return SPK_OK;
+  }
+  if (numel != (int64_t)m->n_means) return fail(SPK_ERR_ARG, "set_act_means: one value per input channel of every conv expected");
+  for (int64_t i = 0; i < numel; ++i)
+    if (!std::isfinite(host[i])) return fail(SPK_ERR_ARG, "set_act_means: non-finite mean");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  m->act_mean.assign(host, host + numel);
+  HIP_TRY(hipMemcpy(m->act_mean_dev, host, (size_t)numel * 4, hipMemcpyHostToDevice));
+  m->have_means = true;
+  m->packed_zs = -1;   // re-round at the next commit
+  return SPK_OK;
+}
+
+extern "C" int spk_model_get_act_means(spk_model* m, float* host, int64_t numel) {
+  if (!m || !host) return fail(SPK_ERR_ARG, "get_act_means: bad arguments");
+  if (!m->have_means) return fail(SPK_ERR_STATE, "no activation means: calibrate or set them first");
+  if (numel != (int64_t)m->n_means) return fail(SPK_ERR_ARG, "get_act_means: size mismatch");
+  memcpy(host, m->act_mean.data(), (size_t)numel * 4);
+  return SPK_OK;
+}
+
+// One calibration batch: the forward in the most accurate mode (every conv hi + lo, nothing fused away, one stream),
+// then the per-channel mean of every generic conv's input tensor, accumulated over calls (reset != 0 starts over).
+// The means describe the DATA the model will see, not the batch composition of any later call: a model's probabilities
+// stay a function of (weights, means, image).  They are stored with the model (`act_means.pth`, sykepic_hip/prob.py).
+extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype,
+                                             int reset) {
+  if (!m || !x || n <= 0) return fail(SPK_ERR_ARG, "calibrate_act_means: bad arguments");
+  if (dtype != SPK_DTYPE_F32 && dtype != SPK_DTYPE_U8) return fail(SPK_ERR_ARG, "calibrate_act_means: dtype must be f32 or u8");
+  if (m->infer_dt != DT_F16) return fail(SPK_ERR_STATE, "calibrate_act_means needs the fp16 eval path");
+  if (m->n_means == 0) return fail(SPK_ERR_UNSUPPORTED, "the graph has no convolution to calibrate");
+  HIP_TRY(hipSetDevice(m->device));
+  std::vector<int> gen;   // generic convs, graph order
+  for (size_t i = 0; i < m->layers.size(); ++i)
+    if (m->layers[i].d.kind == SPK_OP_CONV && m->layers[i].mode == CONV_MODE_GENERIC) gen.push_back((int)i);
+  if (reset || m->cal_sum.size() != m->n_means) {
+    m->cal_sum.assign(m->n_means, 0.0);
+    m->cal_rows.assign(gen.size(), 0.0);
+  }
+  // the accurate forward: remember the caller's settings
+  const int keep_split = m->splitw, keep_fp8 = m->fp8;
+  const bool keep_zs = m->zero_sum, keep_have = m->have_means;
+  m->splitw = 1; m->zero_sum = false; m->have_means = false; m->fp8 = 0;
+  int rc = spk_commit(m);
+  if (rc == SPK_OK) rc = spk_plan(m, n, h, w);
+  float *part = nullptr, *mean_dev = nullptr;
+  std::vector<float> host(m->n_means);
+  if (rc == SPK_OK) {
+    int cmax = 8;
+    for (int li : gen) cmax = std::max(cmax, m->tdims[m->layers[li].d.src].c);
+    if (hipMalloc((void**)&part, (size_t)256 * cmax * 4) != hipSuccess || hipMalloc((void**)&mean_dev, m->n_means * 4) != hipSuccess)
+      rc = fail(SPK_ERR_HIP, "hipMalloc(calibration scratch) failed");
+  }
+  const int mb = micro_batch(m, n);
+  m->force_unfused = true;   // every tensor a conv reads must really be written (no fused stem pool / shortcut conv)
+  for (int i0 = 0; i0 < n && rc == SPK_OK; i0 += mb) {
+    const int nb = std::min(mb, n - i0);
+    const char* xi = (const char*)x + (size_t)i0 * image_stride_bytes(m->in_chans, h, w, dtype);
+    m->act_dt = m->infer_dt;
+    m->t_fp8_scale.assign(m->n_tensors, 0.f);
+    if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream)) {
+      rc = fail(SPK_ERR_HIP, "input conversion launch failed");
+      break;
+    }
+    m->last_eval_nb = nb;
+    for (size_t i = 0; i < m->layers.size() && rc == SPK_OK; ++i) rc = spk_run_layer_eval(m, m->layers[i], nb);
+    for (size_t gi = 0; gi < gen.size() && rc == SPK_OK; ++gi) {
+      const Layer& L = m->layers[gen[gi]];
+      const TDim& in = m->tdims[L.d.src];
+      if (in.c != L.d.cin || !in.bf16) { rc = fail(SPK_ERR_UNSUPPORTED, std::string("calibration: unexpected input layout at ") + L.d.name); break; }
+      if (spk_launch_chan_mean((const bf16_t*)m->T(L.d.src), part, mean_dev + L.mu_off, (size_t)nb * in.h * in.w, in.c,
+                               m->infer_dt, m->stream))
+        rc = fail(SPK_ERR_HIP, "channel-mean launch failed");
+    }
+    if (rc != SPK_OK) break;
+    if (hipMemcpyAsync(host.data(), mean_dev, m->n_means * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+        hipStreamSynchronize(m->stream) != hipSuccess) {
+      rc = fail(SPK_ERR_HIP, "reading the calibration means failed");
+      break;
+    }
+    for (size_t gi = 0; gi < gen.size(); ++gi) {
+      const Layer& L = m->layers[gen[gi]];
+      const TDim& in = m->tdims[L.d.src];
+      const double rows = (double)nb * in.h * in.w;
+      for (int c = 0; c < L.d.cin; ++c) m->cal_sum[L.mu_off + c] += (double)host[L.mu_off + c] * rows;
+      m->cal_rows[gi] += rows;
+    }
+  }
+  m->force_unfused = false;
+  (void)hipStreamSynchronize(m->stream);
+  if (part) (void)hipFree(part);
+  if (mean_dev) (void)hipFree(mean_dev);
+  m->splitw = keep_split; m->zero_sum = keep_zs; m->have_means = keep_have; m->fp8 = keep_fp8;
+  if (rc != SPK_OK) return rc;
+  for (size_t gi = 0; gi < gen.size(); ++gi) {
+    const Layer& L = m->layers[gen[gi]];
+    for (int c = 0; c < L.d.cin; ++c) host[L.mu_off + c] = (float)(m->cal_sum[L.mu_off + c] / m->cal_rows[gi]);
+  }
+  return spk_model_set_act_means(m, host.data(), (int64_t)host.size());
 }
 
 extern "C" int spk_forward_infer(spk_model* m, const void* x, int n, int h, int w, int layout,

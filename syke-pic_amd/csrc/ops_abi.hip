@@ -293,3 +293,16 @@ extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* b
   return SPK_OK;
 }
 extern "C" int spk_op_conv3x3_num_configs(void) { return spk_c3_num_configs(); }
+
+// Zero-sum rounding of fp32 weight rows to fp16 values (zero_sum.hip) on caller-provided device buffers: w, out
+// [rows][row_len] fp32, mu [mu_period] fp32 or null.  The kernel spk_commit runs per conv in the calibrated mode.
+extern "C" int spk_op_zero_sum_round(const float* w, const float* mu, float* out, int64_t rows, int row_len, int mu_period,
+                                     void* stream) {
+  if (!w || !out || rows < 1 || row_len < 1 || mu_period < 1) return ofail(SPK_ERR_ARG, "op_zero_sum_round: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  const int r = spk_launch_zero_sum_round(w, mu, out, (size_t)rows, row_len, mu_period, s);
+  if (r == -2) return ofail(SPK_ERR_UNSUPPORTED, "op_zero_sum_round: row too long (8192 elements at most)");
+  if (r) return ofail(SPK_ERR_HIP, "zero-sum rounding launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "zero-sum rounding kernel failed");
+  return SPK_OK;
+}

@@ -183,6 +183,16 @@ int spk_launch_pack_c3(const float* w_ohwi, bf16_t* out, int cout, int cin, int 
 int spk_conv3x3_launch(const C3Args& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// Zero-sum rounding of fp16 weights + activation means (zero_sum.hip)
+// ---------------------------------------------------------------------------
+// w, out: [rows][row_len] fp32; mu: [mu_period] (element k is weighted with mu[k % mu_period]) or null (all ones).
+// out[i] is fp16(w[i]) or its neighbour on the other side of w[i], chosen so that sum_k mu_k (out_k - w_k) ~ 0 per row.
+int spk_launch_zero_sum_round(const float* w, const float* mu, float* out, size_t rows, int row_len, int mu_period,
+                              hipStream_t s);
+int spk_chan_mean_slices(size_t rows);
+int spk_launch_chan_mean(const bf16_t* x, float* part, float* mean, size_t rows, int C, int dt, hipStream_t s);
+
+// ---------------------------------------------------------------------------
 // Pointwise / pooling / packing kernels (pointwise.hip)
 // ---------------------------------------------------------------------------
 // image batch -> NHWC bf16 with channels padded to 4 (stem input)

@@ -70,6 +70,12 @@ SYMBOLS = {
     "spk_model_set_infer_dtype": (C.c_int, [_P, C.c_int]),
     "spk_model_set_precision": (C.c_int, [_P, C.c_int, C.c_int]),
     "spk_model_set_split_ops": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "spk_model_act_means_size": (C.c_int64, [_P]),
+    "spk_model_calibrate_act_means": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "spk_model_get_act_means": (C.c_int, [_P, _P, C.c_int64]),
+    "spk_model_set_act_means": (C.c_int, [_P, _P, C.c_int64]),
+    "spk_model_set_zero_sum": (C.c_int, [_P, C.c_int]),
+    "spk_op_zero_sum_round": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "spk_model_set_fp8": (C.c_int, [_P, C.c_int]),
     "spk_model_calibrate_fp8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "spk_model_set_bn": (C.c_int, [_P, C.c_float, C.c_float]),

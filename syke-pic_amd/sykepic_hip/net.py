@@ -230,9 +230,45 @@ class HipNet:
         self.load_state_dict(sd)
 
     def set_precision(self, split_weights=3, precise_residual=False, bf16=False):
-        """Eval-path precision knobs (see include/sykepic_hip.h)."""
+        """Eval-path precision knobs (see include/sykepic_hip.h).  split_weights = 5 ("calibrated"): every conv but the
+        stem as ONE fp16 product with zero-sum rounded weights; needs `calibrate` / `set_act_means` first."""
+        if split_weights == "calibrated":
+            split_weights = 5
         lib.check(self._lib.spk_model_set_infer_dtype(self._h, int(bool(bf16))))
         lib.check(self._lib.spk_model_set_precision(self._h, int(split_weights), int(bool(precise_residual))))
+        return self
+
+    # ---- calibrated single-pass mode (csrc/zero_sum.hip) ----
+    def calibrate(self, x, reset=True):
+        """Per-channel means of every conv's input on the representative batch `x` (as `forward` takes it), measured
+        with the most accurate mode; further calls with reset=False accumulate.  Does not change the precision mode:
+        `set_precision("calibrated")` (or `zero_sum(True)` for the un-split convs of another mode) uses the means."""
+        self._ensure_init()
+        x, n, h, w, layout, dtype = self._prep(x)
+        with torch.cuda.device(self.device):
+            lib.check(self._lib.spk_model_set_stream(self._h, self._stream()))
+            lib.check(self._lib.spk_model_calibrate_act_means(self._h, C.c_void_p(x.data_ptr()), n, h, w, layout, dtype,
+                                                              int(bool(reset))))
+        return self
+
+    def act_means(self):
+        """The calibrated means as one flat float32 tensor (what `act_means.pth` stores next to `best_state.pth`)."""
+        out = torch.empty(int(self._lib.spk_model_act_means_size(self._h)), dtype=torch.float32)
+        lib.check(self._lib.spk_model_get_act_means(self._h, C.c_void_p(out.data_ptr()), out.numel()))
+        return out
+
+    def set_act_means(self, means):
+        """Restore stored means (None forgets them)."""
+        if means is None:
+            lib.check(self._lib.spk_model_set_act_means(self._h, None, 0))
+            return self
+        t = torch.as_tensor(means, dtype=torch.float32).contiguous().cpu()
+        lib.check(self._lib.spk_model_set_act_means(self._h, C.c_void_p(t.data_ptr()), t.numel()))
+        return self
+
+    def zero_sum(self, on=True):
+        """Zero-sum round the un-split convs of the CURRENT split mode against the calibrated means (diagnostics)."""
+        lib.check(self._lib.spk_model_set_zero_sum(self._h, int(bool(on))))
         return self
 
     def num_fp8_blocks(self):

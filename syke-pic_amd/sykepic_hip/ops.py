@@ -205,3 +205,18 @@ def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0, res=Non
                                     _p(rh) if rh is not None else None, _p(y), n, h, w, cin, cout, int(bool(relu)), int(bool(split)), int(cfg),
                                     _stream(dev)))
     return y.permute(0, 3, 1, 2)
+
+
+def zero_sum_round(w, mu=None, period=None):
+    """w [rows, row_len] float32 device tensor, mu [period] or None -> the zero-sum rounded rows (float32 values that are
+    fp16 numbers), csrc/zero_sum.hip."""
+    so = lib.load()
+    w = w.float().contiguous()
+    out = torch.empty_like(w)
+    rows, row_len = w.shape
+    if mu is not None:
+        mu = mu.float().contiguous()
+        period = period or mu.numel()
+    with torch.cuda.device(w.device):
+        lib.check(so.spk_op_zero_sum_round(_p(w), _p(mu), _p(out), rows, row_len, int(period or row_len), _stream(w.device)))
+    return out
