@@ -309,6 +309,14 @@ int spk_op_conv3x3(const void* x_dev, const float* w_dev, const float* bn_scale_
                    const void* res_dev, void* y_dev, int n, int h, int w, int cin, int cout, int relu, int split, int cfg,
                    void* hip_stream);
 int spk_op_conv3x3_num_configs(void);
+/* Two chained 1x1 convs in ONE launch (round 4, csrc/conv_pw.hip): y = act(BN(W . x) + res) with cout = 256, then
+ * z = actz(BNz(Wz . y)) computed from the output tile while it is still in registers - what the eval path runs for a
+ * bottleneck's block-closing conv and the next block's first conv in the single-weight-image modes (the trunk y is
+ * written for later shortcut adds, but never re-read by the conv that follows).  Tensors NHWC fp16 on the device,
+ * weights fp32 [cout][cin] / [coutz][cout].  y and z are bit-identical to two spk_op_conv1x1(split = 0) calls. */
+int spk_op_conv1x1_chain(const void* x, const float* w, const float* bn_scale, const float* bn_bias, const void* res,
+                         void* y, const float* wz, const float* bnz_scale, const float* bnz_bias, void* z, int n, int h,
+                         int wd, int cin, int cout, int coutz, int relu, int reluz, void* stream);
 /* Zero-sum rounding (csrc/zero_sum.hip) of fp32 weight rows on caller-provided DEVICE buffers: w, out [rows][row_len],
  * mu [mu_period] (element k weighted with mu[k % mu_period]) or NULL (all ones).  out[i] is fp16(w[i]) or the fp16
  * neighbour on the other side of w[i]; per row sum_k mu_k (out_k - w_k) is driven to ~0.  Synchronises the stream. */

@@ -50,9 +50,19 @@ template <int DT> __device__ __forceinline__ unsigned int pack2_nosat(float lo, 
 // HAS_RES: the launch has a shortcut operand (compile-time: with both epilogues in one kernel the compiler's s_waitcnt
 // placement merges the two paths and waits for the previous epilogue's stores at the top of every tile).
 // DUAL: K-concatenated second activation source (PwConvArgs::x2).
-template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC, bool HAS_RES, bool DUAL = false>
+// NPZ > 0: CHAINED second 1x1 conv with 32 * NPZ couts (PwConvArgs::wpz): the block owns every cout of this conv, so a
+// lane's packed output registers - 8 consecutive couts of one pixel per cout pair - ARE the MFMA B fragments of a conv
+// that reads this output: pair P is its K step P.  After the epilogue (which still writes the tile: shortcut adds further
+// down need the trunk) the wave multiplies those registers with the second panel, resident in LDS behind the first, and
+// stores z.  The 16-bit values the second conv consumes are the ones just stored and its K steps accumulate in the
+// same order as a stand-alone launch: z is bit-identical to the two-kernel result.
+template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC, bool HAS_RES, bool DUAL = false, int NPZ = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, int m_tiles, int n_tiles) {
   constexpr bool RESIDENT = KSC > 0;
+  constexpr bool CHAIN = NPZ > 0;
+  static_assert(!CHAIN || (KSC > 0 && NB == 1), "the chained conv rides on the resident flavour with single weight images");
+  constexpr int CHZ = NPZ * 2048;          // bytes of one 32-deep K step of the chained conv's panel
+  constexpr int KSZ = NPAIR;               // its K steps: one per cout pair of this conv
   constexpr int XS = RESIDENT ? KSC : PA;   // activation register sets
   constexpr int NT = 2 * NPAIR;            // 16-cout MFMA tiles of the block tile
   constexpr int BN = 32 * NPAIR;           // couts of the block tile
@@ -81,6 +91,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
       __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (a.ablate & 1) ? 0 : a.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, (HAS_RES && !(a.ablate & 2)) ? a.y_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(CHAIN ? a.z : a.y), 0, CHAIN && !(a.ablate & 1) ? a.z_bytes : 0, 0x00020000);
 
   // ---- block -> work ----
   int n_tile, mt, mt_step;
@@ -102,6 +114,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
   const int n0 = n_tile * BN;
   unsigned char* const sW = smem;
   float* const sScale = (float*)(smem + (RESIDENT ? KS : 2) * CH);   // [BN] scale, then [BN] shift
+  unsigned char* const sWz = (unsigned char*)(sScale + 2 * BN);       // chained conv: [KSZ][CHZ] panel ...
+  float* const sScaleZ = (float*)(sWz + KSZ * CHZ);                   // ... and its [32 NPZ] scale, [32 NPZ] shift
 
   // byte offset of K step s of this block's panel in the packed weights
   auto w_goff = [&](int s) { return (size_t)(s * pairs_total + n_tile * NPAIR) * (NB * 2048); };
@@ -109,6 +123,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
   // pixel tile -> per-lane byte offsets of the activation fragments (pixel p of each of the wave's MT pixel tiles,
   // 16-byte chunk g of a K step) and of the output row segments (8 couts from n0 + 8g)
   constexpr int MT2 = DUAL ? MT : 1;
+  constexpr int MTZ = CHAIN ? MT : 1;
+  auto tile_zoffsets = [&](int tile, unsigned (&zoff)[MTZ]) {
+#pragma unroll
+    for (int m = 0; m < MTZ; ++m) {
+      const int px = tile * BM + wave * WPX + m * 16 + p;
+      zoff[m] = (CHAIN && tile < m_tiles && px < a.M) ? (unsigned)px * (unsigned)(a.Coutz * 2) + (unsigned)(8 * g) * 2 : 0x80000000u;
+    }
+  };
   auto tile_offsets = [&](int tile, unsigned (&aoff)[MT], unsigned (&yoff)[MT], unsigned (&aoff2)[MT2]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -190,6 +212,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
   // the wave sit through the HBM write latency of those stores; one tile later they have long drained.
   constexpr bool PRE_RES = MT * NPAIR <= 8;
   u32x4_t rv[PRE_RES ? MT : 1][NPAIR];
+  u32x4_t xb[CHAIN ? NPAIR : 1][MT];   // chained conv: the packed output tile = its B fragments, K step P x pixel tile m
   // ReLU and the fp16 saturation in ONE v_med3_f32 per value: floor 0 (ReLU) or -65504 (none), ceiling 65504
   const float out_max = DT == DT_F16 ? 65504.f : 3.3895314e38f;
   const float relu_floor = a.relu == 1 ? 0.f : -out_max;
@@ -239,7 +262,65 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         // in an SGPR the next tile's address arithmetic overwrote the 4th data dword of the last store of a tile
         // (measured: couts 6, 7 of every 8 came out as pixel indices in 0.01-0.1 % of the rows).
         __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yoff[m] + P * 64, 0, 0);
+        if constexpr (CHAIN) xb[P][m] = ov;
       }
+    }
+  };
+  // chained conv: z[pixel][32 Pz + 8g ..] = act(BN(sum_s Wz[s] . xb[s])) - fragments ping-pong between two register sets
+  // as in compute(), one (K step, pair) unit ahead
+  auto chain_stage = [&](const unsigned (&zoff)[MTZ]) {
+    if constexpr (CHAIN) {
+      f32x4_t az[MT][2 * NPZ];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < 2 * NPZ; ++t) az[m][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      u32x4_t fz[2][2];
+      lds_u8_t zb = (lds_u8_t)sWz + lane * 16;
+      asm volatile("" : "+v"(zb));
+      fz[0][0] = *(lds_u32x4_t)(zb);
+      fz[0][1] = *(lds_u32x4_t)(zb + 1024);
+#pragma unroll
+      for (int u = 0; u < KSZ * NPZ; ++u) {
+        const int sz = u / NPZ, Pz = u % NPZ;
+        if (u + 1 < KSZ * NPZ) {
+          fz[(u + 1) & 1][0] = *(lds_u32x4_t)(zb + (u + 1) * 2048);
+          fz[(u + 1) & 1][1] = *(lds_u32x4_t)(zb + (u + 1) * 2048 + 1024);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          az[m][2 * Pz] = mfma16<DT>(fz[u & 1][0], xb[sz][m], az[m][2 * Pz]);
+          az[m][2 * Pz + 1] = mfma16<DT>(fz[u & 1][1], xb[sz][m], az[m][2 * Pz + 1]);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
+      }
+      const float zfloor = a.reluz == 1 ? 0.f : -out_max;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int Pz = 0; Pz < NPZ; ++Pz) {
+          typedef __attribute__((address_space(3))) const f32x4_t* lds_f32x4_t;
+          lds_f32x4_t sp = (lds_f32x4_t)(sScaleZ + Pz * 32 + 8 * g);
+          asm volatile("" : "+v"(sp));
+          const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[8 * NPZ], sh1 = sp[8 * NPZ + 1];
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = __builtin_fmaf(az[m][2 * Pz][r], sc0[r], sh0[r]);
+            v[4 + r] = __builtin_fmaf(az[m][2 * Pz + 1][r], sc1[r], sh1[r]);
+          }
+          if (a.reluz == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], zfloor, out_max);
+          u32x4_t ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = pack2_nosat<DT>(v[2 * j], v[2 * j + 1]);
+          __builtin_amdgcn_raw_buffer_store_b128(ov, rz, zoff[m] + Pz * 64, 0, 0);
+        }
     }
   };
   auto epilogue = [&](const unsigned (&yoff)[MT], const unsigned (&yoff_next)[MT]) {
@@ -265,6 +346,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         if (PRE_RES && HAS_RES) rv[m][P] = __builtin_amdgcn_raw_buffer_load_b128(rr, yoff[m] + P * 64, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0, 0, 0, 0}, rnull, yoff[m] + P * 64, 0, 0);
       }
+    if (CHAIN) {
+#pragma unroll
+      for (int i = 0; i < MT * NPZ; ++i) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0, 0, 0, 0}, rnull, yoff[0], 0, 0);
+    }
   };
 
   // folded BatchNorm scale / shift of this block's couts
@@ -273,6 +358,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
     sScale[BN + c] = a.shift ? a.shift[n0 + c] : 0.f;
   }
 
+  if (CHAIN) {
+    for (int c = tid; c < 32 * NPZ; c += T) {
+      sScaleZ[c] = a.scalez ? a.scalez[c] : 1.f;
+      sScaleZ[32 * NPZ + c] = a.shiftz ? a.shiftz[c] : 0.f;
+    }
+    for (int o = tid * 16; o < KSZ * CHZ; o += T * 16) *(u32x4_t*)(sWz + o) = *(const u32x4_t*)((const unsigned char*)a.wpz + o);
+  }
   if (RESIDENT) {
     // ---- whole [K x BN] panel into LDS, once ----
     for (int s = 0; s < KS; ++s) {
@@ -283,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         if (CH % (T * 16) == 0 || o < CH) *(u32x4_t*)(sW + s * CH + o) = *(const u32x4_t*)(src + o);
       }
     }
-    unsigned aoff[MT], yoff[MT], aoff_n[MT], yoff_n[MT], aoff2[MT2], aoff2_n[MT2];
+    unsigned aoff[MT], yoff[MT], aoff_n[MT], yoff_n[MT], aoff2[MT2], aoff2_n[MT2], zoff[MTZ];
     tile_offsets(mt, aoff, yoff, aoff2);
     tile_offsets(mt + mt_step, aoff_n, yoff_n, aoff2_n);
 #pragma unroll
@@ -312,6 +404,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void conv_pw_kernel(PwConvArgs a, in
         sbase = snext;
       }
       epilogue(yoff, yoff_n);
+      if (CHAIN) {
+        tile_zoffsets(mt, zoff);
+        chain_stage(zoff);
+      }
       mt += mt_step;
 #pragma unroll
       for (int m = 0; m < MT; ++m) { aoff[m] = aoff_n[m]; yoff[m] = yoff_n[m]; }
@@ -422,21 +518,27 @@ __global__ void pw_dual_prep_kernel(const float* __restrict__ w1, const float* _
   }
 }
 
-template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC>
+template <int DT, int NB, int MT, int NPAIR, int WAVES, int PA, int KSC, int NPZ = 0>
 int launch_k(const PwConvArgs& a, hipStream_t s) {
   constexpr int BN = 32 * NPAIR, BM = WAVES * MT * 16, CH = NPAIR * NB * 2048;
   constexpr bool RESIDENT = KSC > 0;
   const bool dual = a.x2 != nullptr;
+  if ((NPZ > 0) != (a.wpz != nullptr)) return -3;
+  if (NPZ > 0 && (a.Coutz != 32 * NPZ || a.Cout != BN || !a.z || (!dual && !a.res))) return -3;
   const int KS = (a.Cin + (dual ? a.Cin2 : 0)) / 32;
   if (a.Cout % BN) return -3;
   if (RESIDENT ? KS != KSC : (KS % PA || KS < PA)) return -3;
   if (dual && a.res) return -3;   // (the fused shortcut IS the second source)
   const int n_tiles = a.Cout / BN, m_tiles = (a.M + BM - 1) / BM;
-  const size_t lds = (size_t)(RESIDENT ? KS : 2) * CH + 2 * BN * 4;
+  const size_t lds = (size_t)(RESIDENT ? KS : 2) * CH + 2 * BN * 4 + (size_t)NPZ * (NPAIR * 2048 + 2 * 32 * 4);
   if (lds > 160 * 1024) return -3;
-  auto k = dual ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false, true>
-                : (a.res ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true>
-                         : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false>);
+  void (*k)(PwConvArgs, int, int);
+  if constexpr (NPZ > 0)   // (chained: a block-closing conv always has a shortcut operand or the fused shortcut conv)
+    k = dual ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false, true, NPZ>
+             : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true, false, NPZ>;
+  else
+    k = dual ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false, true>
+             : (a.res ? conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, true> : conv_pw_kernel<DT, NB, MT, NPAIR, WAVES, PA, KSC, false>);
   // hipFuncSetAttribute applies to the CURRENT device only: one bit per (kernel flavour, device), so that a process
   // holding models on several GPUs raises the dynamic-LDS limit on each of them (devices >= 64: set on every launch)
   static std::atomic<unsigned long long> attr[3];
@@ -504,6 +606,23 @@ int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s) {
   if ((size_t)a.y_bytes >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull) return -2;
   if (a.dt == DT_F16) return a.nb == 2 ? launch_cfg<DT_F16, 2>(a, cfg, s) : launch_cfg<DT_F16, 1>(a, cfg, s);
   return -2;   // (bf16 training path: not instantiated yet)
+}
+
+// A block-closing 1x1 conv (256 couts: its whole panel and output tile per block) chained with the 1x1 conv that reads
+// its output (PwConvArgs::wpz), both with single fp16 weight images.  -3: this problem has no chained kernel.
+int spk_pw_chain_launch(const PwConvArgs& a, hipStream_t s) {
+  if (!a.wpz || !a.z || a.dt != DT_F16 || a.nb != 1 || a.Cout != 256 || a.Cin % 64 || a.M <= 0) return -3;
+  if (a.x2 && (a.Cin2 % 64 || (size_t)a.x2_bytes >= 0x80000000ull)) return -3;
+  if ((size_t)a.y_bytes >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull || (size_t)a.z_bytes >= 0x80000000ull) return -3;
+  const int KS = (a.Cin + (a.x2 ? a.Cin2 : 0)) / 32;
+  if (a.Coutz == 64) {
+    if (KS == 2) return launch_k<DT_F16, 1, 1, 8, 8, 2, 2, 2>(a, s);
+    if (KS == 4) return launch_k<DT_F16, 1, 1, 8, 8, 2, 4, 2>(a, s);
+  } else if (a.Coutz == 128) {
+    if (KS == 2) return launch_k<DT_F16, 1, 1, 8, 8, 2, 2, 4>(a, s);
+    if (KS == 4) return launch_k<DT_F16, 1, 1, 8, 8, 2, 4, 4>(a, s);
+  }
+  return -3;
 }
 
 int spk_launch_pw_dual_prep(const float* w1, const float* w2, const float* s1, const float* s2, const float* b1,

@@ -47,6 +47,11 @@ struct Layer {
   bool dual_ok = false;           // images packed for the current precision settings (spk_commit)
   size_t wdual_off = 0;           // fragment-ordered concatenated weights (elements into spk_model::wdual)
   size_t sdual_off = 0;           // [2^e per cout][summed shifts] (floats into spk_model::sdual)
+  // eval, single-weight modes: a block-closing 1x1 conv (256 couts) and the 1x1 conv of the NEXT block that reads its
+  // output, as one kernel (conv_pw.hip, PwConvArgs::wpz): the trunk is written but not re-read by that conv
+  int chain_next = -1;            // block-closing conv: index of the conv it can also compute, or -1
+  int chained_by = -1;            // that conv: index of the block-closing conv
+  bool chained_now = false;       // set by the block-closing conv's launch of the current forward: chain_next is done
   size_t mu_off = 0;              // generic convs: offset of this layer's cin input-channel means in spk_model::act_mean
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
@@ -87,6 +92,8 @@ struct spk_model {
   bf16_t* wdual = nullptr;     // K-concatenated weight images of the fused (block-closing + shortcut) convs
   float* sdual = nullptr;      // their epilogue factors
   bool fuse_ds = true;         // SPK_FUSE_DS=0 turns the fusion off
+  int chain = 1;               // conv3 -> next conv1 chaining: 1 where it is faster (timed once per problem), SPK_CHAIN=0 never, 2 always
+  bool no_chain_now = false;   // the chain tuner is timing the two-kernel alternative
   std::vector<char> stale;     // per tensor: the last eval forward did not write it (a fused-away shortcut tensor)
   bool effnet = false;         // EfficientNet graph (widths that are not multiples of 64, depthwise / SE / SiLU ops): its
                                // TRAINING plan pads every activation tensor to a multiple of 64 channels (train_effnet.hip)

@@ -279,6 +279,21 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       sdual += (size_t)2 * L.d.cout;
     }
   }
+  // block-closing conv -> the next block's first conv (both 1x1, stride 1, 256 -> 64 / 128 channels in between)
+  for (size_t i = 0; i < m->layers.size(); ++i) {
+    Layer& L = m->layers[i];
+    if (L.d.kind != SPK_OP_CONV || !L.pw_ok || L.d.res < 0 || L.d.stride != 1 || L.d.cout != 256) continue;
+    for (size_t j = i + 1; j < m->layers.size(); ++j) {
+      Layer& Q = m->layers[j];
+      if (Q.d.kind != SPK_OP_CONV || !Q.pw_ok || Q.d.src != L.d.dst || Q.d.stride != 1 || Q.d.res >= 0 || Q.side_branch ||
+          (Q.d.cout != 64 && Q.d.cout != 128) || Q.chained_by >= 0)
+        continue;
+      L.chain_next = (int)j;
+      Q.chained_by = (int)i;
+      break;
+    }
+  }
+  if (const char* e = getenv("SPK_CHAIN")) m->chain = atoi(e);
   // per-channel means of every generic conv's input (zero_sum.hip): one flat vector, graph order
   for (Layer& L : m->layers) {
     if (L.d.kind != SPK_OP_CONV || L.mode != CONV_MODE_GENERIC) continue;
@@ -892,9 +907,119 @@ static bool dual_active(const spk_model* m, const Layer& L) {
          !m->side;
 }
 
+// eval: may the block-closing conv L also compute the conv that reads its output (single fp16 weight images only)?
+static bool chain_possible(const spk_model* m, const Layer& L) {
+  if (!m->chain || m->no_chain_now || L.chain_next < 0 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused || m->side)
+    return false;
+  const Layer& Q = m->layers[L.chain_next];
+  if (layer_split(m, L) || layer_split(m, Q)) return false;
+  if (L.dual_src >= 0 && !dual_active(m, L)) return false;   // (a shortcut conv that runs on its own: plain res operand)
+  return true;
+}
+
+// chained kernel or two kernels?  Timed once per problem (both give the same bits), "chain ..." lines of SPK_TUNE_CACHE
+#include <map>
+#include <mutex>
+#include <tuple>
+typedef std::tuple<int, int, int, int, int, int> ChainKey;   // H W Cin Cin2 Coutz N
+static std::map<ChainKey, int> g_chain_choice;
+static std::mutex g_chain_mu;
+static bool g_chain_loaded = false;
+
+static int run_conv_eval(spk_model* m, Layer& L, int nb);
+
+static int chain_choice(spk_model* m, Layer& L, const PwConvArgs& q, int nb) {
+  if (m->chain >= 2) return 1;
+  const ChainKey key(q.H, q.W, q.Cin, q.x2 ? q.Cin2 : 0, q.Coutz, q.N);
+  const char* path = getenv("SPK_TUNE_CACHE");
+  if (path && (!*path || !strcmp(path, "off"))) path = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    if (!g_chain_loaded) {
+      g_chain_loaded = true;
+      if (path)
+        if (FILE* f = fopen(path, "r")) {
+          char line[256];
+          int v[7];
+          while (fgets(line, sizeof line, f))
+            if (sscanf(line, "chain %d %d %d %d %d %d %d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7 && (v[6] == 0 || v[6] == 1))
+              g_chain_choice[ChainKey(v[0], v[1], v[2], v[3], v[4], v[5])] = v[6];
+          fclose(f);
+        }
+    }
+    auto it = g_chain_choice.find(key);
+    if (it != g_chain_choice.end()) return it->second;
+    for (const auto& kv : g_chain_choice) {   // a ragged tail batch: the choice of a tuned batch within a factor of two
+      ChainKey k2 = kv.first;
+      const int n2 = std::get<5>(k2);
+      std::get<5>(k2) = q.N;
+      if (k2 == key && n2 <= 2 * q.N && q.N <= 2 * n2) return kv.second;
+    }
+  }
+  const bool tune = !getenv("SPK_AUTOTUNE") || atoi(getenv("SPK_AUTOTUNE")) != 0;
+  int choice = 1;
+  float t_two = 0.f, t_one = 0.f;
+  hipEvent_t e0, e1;
+  if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    Layer& Q = m->layers[L.chain_next];
+    auto two = [&]() {
+      m->no_chain_now = true;
+      int r = run_conv_eval(m, L, nb);
+      if (r == SPK_OK) r = run_conv_eval(m, Q, nb);
+      m->no_chain_now = false;
+      return r;
+    };
+    bool ok = two() == SPK_OK && spk_pw_chain_launch(q, m->stream) == 0;   // warm-up (and the other kernels' own tuning)
+    if (ok) {
+      (void)hipEventRecord(e0, m->stream);
+      for (int r = 0; r < 3; ++r) (void)two();
+      (void)hipEventRecord(e1, m->stream);
+      ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t_two, e0, e1) == hipSuccess;
+    }
+    if (ok) {
+      (void)hipEventRecord(e0, m->stream);
+      for (int r = 0; r < 3; ++r) (void)spk_pw_chain_launch(q, m->stream);
+      (void)hipEventRecord(e1, m->stream);
+      ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t_one, e0, e1) == hipSuccess;
+    }
+    choice = ok && t_one < t_two ? 1 : 0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("SPK_TUNE_LOG"))
+      fprintf(stderr, "[spk tune chain] N%d %dx%d C%d+%d->256->%d: two kernels %.1f us, chained %.1f us\n", q.N, q.H, q.W, q.Cin,
+              q.x2 ? q.Cin2 : 0, q.Coutz, t_two * 1000.f / 3.f, t_one * 1000.f / 3.f);
+    std::lock_guard<std::mutex> lk(g_chain_mu);
+    g_chain_choice[key] = choice;
+    if (path)
+      if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "chain %d %d %d %d %d %d %d\n", q.H, q.W, q.Cin, q.x2 ? q.Cin2 : 0, q.Coutz, q.N, choice);
+        fclose(f);
+      }
+  }
+  return choice;
+}
+
+// fills the chained conv's fields of q; false: shapes the kernel does not cover
+static bool chain_args(spk_model* m, const Layer& L, PwConvArgs& q, int nb) {
+  const Layer& Q = m->layers[L.chain_next];
+  const TDim& zo = m->tdims[Q.d.dst];
+  const TDim& o = m->tdims[L.d.dst];
+  if (zo.h != o.h || zo.w != o.w || zo.c != Q.d.cout || Q.d.cin != L.d.cout) return false;
+  q.wpz = m->wpack + Q.wpw_off;
+  q.z = (bf16_t*)m->TI(Q.d.dst);
+  q.scalez = m->scale_bias + Q.sb_off;
+  q.shiftz = q.scalez + Q.cout_p;
+  q.Coutz = Q.d.cout;
+  q.reluz = Q.d.relu;
+  q.z_bytes = (unsigned)((size_t)nb * zo.h * zo.w * zo.c * 2);
+  return true;
+}
+
 static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
+  if (L.chained_by >= 0 && !m->no_chain_now && m->layers[L.chained_by].chained_now) return SPK_OK;   // done by that launch
+  if (L.chain_next >= 0 && !m->no_chain_now) L.chained_now = false;
   if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) {
     m->stale[L.d.dst] = 1;   // computed inside the block-closing conv's kernel; read_activation recomputes it on demand
     return SPK_OK;
@@ -954,6 +1079,14 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     q.x_bytes = a.x_bytes; q.y_bytes = (unsigned)((size_t)a.M * a.Cout * 2);
     q.x2 = (const bf16_t*)m->TI(D.d.src); q.Cin2 = D.d.cin; q.H2 = din.h; q.W2 = din.w; q.stride2 = D.d.stride;
     q.x2_bytes = (unsigned)((size_t)nb * din.h * din.w * din.c * 2);
+    if (chain_possible(m, L)) {
+      PwConvArgs qc = q;
+      if (chain_args(m, L, qc, nb) && chain_choice(m, L, qc, nb) == 1 && spk_pw_chain_launch(qc, m->stream) == 0) {
+        L.chained_now = true;
+        return SPK_OK;
+      }
+      (void)hipGetLastError();
+    }
     const int r = spk_conv1x1_dual_launch(q, m->stream);
     if (r == 0) return SPK_OK;
     if (r != -3) return fail(SPK_ERR_HIP, std::string("fused 1x1 conv launch failed for ") + L.d.name);
@@ -971,6 +1104,14 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     q.N = nb; q.H = in.h; q.W = in.w; q.Ho = o.h; q.Wo = o.w; q.stride = L.d.stride;
     q.Cin = a.Cin; q.Cout = a.Cout; q.M = a.M; q.relu = a.relu; q.dt = DT_F16; q.nb = a.splitw ? 2 : 1;
     q.x_bytes = a.x_bytes; q.y_bytes = (unsigned)((size_t)a.M * a.Cout * 2);
+    if (chain_possible(m, L) && q.res) {
+      PwConvArgs qc = q;
+      if (chain_args(m, L, qc, nb) && chain_choice(m, L, qc, nb) == 1 && spk_pw_chain_launch(qc, m->stream) == 0) {
+        L.chained_now = true;
+        return SPK_OK;
+      }
+      (void)hipGetLastError();
+    }
     if (spk_conv1x1_launch(a, q, m->stream))
       return fail(SPK_ERR_HIP, std::string("1x1 conv launch failed for ") + L.d.name);
     return SPK_OK;
@@ -1667,6 +1808,16 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
         fl += 2.0 * nb * o.h * o.w * (double)D.d.cout * D.d.cin;
         by = in_b + (double)nb * o.h * o.w * din.c * 2 + out_b + (double)L.d.cout * (L.d.cin + D.d.cin) * 2;
         snprintf(nm, sizeof nm, "%s+%s", L.d.name, D.d.name);
+      }
+      if (L.chained_by >= 0 && m->layers[L.chained_by].chained_now) by = fl = 0;   // computed by the block-closing conv's launch
+      if (L.chain_next >= 0 && L.chained_now) {   // ... which also read that conv's weights and wrote its output
+        const Layer& Q = m->layers[L.chain_next];
+        const TDim& zo = m->tdims[Q.d.dst];
+        fl += 2.0 * nb * zo.h * zo.w * (double)Q.d.cout * Q.d.cin;
+        by += (double)nb * zo.h * zo.w * zo.c * 2 + (double)Q.d.cout * Q.d.cin * 2;
+        char both[96];
+        snprintf(both, sizeof both, "%.60s>%.30s", nm, Q.d.name);
+        snprintf(nm, sizeof nm, "%s", both);
       }
       if (stem_pool_fused(m, L)) {   // the kernel writes the pooled tensor only
         const TDim& po = m->tdims[m->layers[L.fuse_pool].d.dst];

@@ -246,6 +246,41 @@ extern "C" int spk_op_conv1x1(const void* x, const float* w, const float* bn_sca
 }
 extern "C" int spk_op_conv1x1_num_configs(void) { return spk_pw_num_configs(); }
 
+// Two chained 1x1 convs in one launch (conv_pw.hip, PwConvArgs::wpz): y = act(BN(W . x) + res) with 256 couts, then
+// z = actz(BNz(Wz . y)) from the output tile in registers; single fp16 weight images.  What the eval path runs for a
+// bottleneck's block-closing conv and the next block's first conv.  SPK_ERR_UNSUPPORTED: no chained kernel for the shape.
+extern "C" int spk_op_conv1x1_chain(const void* x, const float* w, const float* bn_scale, const float* bn_bias, const void* res,
+                                    void* y, const float* wz, const float* bnz_scale, const float* bnz_bias, void* z, int n,
+                                    int h, int wd, int cin, int cout, int coutz, int relu, int reluz, void* stream) {
+  if (!x || !w || !bn_scale || !bn_bias || !res || !y || !wz || !bnz_scale || !bnz_bias || !z || n < 1 || h < 1 || wd < 1)
+    return ofail(SPK_ERR_ARG, "op_conv1x1_chain: bad arguments");
+  if (cin % 64 || cout % 64 || coutz % 32) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = n * h * wd;
+  if ((size_t)M * cin * 2 >= 0x80000000ull || (size_t)M * cout * 2 >= 0x80000000ull)
+    return ofail(SPK_ERR_UNSUPPORTED, "op_conv1x1_chain: an operand of 2 GiB or more");
+  Scratch sc, scz;
+  bf16_t* wp = sc.get<bf16_t>((size_t)cout * cin);
+  bf16_t* wpz = scz.get<bf16_t>((size_t)coutz * cout);
+  if (!wp || !wpz) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pack_pw(w, nullptr, wp, cout, cin, DT_F16, 1, s), "pack_pw");
+  O_TRY(spk_launch_pack_pw(wz, nullptr, wpz, coutz, cout, DT_F16, 1, s), "pack_pw");
+  PwConvArgs q;
+  memset(&q, 0, sizeof q);
+  q.x = (const bf16_t*)x; q.wp = wp; q.y = (bf16_t*)y; q.res = (const bf16_t*)res; q.scale = bn_scale; q.shift = bn_bias;
+  q.N = n; q.H = h; q.W = wd; q.Ho = h; q.Wo = wd; q.stride = 1; q.Cin = cin; q.Cout = cout; q.M = M;
+  q.relu = relu; q.dt = DT_F16; q.nb = 1;
+  q.x_bytes = (unsigned)((size_t)M * cin * 2);
+  q.y_bytes = (unsigned)((size_t)M * cout * 2);
+  q.wpz = wpz; q.z = (bf16_t*)z; q.scalez = bnz_scale; q.shiftz = bnz_bias; q.Coutz = coutz; q.reluz = reluz;
+  q.z_bytes = (unsigned)((size_t)M * coutz * 2);
+  const int r = spk_pw_chain_launch(q, s);
+  if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "no chained kernel for this problem");
+  if (r) return ofail(SPK_ERR_HIP, "chained conv1x1 launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "chained conv1x1 kernel failed");
+  return SPK_OK;
+}
+
 // 3x3 stride-1 pad-1 convolution + folded BatchNorm (+ReLU) of the eval path (conv_c3.hip) on caller-provided buffers;
 // cfg >= 0: that tile configuration (SPK_ERR_UNSUPPORTED when it does not fit), cfg < 0: the implicit-GEMM kernel.
 extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* bn_scale, const float* bn_bias,

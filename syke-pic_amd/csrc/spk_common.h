@@ -144,6 +144,16 @@ struct PwConvArgs {
   const bf16_t* x2;     // [N,H2,W2,Cin2]
   int Cin2, H2, W2, stride2;
   unsigned int x2_bytes;
+  // Chained second 1x1 conv (round 4): z = act2(BN2(W2 . y)) for the SAME pixels, computed from the output tile while it
+  // is still in registers - a bottleneck's block-closing conv and the next block's first conv as one kernel: the trunk
+  // tensor y is written (later shortcut adds need it) but never re-read by the conv that follows.  wpz == null: none.
+  // Needs the whole cout range in one block (resident flavour, n_tiles == 1) and single (nb == 1) weight images.
+  const bf16_t* wpz;    // [Cout -> Coutz] packed by spk_launch_pack_pw (nb = 1)
+  bf16_t* z;            // [N,Ho,Wo,Coutz]
+  const float* scalez;  // [Coutz]
+  const float* shiftz;
+  int Coutz, reluz;
+  unsigned int z_bytes;
 };
 int spk_pw_num_configs();
 // K-concatenation of two 1x1 convs that are added (w1 [Cout][Cin1] with eval-BN scale s1, w2 [Cout][Cin2] with s2):
@@ -157,6 +167,7 @@ int spk_launch_pw_dual_prep(const float* w1, const float* w2, const float* s1, c
 // -3: no configuration fits
 int spk_conv1x1_dual_launch(const PwConvArgs& q, hipStream_t s);
 int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s);   // -3: this config does not fit the problem
+int spk_pw_chain_launch(const PwConvArgs& a, hipStream_t s);      // with PwConvArgs::wpz; -3: no chained kernel for this problem
 int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout, int cin, int dt, int nb, hipStream_t s);
 // eval path: the faster of the implicit GEMM (a) and conv_pw (q) for this problem, tuned once and cached
 int spk_conv1x1_launch(const ConvArgs& a, const PwConvArgs& q, hipStream_t s);

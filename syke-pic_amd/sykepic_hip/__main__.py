@@ -35,7 +35,24 @@ def build_parser():
         pp.add_argument("-w", "--num-workers", type=int, default=2, metavar="INT", help="Default is 2")
         pp.add_argument("-f", "--force", action="store_true", help="Force overwrite of previous probabilities")
         pp.set_defaults(func=_prob)
+    # not in the reference: one-off preparation of a model directory for the calibrated single-pass mode
+    cp = sub.add_parser("calibrate", description="Measure activation means for a model directory (writes act_means.pth: "
+                                                 "`prob` then runs every convolution as one fp16 product)")
+    craw = cp.add_mutually_exclusive_group(required=True)
+    craw.add_argument("-r", "--raw", metavar="DIR", help="Root directory of raw IFCB data")
+    craw.add_argument("-s", "--samples", nargs="+", metavar="SAMPLE PATH", help="One or more sample paths")
+    craw.add_argument("--image-dir", metavar="DIR", help="Root directory of images")
+    craw.add_argument("--images", nargs="+", metavar="FILE", help="One or more image paths")
+    cp.add_argument("-m", "--model", required=True, help="Model directory")
+    cp.add_argument("-n", "--num-images", type=int, default=2048, metavar="INT", help="Images to measure on (default 2048)")
+    cp.add_argument("-b", "--batch-size", type=int, default=64, metavar="INT", help="Default is 64")
+    cp.set_defaults(func=_calibrate)
     return parser
+
+
+def _calibrate(args):
+    from . import prob
+    return prob.calibrate_call(args)
 
 
 def _train(args):

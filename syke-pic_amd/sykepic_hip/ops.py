@@ -184,6 +184,25 @@ def conv1x1(x, weight, bn_scale, bn_bias, stride=1, relu=True, res=None, split=T
     return y.permute(0, 3, 1, 2)
 
 
+def conv1x1_chain(x, weight, bn_scale, bn_bias, res, weight_z, bnz_scale, bnz_bias, relu=True, relu_z=True):
+    """Two chained 1x1 convs in one launch (spk_op_conv1x1_chain): returns (y [N,256,H,W], z [N,Coutz,H,W]) float16."""
+    so = lib.load()
+    dev = x.device
+    n, cin, h, w = x.shape
+    cout, coutz = weight.shape[0], weight_z.shape[0]
+    xh = x.half().permute(0, 2, 3, 1).contiguous()
+    rh = res.half().permute(0, 2, 3, 1).contiguous()
+    y = torch.full((n, h, w, cout), float("nan"), dtype=torch.float16, device=dev)
+    z = torch.full((n, h, w, coutz), float("nan"), dtype=torch.float16, device=dev)
+    f = lambda t: t.float().contiguous()   # noqa: E731
+    wk, wzk = f(weight.reshape(cout, cin)), f(weight_z.reshape(coutz, cout))
+    s1, b1, s2, b2 = f(bn_scale), f(bn_bias), f(bnz_scale), f(bnz_bias)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv1x1_chain(_p(xh), _p(wk), _p(s1), _p(b1), _p(rh), _p(y), _p(wzk), _p(s2), _p(b2), _p(z), n, h, w,
+                                          cin, cout, coutz, int(bool(relu)), int(bool(relu_z)), _stream(dev)))
+    return y.permute(0, 3, 1, 2), z.permute(0, 3, 1, 2)
+
+
 def conv3x3_num_configs():
     return int(lib.load().spk_op_conv3x3_num_configs())
 

@@ -180,7 +180,52 @@ def prepare_model(model_dir, device=None):
     device = torch.device(device or "cuda:0")
     net = get_network(config, len(classes), device=device, pretrained_ok=False)
     net.load_state_dict(torch.load(model_dir / "best_state.pth", map_location="cpu"))
+    use_act_means(net, model_dir)
     return net, classes, img_shape, eval_transform, device
+
+
+ACT_MEANS_FILE = "act_means.pth"   # next to best_state.pth: written by `sykepic train` / `sykepic calibrate`
+
+
+def use_act_means(net, model_dir):
+    """A model directory that carries activation means runs the calibrated single-pass mode (csrc/zero_sum.hip:
+    every conv one fp16 product, as accurate as hi + lo weights); one without them - every directory the reference
+    itself trained - runs the default split mode.  SYKEPIC_CALIBRATED=0 ignores the file."""
+    path = Path(model_dir) / ACT_MEANS_FILE
+    if os.environ.get("SYKEPIC_CALIBRATED", "1") == "0" or not path.is_file():
+        return False
+    try:
+        means = torch.load(path, map_location="cpu")
+        net.set_act_means(means["means"] if isinstance(means, dict) else means)
+        net.set_precision("calibrated")
+    except Exception as e:  # noqa: BLE001 - a stale or foreign file must not stop classification
+        log.warning(f"{path.name} does not fit this model ({e}); using the default precision mode")
+        net.set_act_means(None)
+        net.set_precision(split_weights=3)
+        return False
+    log.info(f"activation means from {path.name}: calibrated single-pass mode")
+    return True
+
+
+def save_act_means(net, model_dir, n_images):
+    torch.save({"means": net.act_means(), "images": int(n_images), "network": net.graph.network}, Path(model_dir) / ACT_MEANS_FILE)
+
+
+def calibrate_model(net, batches, max_images=2048):
+    """Accumulates the activation means over `batches` (tensors as `net.forward` takes them, or (x, ...) tuples) until
+    `max_images` have been seen.  Returns the number of images used."""
+    seen = 0
+    for batch in batches:
+        x = batch[0] if isinstance(batch, (tuple, list)) else batch
+        if seen + len(x) > max_images:
+            x = x[:max_images - seen]
+        if len(x) == 0:
+            break
+        net.calibrate(x, reset=seen == 0)
+        seen += len(x)
+        if seen >= max_images:
+            break
+    return seen
 
 
 def _batches(items, transform, batch_size):
@@ -432,6 +477,41 @@ def main(sample_paths, model_dir, out_dir, batch_size=64, num_workers=2, force=F
         if reader is not None:
             reader.shutdown(wait=True)
     return done
+
+
+def calibrate_call(args):
+    """`sykepic calibrate`: measure the activation means of an existing model directory on ROIs of the kind it will
+    classify (raw samples or PNG images, chosen as for `prob`) and store them as `act_means.pth` beside
+    `best_state.pth`.  From then on `sykepic prob -m <dir>` runs the calibrated single-pass mode."""
+    from . import files, ifcb, pngio
+    os.environ["SYKEPIC_CALIBRATED"] = "0"      # measure with the weights alone, whatever file is already there
+    net, classes, img_shape, transform, device = prepare_model(args.model)
+
+    def images():
+        if args.image_dir or args.images:
+            for p in (sorted(Path(args.image_dir).rglob("*.png")) if args.image_dir else [Path(q) for q in args.images]):
+                yield pngio.read_image(p, img_shape[0])
+        else:
+            for sp in (files.list_sample_paths(args.raw) if args.raw else [Path(q) for q in args.samples]):
+                for _, img in ifcb.read_rois(sp.with_suffix(".adc"), sp.with_suffix(".roi")):
+                    yield _as_chans(img, img_shape[0])
+
+    def batches():
+        chunk = []
+        for img in images():
+            chunk.append(transform(img))
+            if len(chunk) == args.batch_size:
+                yield torch.stack(chunk)
+                chunk = []
+        if chunk:
+            yield torch.stack(chunk)
+
+    n = calibrate_model(net, batches(), args.num_images)
+    if n == 0:
+        raise ValueError("no image to calibrate on")
+    save_act_means(net, args.model, n)
+    log.info(f"activation means of {n} images saved to {Path(args.model) / ACT_MEANS_FILE}")
+    return n
 
 
 def call(args):

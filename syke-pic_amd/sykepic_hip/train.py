@@ -143,6 +143,17 @@ def main(args):
     if dist is not None:
         dist.barrier()
     net.load_state_dict(torch.load(best_state, map_location="cpu"))
+    if chief:
+        # activation means of the best model on (this rank's share of) the validation images, stored beside
+        # best_state.pth: `sykepic prob` then runs the calibrated single-pass mode (prob.use_act_means)
+        from . import prob
+        try:
+            n_cal = prob.calibrate_model(net, model_data.val_loader, 2048)
+            if n_cal:
+                prob.save_act_means(net, model_dir, n_cal)
+                print(f"[INFO] Activation means of {n_cal} validation images saved to {prob.ACT_MEANS_FILE}")
+        except Exception as e:  # noqa: BLE001 - an optimisation of later inference, never a reason to lose the run
+            print(f"[INFO] No activation means stored ({e})")
     tests = ([(None, model_data.test_loader)] if test_split else []) + \
             ([(Path(external_test).name, extra_loader)] if external_test else [])
     for name, loader in tests if chief else []:

@@ -210,3 +210,39 @@ def test_calibrated_mode_with_the_fused_shortcut_conv(golden_dir):
         errs.append(float([ln for ln in out.stdout.splitlines() if ln.startswith("ERR")][0].split()[1]))
     print(f"fused shortcut conv on / off: {errs[0]:.2e} / {errs[1]:.2e}")
     assert max(errs) <= PROB_TOL
+
+
+def test_chained_convs_do_not_change_a_bit():
+    """Single-weight modes run a bottleneck's block-closing conv and the next block's first conv as one launch where that
+    is faster (csrc/conv_pw.hip, PwConvArgs::wpz).  Forced on (SPK_CHAIN=2) against off (SPK_CHAIN=0): identical logits,
+    in the calibrated and in the plain fp16 mode, at a batch that takes the two-stream path and at a ragged one."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path[:0] = [{str(root)!r}, {str(root / 'syke-pic_amd')!r}]\n"
+        "from sykepic_hip import arch, synth\n"
+        "from sykepic_hip.net import HipNet\n"
+        "g = arch.build_graph('resnet50', 50)\n"
+        "sd = synth.synth_state_dict(arch.param_specs(g), seed=2)\n"
+        "net = HipNet('resnet50', 50, weights=None)\n"
+        "net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); net.eval()\n"
+        "net.calibrate(torch.from_numpy(synth.synth_images(16, 3, 96, 96, seed=9000)).cuda())\n"
+        "for mode in ('calibrated', 0):\n"
+        "    net.set_precision(mode)\n"
+        "    for n in (70, 5):\n"
+        "        x = torch.from_numpy(synth.synth_images(n, 3, 96, 96, seed=5)).cuda()\n"
+        "        z = net.forward(x).cpu().numpy()\n"
+        "        z2 = net.forward(x).cpu().numpy()\n"
+        "        assert np.array_equal(z, z2)\n"
+        "        print('SHA', mode, n, hashlib.sha256(z.tobytes()).hexdigest())\n")
+    outs = []
+    for chain in ("2", "0"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPK_CHAIN=chain, SPK_TUNE_CACHE="off"),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append([ln for ln in out.stdout.splitlines() if ln.startswith("SHA")])
+    assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])

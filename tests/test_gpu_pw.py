@@ -91,3 +91,27 @@ def test_saturates_instead_of_overflowing():
     assert torch.isfinite(y).all() and float(y.max()) == 65504.0
     y = ops.conv1x1(x.to(dev), (-wgt).to(dev), torch.ones(64).to(dev), torch.zeros(64).to(dev), relu=False, cfg=9)
     assert torch.isfinite(y).all() and float(y.min()) == -65504.0
+
+
+@pytest.mark.parametrize("shape", [(2, 56, 56, 64, 64), (3, 20, 17, 64, 128), (1, 9, 7, 128, 64), (2, 28, 28, 128, 128),
+                                   (1, 1, 1, 64, 64)],
+                         ids=lambda s: "n%d_%dx%d_c%d-256-%d" % s)
+def test_chained_pair_equals_two_launches(shape):
+    """A block-closing conv (cout 256, + shortcut, ReLU) and the conv that reads its output as ONE launch: the trunk
+    tile goes from the epilogue's registers into the second product.  Both tensors are bit-identical to two stand-alone
+    launches of the kernel (same fp16 values in between, same K order), on ragged pixel counts too."""
+    from sykepic_hip import ops
+    n, h, w, cin, coutz = shape
+    dev = "cuda:0"
+    x, wgt, scale, bias, r, ref = _case(n, h, w, cin, 256, 1, True, True, seed=cin + coutz)
+    g = torch.Generator().manual_seed(coutz)
+    wz = (torch.rand(coutz, 256, generator=g) * 2 - 1) * (6.0 / 256) ** 0.5
+    sz, bz = 0.5 + torch.rand(coutz, generator=g), torch.rand(coutz, generator=g) - 0.5
+    y, z = ops.conv1x1_chain(x.to(dev), wgt.to(dev), scale.to(dev), bias.to(dev), r.to(dev), wz.to(dev), sz.to(dev), bz.to(dev))
+    y1 = ops.conv1x1(x.to(dev), wgt.to(dev), scale.to(dev), bias.to(dev), relu=True, res=r.to(dev), split=False, cfg=-1)
+    z1 = ops.conv1x1(y1, wz.to(dev), sz.to(dev), bz.to(dev), relu=True, split=False, cfg=-1)
+    assert torch.isfinite(y.float()).all() and torch.isfinite(z.float()).all()
+    assert torch.equal(y, y1)
+    assert torch.equal(z, z1)
+    err = (y.float().cpu() - ref).abs()
+    assert (err <= 8e-3 + 6e-3 * ref.abs()).all()

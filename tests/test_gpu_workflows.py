@@ -182,3 +182,20 @@ def test_train_main_end_to_end(tmp_path, capsys, network):
     ref.load_state_dict(sd)
     assert int(sd["base.1.num_batches_tracked" if network == "resnet18" else "base.0.0.1.num_batches_tracked"]) > 0
     assert "accuracy" in (mdir / "test_report.txt").read_text()
+    # the run leaves activation means of the validation images beside the checkpoint; `prob.prepare_model` picks them up
+    # (calibrated single-pass mode) and stays within the tolerance of the fp32 torch module on the trained weights
+    from sykepic_hip import prob
+    assert (mdir / prob.ACT_MEANS_FILE).is_file() and "Activation means" in out
+    net, classes, img_shape, ev, dev = prob.prepare_model(mdir)
+    assert classes == ["bars", "blob", "flat"]
+    imgs = sorted(ds.rglob("*.png"))[::3]
+    x = torch.stack([ev(np.repeat(np.array(Image.open(p))[:, :, None], 3, axis=2)) for p in imgs])
+    ref.eval()
+    pr = refnet.probabilities(ref, x).numpy()
+    p_cal = net.probabilities(x.cuda()).cpu().numpy()
+    net.set_precision(split_weights=1)
+    p_two = net.probabilities(x.cuda()).cpu().numpy()
+    e_cal, e_two = np.abs(p_cal - pr).max(), np.abs(p_two - pr).max()
+    print(f"{network} trained by train.main: calibrated max |dp| {e_cal:.2e}, every conv hi+lo {e_two:.2e}")
+    assert e_cal <= (1e-3 if network == "resnet18" else 4e-3)
+    assert (p_cal.argmax(1) == pr.argmax(1))[np.sort(pr, 1)[:, -1] - np.sort(pr, 1)[:, -2] > 2e-3].all()
