@@ -46,11 +46,11 @@ def parse():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=50)
     ap.add_argument("--mode", default="both", choices=["both", "infer", "train"])
-    ap.add_argument("--precision", default="mixed", choices=["calibrated", "mixed", "precise", "balanced", "fast", "bf16", "fp8"],
-                    help="calibrated: every conv but the stem as ONE fp16 product, weights zero-sum rounded against "
+    ap.add_argument("--precision", default=None, choices=["calibrated", "mixed", "precise", "balanced", "fast", "bf16", "fp8"],
+                    help="calibrated: every conv as ONE fp16 product, weights zero-sum rounded against "
                          "per-channel activation means measured on 32 calibration images that are not in the timed batch "
                          "(csrc/zero_sum.hip; as accurate as `precise`: tests/test_gpu_calibrated.py); "
-                         "mixed (library default without means): fp16 + hi/lo split weights on every conv except the 3x3 convs "
+                         "mixed (what a model directory without act_means.pth runs): fp16 + hi/lo split weights on every conv except the 3x3 convs "
                          "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tests/diagnostics/split_rules.py: "
                          "passes the 1e-3 parity tolerance); precise: split on every conv (5.9e-4); balanced: split "
                          "only the layers that write the residual trunk (1.3e-3 worst case); fast: plain fp16 "
@@ -59,7 +59,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.precision is None:
+        # the fastest mode that holds the parity tolerance: ResNets - calibrated single pass (tests/test_gpu_calibrated.py);
+        # EfficientNets - the fp16 split rule (their 1x1 convs wait for HBM: one weight pass or two makes no difference)
+        args.precision = "mixed" if args.network.startswith("efficientnet") else "calibrated"
+    return args
 
 
 # the sources the ResNet inference conv kernels (the roofline's dominant kernel) are built from AND the executor that

@@ -165,11 +165,12 @@ int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops)
  * logit error of a plain fp16 forward.  With per-channel means E[x_k] of every conv's input, each weight row (per filter
  * tap) is rounded to nearest and then the weights nearest a rounding midpoint are re-rounded until sum_k E[x_k] dw_k ~ 0
  * ("zero-sum rounding", csrc/zero_sum.hip): the mean error is gone at no run-time cost, the row's squared error grows
- * by < 1 %.  Mode 5 runs every conv as ONE fp16 product (the 7x7 stem alone keeps hi + lo) and needs the means:
+ * by < 1 %.  Mode 5 runs every conv as ONE fp16 product (the 7x7 stem too: its 147-weight rows are balanced as a whole
+ * against the image's own channel means) and needs the means:
  *   spk_model_calibrate_act_means - one batch of representative images (as spk_forward_infer takes them) through the
  *     most accurate mode; per-channel means of every conv input, accumulated over calls (reset != 0 starts over);
  *   spk_model_get_act_means / spk_model_set_act_means - the flat vector (spk_model_act_means_size floats: cin values
- *     per conv other than the stem, graph order) to store with the model and restore (`act_means.pth` next to
+ *     per conv, graph order) to store with the model and restore (`act_means.pth` next to
  *     `best_state.pth`); set with host == NULL forgets them;
  *   spk_model_set_zero_sum - apply the rounding to the un-split convs of ANY split mode (diagnostics).
  * A model's probabilities stay a function of (weights, means, image): nothing depends on the batch an image arrives in.
@@ -279,6 +280,19 @@ int spk_op_bn_backward(const void* g_dev, const unsigned char* mask_dev, const v
 /* Conv2d data gradient: dx [n,h,w,cin] (= or, accumulate != 0, +=) conv_transpose(dy [n,ho,wo,cout], w). */
 int spk_op_conv_dgrad(const void* dy_dev, const float* w_dev, void* dx_dev, int accumulate, int n, int h, int w,
                       int cin, int cout, int k, int stride, int pad, void* hip_stream);
+/* Data gradient of a STRIDE-1 conv + the BatchNorm backward of the layer that produced the conv's input, as a training step
+ * runs them since round 4: the dgrad epilogue makes that BatchNorm's per-channel sums (sum dz, sum dz * xhat) from the fp32
+ * gradient values it is about to store, so the producer's reduce pass is skipped (csrc/conv_igemm.hip, spk_set_bnb).
+ * dx (+)= conv_transpose(dy, w) [n,h,w,cin] bf16; raw / mask / mean / invstd / gamma describe the producer ([n,h,w,cin] bf16
+ * raw output, one ReLU bit per element, [cin] floats); dy_prod = gradient of the producer's raw output, dgamma / dbeta [cin].
+ * res_src / res_bits (both or neither, instead of accumulate): the shortcut gradient picked up at its source - dx =
+ * conv_transpose(dy, w) + res_src * bit, res_src [n,h,w,cin] bf16 = the output gradient of the block-closing conv whose
+ * shortcut this tensor is, res_bits its ReLU bits - so that its BatchNorm backward need not write it into dx first.
+ * Reference: loss.backward(), sykepic/train/train.py:242. */
+int spk_op_conv_dgrad_bn_backward(const void* dy, const float* w_ohwi, void* dx, int accumulate, const void* raw,
+                                  const unsigned char* mask, const float* mean, const float* invstd, const float* gamma,
+                                  float* dgamma, float* dbeta, void* dy_prod, int n, int h, int w, int cin, int cout, int k,
+                                  int pad, int relu, const void* res_src, const unsigned char* res_bits, void* stream);
 /* Conv2d weight gradient: dw [Cout][kh][kw][Cin] float32 from x [n,h,w,cin] and dy [n,ho,wo,cout]. */
 int spk_op_conv_wgrad(const void* x_dev, const void* dy_dev, float* dw_dev, int n, int h, int w, int cin, int cout,
                       int k, int stride, int pad, void* hip_stream);

@@ -222,8 +222,25 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
     G = {last: (logp.exp() - F.one_hot(y, logits.shape[1]).float()) / n}
     grads = {}
 
-    def put(t, val):  # first consumer writes, later ones add and round again
-        G[t] = rg(val) if t not in G else rg(G[t] + val)
+    # Since round 4 the HIP path takes a layer's BatchNorm-backward SUMS from the data-gradient kernel that completes the
+    # gradient of its output - when that kernel is a stride-1 conv dgrad and the last writer (no consumer of the tensor
+    # comes earlier in the graph) - i.e. from the float32 values before they are rounded for storage (csrc/conv_igemm.hip,
+    # spk_set_bnb); everything else (dy, the shortcut gradient) still reads the stored bf16 tensor.
+    G32 = {}
+    pre_round_sums = set()
+    for t in {o.dst for o in graph.ops if o.kind == arch.OP_CONV}:
+        users = [j for j, o in enumerate(graph.ops) if o.src == t or (o.kind == arch.OP_CONV and o.res == t)]
+        if users and graph.ops[min(users)].kind == arch.OP_CONV and graph.ops[min(users)].src == t \
+                and graph.ops[min(users)].stride == 1:
+            pre_round_sums.add(t)
+
+    def put(t, val, dgrad=False):  # first consumer writes, later ones add and round again
+        full = val if t not in G else G[t] + val
+        if dgrad:
+            G32[t] = full
+        else:
+            G32.pop(t, None)
+        G[t] = rg(full)
 
     for i in range(len(graph.ops) - 1, first_op - 1, -1):
         op = graph.ops[i]
@@ -251,15 +268,18 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
                 put(op.res, dz)
             m = dz.shape[0] * dz.shape[2] * dz.shape[3]
             xhat = (yr - mean.view(1, -1, 1, 1)) * invstd.view(1, -1, 1, 1)
-            s1 = dz.double().sum((0, 2, 3))
-            s2 = (dz * xhat).double().sum((0, 2, 3))
+            dzs = dz
+            if round_grads and op.dst in pre_round_sums and op.dst in G32:   # sums made by the dgrad epilogue
+                dzs = G32[op.dst] * pos if pos is not None else G32[op.dst]
+            s1 = dzs.double().sum((0, 2, 3))
+            s2 = (dzs * xhat).double().sum((0, 2, 3))
             grads[op.bn + ".bias"] = s1.float()
             grads[op.bn + ".weight"] = s2.float()
             c1, c2 = (s1 / m).float().view(1, -1, 1, 1), (s2 / m).float().view(1, -1, 1, 1)
             k3 = (state[op.bn + ".weight"] * invstd).view(1, -1, 1, 1)
             dy = rg(k3 * (dz - c1 - xhat * c2))
             if op.src != 0:
-                put(op.src, torch.nn.grad.conv2d_input(a.shape, wb, dy, op.stride, op.pad))
+                put(op.src, torch.nn.grad.conv2d_input(a.shape, wb, dy, op.stride, op.pad), dgrad=True)
             grads[op.name + ".weight"] = torch.nn.grad.conv2d_weight(a, wb.shape, dy, op.stride, op.pad)
         elif op.kind == arch.OP_DROPOUT and i in saved:
             G[op.src] = gy * saved[i] / (1.0 - op.p) if op.p < 1 else torch.zeros_like(gy)

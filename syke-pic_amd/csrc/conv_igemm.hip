@@ -42,6 +42,10 @@ __device__ __forceinline__ int src_swizzle(int row) {  // DMA lands lane l in sl
 template <int BM, int BN, int WARPS_M, int WARPS_N, int MODE, int DT, int SPLITW, int DMA, int PERSIST, int BKT = 64>
 __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_igemm_kernel(ConvArgs a, int m_tiles,
                                                                             int n_tiles) {
+  // DGRAD_BNB: the data gradient that also makes the BatchNorm-backward sums of the layer behind its output (spk_set_bnb).
+  // Its own instantiation: the operands it prefetches cost 16-36 VGPRs (one wave per SIMD on several tiles) that the
+  // plain data-gradient launches must not pay.
+  constexpr bool IS_DGRAD = MODE == CONV_MODE_DGRAD || MODE == CONV_MODE_DGRAD_BNB;
   // BKT: K elements per LDS stage.  32 halves the stage: twice the resident blocks per CU, whose load, operand-read
   // and MFMA phases (which add up within one block) then overlap across blocks.
   constexpr int BK = BKT;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   unsigned char* const sA = smem;                    // [nbuf][BM][128 B]   (DMA: stage s at s*STAGE_BYTES)
   unsigned char* const sB = smem + (DMA ? A_BYTES : nbuf * A_BYTES);   // [nbuf][NB*BN][128 B]
 
-  const bool cls = MODE == CONV_MODE_DGRAD && a.cls_ph >= 0;
+  const bool cls = IS_DGRAD && a.cls_ph >= 0;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,9 +119,9 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   const int HoWo = a.Ho * a.Wo;
   const int KT = a.kt_count > 0 ? a.kt_count * (64 / BK) : a.K / BK;  // kt_count is in 64-deep steps
   // scalar walk over (tap row r, tap col s, channel block c0) for generic mode
-  const int r_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_ph + a.pad) & 1) : 0;
-  const int s_first = (MODE == CONV_MODE_DGRAD && cls) ? ((a.cls_pw + a.pad) & 1) : 0;
-  const int tap_step = (MODE == CONV_MODE_DGRAD && cls) ? 2 : 1;
+  const int r_first = (IS_DGRAD && cls) ? ((a.cls_ph + a.pad) & 1) : 0;
+  const int s_first = (IS_DGRAD && cls) ? ((a.cls_pw + a.pad) & 1) : 0;
+  const int tap_step = (IS_DGRAD && cls) ? 2 : 1;
   int kr = r_first, ks_ = s_first, kc0 = 0;
   int wr = r_first, ws = s_first, wc0 = 0;  // tap walk of the weight tiles (dgrad)
 
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
         a_w0[i] = p0;
         a_base[i] = ((img * a.H + h0) * a.W + p0) * 4;
-      } else if (MODE == CONV_MODE_DGRAD) {
+      } else if (IS_DGRAD) {
         // rows are pixels of the forward conv's INPUT; the "input" tensor is dy.
         // tap (r,s) reads dy[(h+pad-r)/stride][(w+pad-s)/stride] when divisible.
         // stride 2 is decomposed by output parity (cls_ph, cls_pw): the GEMM rows
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         const unsigned off = ok ? (unsigned)((a_base[i] + (krow * a.W + 2 * qq) * 4) * 2) : 0x80000000u;
         put_a(rs, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
       }
-    } else if (MODE == CONV_MODE_DGRAD) {
+    } else if (IS_DGRAD) {
       const int sh = a.stride == 2 ? 1 : 0;
 #pragma unroll
       for (int i = 0; i < A_ITERS; ++i) {
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         DMA == 3 ? __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, live ? a.w_bytes : 0, 0x00020000) : rw;
     unsigned char* const dB = sB + stage * STAGE_BYTES + wave * (PIECE_ROWS * ROW_BYTES);
     int wk = kt * (BK * 2);
-    if (MODE == CONV_MODE_DGRAD) {
+    if (IS_DGRAD) {
       wk = ((wr * a.kw + ws) * a.Cin + wc0) * 2;
       wc0 += BK;
       if (wc0 >= a.Cin) {
@@ -513,6 +517,28 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    // dgrad with the BatchNorm-backward reduction of the layer that produced this tensor (spk_set_bnb): sc / bi hold
+    // that layer's batch mean / invstd of this lane's 8 channels, a.res_lo is its raw output, a.pool_y its ReLU bits
+    constexpr bool bnb = MODE == CONV_MODE_DGRAD_BNB;
+    // ... both requested for the whole tile up front: left at their point of use each 16-byte load waited out its own
+    // HBM round trip behind the accumulator staging (measured: the fused launches took back what the dropped pass saved)
+    u32x4_t rraw[PREFETCH_RES ? MT : 1][PREFETCH_RES ? PASSES : 1];
+    unsigned rbit[PREFETCH_RES ? MT : 1][PREFETCH_RES ? PASSES : 1];
+    unsigned rbit2[PREFETCH_RES ? MT : 1][PREFETCH_RES ? PASSES : 1];   // ReLU bits of the `res` operand (a.y_lo), see below
+    if (PREFETCH_RES && bnb) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+          const int m = em0 + wm * WM + i * 16 + erow + p * RPP;
+          const bool ok = m < a.M && (!PADC || gcol < cout_s);
+          const size_t o = ok ? out_pixel(m) * cout_s + gcol : 0;
+          rraw[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0] = ok ? *(const u32x4_t*)(a.res_lo + o) : u32x4_t{0, 0, 0, 0};
+          rbit[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0] = ok && a.pool_y ? ((const unsigned char*)a.pool_y)[o >> 3] : 0xffu;
+          rbit2[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0] = ok && a.y_lo ? ((const unsigned char*)a.y_lo)[o >> 3] : 0xffu;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -530,27 +556,56 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
       if (m < a.M && (!PADC || gcol < cout_s)) {
         const size_t o = out_pixel(m) * cout_s + gcol;
-        if (a.stats) {
+        if (a.stats && !bnb) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
         }
+        if (!bnb) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + bi[j];
+        }
         if (a.res) {
           const u32x4_t rr = PREFETCH_RES ? rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0]
                                           : *(const u32x4_t*)(a.res + o);
+          if (bnb && a.y_lo) {
+            // the `res` operand is the gradient of a LATER layer's output (a block-closing conv whose shortcut is this
+            // tensor) and a.y_lo that layer's ReLU bits: res * bit is what its BatchNorm backward would have written into
+            // this tensor first - that write (and this launch's read-modify-write of it) is skipped
+            const unsigned b2 = PREFETCH_RES ? rbit2[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0]
+                                             : ((const unsigned char*)a.y_lo)[o >> 3];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[2 * j] += (b2 >> (2 * j)) & 1u ? lo_f32<DT>(rr[j]) : 0.f;
+              v[2 * j + 1] += (b2 >> (2 * j + 1)) & 1u ? hi_f32<DT>(rr[j]) : 0.f;
+            }
+          } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             v[2 * j] += lo_f32<DT>(rr[j]);
             v[2 * j + 1] += hi_f32<DT>(rr[j]);
           }
-          if (a.res_lo) {  // rounding remainder of the shortcut tensor
+          }
+          if (a.res_lo && !bnb) {  // rounding remainder of the shortcut tensor
             const u32x4_t rl = *(const u32x4_t*)(a.res_lo + o);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               v[2 * j] += lo_f32<DT>(rl[j]);
               v[2 * j + 1] += hi_f32<DT>(rl[j]);
             }
+          }
+        }
+        if (bnb) {   // v = the complete gradient of this element (accumulated contributions included), still fp32
+          float rw[8];
+          const u32x4_t rq = PREFETCH_RES ? rraw[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0] : *(const u32x4_t*)(a.res_lo + o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { rw[2 * j] = lo_f32<DT>(rq[j]); rw[2 * j + 1] = hi_f32<DT>(rq[j]); }
+          const unsigned bits = PREFETCH_RES ? rbit[PREFETCH_RES ? i : 0][PREFETCH_RES ? p : 0]
+                                             : (a.pool_y ? ((const unsigned char*)a.pool_y)[o >> 3] : 0xffu);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float dz = (bits >> j) & 1u ? v[j] : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (rw[j] - sc[j]) * bi[j];
           }
         }
         if (a.relu == 1) {
@@ -564,7 +619,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
 #pragma unroll
         for (int j = 0; j < 4; ++j) ov[j] = pack2<DT>(v[2 * j], v[2 * j + 1]);
         *(u32x4_t*)(a.y + o) = ov;
-        if (a.y_lo) {  // what the 16-bit rounding dropped, for the next shortcut add
+        if (a.y_lo && !bnb) {  // what the 16-bit rounding dropped, for the next shortcut add
           u32x4_t lv;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -685,7 +740,10 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.dt == DT_F16) { if (a.splitw) SPK_GO(CONV_MODE_STEM, DT_F16, 1); SPK_GO(CONV_MODE_STEM, DT_F16, 0); }
     SPK_GO(CONV_MODE_STEM, DT_BF16, 0);
   }
-  if (mode == CONV_MODE_DGRAD) SPK_GO(CONV_MODE_DGRAD, DT_BF16, 0);
+  if (mode == CONV_MODE_DGRAD) {
+    if (a.stats) SPK_GO(CONV_MODE_DGRAD_BNB, DT_BF16, 0);
+    SPK_GO(CONV_MODE_DGRAD, DT_BF16, 0);
+  }
   if (a.dt == DT_F16 && (a.cin_s > 0 || a.cout_s > 0)) {
     // stored channels != padded GEMM channels: the three flavours instantiated with the channel checks
 #define SPK_GO_PAD(SW)                                                                                        \

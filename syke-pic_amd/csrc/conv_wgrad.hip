@@ -331,7 +331,11 @@ void spk_wgrad_plan(int M, int Cout, int Ktot, int* splits, int* pix_per_split) 
   const int bco = Cout % 128 == 0 ? 128 : 64;
   const int bci = 128;
   const int tiles = (Cout / bco) * ((Ktot + bci - 1) / bci);
-  static const int want = getenv("SPK_WGRAD_BLOCKS") ? atoi(getenv("SPK_WGRAD_BLOCKS")) : 1024;
+  // blocks per launch the split count aims at.  384 since round 4 (1024 before): every split writes a full [Cout][Ktot] fp32
+  // slab that the ordered reduce reads back - 3.0 GB + 3.0 GB per ResNet-50 step at 1024 - and the kernels run on their
+  // own low-priority stream beside the HBM-bound BatchNorm passes; measured step 23.10 (1024) / 22.93 (512) / 22.91 (384) /
+  // 22.90 ms (256)
+  static const int want = getenv("SPK_WGRAD_BLOCKS") ? atoi(getenv("SPK_WGRAD_BLOCKS")) : 384;
   int sp = (want + tiles - 1) / tiles;
   const int max_sp = (M + 511) / 512;
   if (sp > max_sp) sp = max_sp;

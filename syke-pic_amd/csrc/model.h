@@ -61,10 +61,9 @@ struct Layer {
                               // (gates only), 4 project conv (e4m3 in x gate, fp16 out)
   float amax_in = 0.f, amax_out = 0.f;   // max |x| of the input / output tensor on the calibration batch
   size_t w8_off = 0, s8_off = 0;         // e4m3 weights / [ws, epilogue scale] floats of this layer
-  bool side_branch = false;   // output is only ever a shortcut operand (downsample conv): may run beside the main branch
+  bool side_branch = false;   // output is only ever a shortcut operand (downsample conv): what the block-closing conv can absorb
   int fuse_pool = -1;         // stem conv: index of the 3x3/2 max-pool layer its eval kernel can absorb (conv_stem.hip), or -1
   bool pooled_by_stem = false;  // that max-pool layer
-  hipEvent_t join = nullptr;  // side branches: recorded on the side stream after the layer
 };
 
 struct TrainState;
@@ -73,8 +72,6 @@ struct spk_model {
   int device = 0;
   int in_chans = 3, num_classes = 0;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;  // second stream for the shortcut (downsample) convs of the eval forward
-  hipEvent_t fork = nullptr;
   // eval: the two halves of a batch on two streams (see spk_forward_eval_logits)
   hipStream_t half_stream = nullptr;
   hipEvent_t half_fork = nullptr, half_join = nullptr;
@@ -138,10 +135,14 @@ struct spk_model {
   float* s8 = nullptr;
   unsigned char* fp8_shadow = nullptr;  // fp8 mode: e4m3 copy of the trunk tensor the last project conv wrote (pw_fp8.hip)
   size_t fp8_shadow_bytes = 0;
-  int shadow_t = -1, shadow_stride = 0;  // ... its tensor id (-1: none valid) and row stride in bytes
-  int cur_dw_chunks = 0;             // pool-partial rows per image the depthwise layer that ran last wrote
-  const float* cur_gate = nullptr;   // gates of the squeeze-excitation op that ran last (consumed by the project conv)
-  int cur_gate_stride = 0;
+  // state one layer leaves for the next, per half-batch chain of the two-stream forward (index = spk_model::half)
+  int half = 0;                      // which of the two chains the executor is enqueueing (0: the caller's stream)
+  int dw_chunks_h[2] = {0, 0};       // pool-partial rows per image the depthwise layer that ran last wrote
+  const float* gate_h[2] = {nullptr, nullptr};   // gates of the squeeze-excitation op that ran last (consumed by the project conv)
+  int gate_stride_h[2] = {0, 0};
+  int shadow_t_h[2] = {-1, -1};      // fp8 mode: tensor id whose e4m3 copy the last project conv left (-1: none valid)
+  int shadow_stride_h[2] = {0, 0};   // ... and its row stride in bytes
+  size_t se_stride = 0;              // floats of squeeze-excitation scratch per image (the halves use disjoint slices)
   std::vector<float> t_fp8_scale;    // per tensor: 0 = 16-bit storage, else value = byte * scale
 
   // data-parallel overlap (spk_model_set_grad_ready_callback)
@@ -167,6 +168,13 @@ struct spk_model {
     const TDim& d = tdims[t];
     return (char*)arena + toff[t] + (size_t)img0 * d.h * d.w * d.c * (d.bf16 ? 2 : 4);
   }
+  // ... when it holds e4m3 bytes (fp8 mode: one byte per element in a slot sized for two)
+  void* TI8(int t) const {
+    const TDim& d = tdims[t];
+    return (char*)arena + toff[t] + (size_t)img0 * d.h * d.w * d.c;
+  }
+  // squeeze-excitation scratch of the chunk in work
+  float* SE() const { return (float*)((char*)arena + se_off) + (size_t)img0 * se_stride; }
   void* TLo(int t) const { return toff_lo[t] ? (char*)arena + toff_lo[t] : nullptr; }
 };
 
@@ -179,8 +187,23 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
 int spk_read_flat(spk_model* m, const float* flat, const Param& p, float* host);
 void spk_train_free(spk_model* m);
 // backward of one convolution (train.hip): shared by the training step and the single-operator test hooks
+// fuse: (stride 1 only) the BatchNorm-backward reduction of the layer that produced the tensor dx is the gradient of,
+// emitted by the dgrad epilogue (ConvArgs::bnb_raw); `tiles` returns the number of [2][cin] partial rows written
+struct BnbFuse {
+  const bf16_t* raw;
+  const unsigned char* mask;   // null: no ReLU behind that BatchNorm
+  const float* mean;
+  const float* invstd;
+  float* partials;
+  int tiles;
+  // optional: the shortcut gradient is taken from its source instead of from dx (dx is then overwritten, not accumulated):
+  // res_src = output gradient of the block-closing conv whose shortcut this tensor is, res_bits = that conv's ReLU bits
+  const bf16_t* res_src;
+  const unsigned char* res_bits;
+};
 int spk_conv_dgrad_all(const bf16_t* dy, const bf16_t* wdg, bf16_t* dx, bool accumulate, int n, int oh, int ow,
-                       int cout, int ih, int iw, int cin, int k, int stride, int pad, hipStream_t s);
+                       int cout, int ih, int iw, int cin, int k, int stride, int pad, hipStream_t s,
+                       BnbFuse* fuse = nullptr);
 size_t spk_conv_wgrad_slab_floats(int M, int cin, int cout, int k, bool stem);
 int spk_conv_wgrad_slabs(const bf16_t* x, const bf16_t* dy, float* slabs, int n, int ih, int iw, int cin, int oh,
                          int ow, int cout, int k, int stride, int pad, bool stem, hipStream_t s);

@@ -296,8 +296,8 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
   if (const char* e = getenv("SPK_CHAIN")) m->chain = atoi(e);
   // per-channel means of every generic conv's input (zero_sum.hip): one flat vector, graph order
   for (Layer& L : m->layers) {
-    if (L.d.kind != SPK_OP_CONV || L.mode != CONV_MODE_GENERIC) continue;
-    L.mu_off = m->n_means;
+    if (L.d.kind != SPK_OP_CONV || (L.mode != CONV_MODE_GENERIC && L.mode != CONV_MODE_STEM)) continue;
+    L.mu_off = m->n_means;   // (the 7x7 stem: the image's own channel means)
     m->n_means += (size_t)L.d.cin;
   }
   m->stale.assign(m->n_tensors, 0);
@@ -337,13 +337,9 @@ extern "C" void spk_model_destroy(spk_model* m) {
   if (m->w8pack) hipFree(m->w8pack);
   if (m->fp8_shadow) hipFree(m->fp8_shadow);
   if (m->s8) hipFree(m->s8);
-  if (m->side) hipStreamDestroy(m->side);
   if (m->half_stream) hipStreamDestroy(m->half_stream);
   if (m->half_fork) hipEventDestroy(m->half_fork);
   if (m->half_join) hipEventDestroy(m->half_join);
-  if (m->fork) hipEventDestroy(m->fork);
-  for (Layer& L : m->layers)
-    if (L.join) hipEventDestroy(L.join);
   spk_train_free(m);
   delete m;
 }
@@ -497,9 +493,9 @@ extern "C" int spk_model_set_seed(spk_model* m, uint64_t seed) {
 static int layer_split(const spk_model* m, const Layer& L) {
   if (m->infer_dt != DT_F16 || m->splitw == 0) return 0;
   if (m->splitw == 4) return m->split_mask[&L - m->layers.data()] ? 1 : 0;
-  // 5: only the stem (its input - raw pixels on a near-constant background - has hardly any variance around its mean,
-  // and its K = 147 gives zero-sum rounding the fewest weights to balance with); every other conv single pass
-  if (m->splitw == 5) return L.mode != CONV_MODE_GENERIC ? 1 : 0;
+  // 5: no conv at all - every fp16 weight image is zero-sum rounded instead (the 7x7 stem as whole rows against the
+  // image's channel means: raw pixels on a near-constant background are almost all mean)
+  if (m->splitw == 5) return 0;
   // 3: every conv except the 3x3 conv in the middle of a BOTTLENECK block, i.e. a 3x3 conv that neither writes the
   // trunk nor reads it (tests/diagnostics/split_rules.py: its weight rounding adds the least logit error per MFMA
   // cycle a lo-product costs).  The first 3x3 conv of a basic block (ResNet-18/34) reads the trunk and stays split:
@@ -513,7 +509,7 @@ static int layer_split(const spk_model* m, const Layer& L) {
 // is this conv's single fp16 weight image zero-sum rounded against the calibrated input means?
 static bool layer_zero_sum(const spk_model* m, const Layer& L) {
   return (m->zero_sum || m->splitw == 5) && m->have_means && m->infer_dt == DT_F16 && L.d.kind == SPK_OP_CONV &&
-         L.mode == CONV_MODE_GENERIC && !layer_split(m, L);
+         (L.mode == CONV_MODE_GENERIC || L.mode == CONV_MODE_STEM) && !layer_split(m, L);
 }
 
 // 3x3 RGB stem: master [cout][3][3][cin<=3] -> fp32 [9 taps][4][cout_p] (host repack: 1.3k floats, once per load)
@@ -561,8 +557,10 @@ int spk_commit(spk_model* m) {
     // group per (cout, tap), weighted with the input-channel means
     const float* wsrc = m->P(L.p_w);
     if (layer_zero_sum(m, L)) {
-      if (spk_launch_zero_sum_round(wsrc, m->act_mean_dev + L.mu_off, wround, (size_t)L.d.cout * L.d.k * L.d.k, L.d.cin,
-                                    L.d.cin, m->stream))
+      // (the stem's 3-channel taps are too short to balance one by one: its 147-weight rows as a whole)
+      const bool whole = L.mode == CONV_MODE_STEM;
+      if (spk_launch_zero_sum_round(wsrc, m->act_mean_dev + L.mu_off, wround, (size_t)L.d.cout * (whole ? 1 : L.d.k * L.d.k),
+                                    whole ? L.d.k * L.d.k * L.d.cin : L.d.cin, L.d.cin, m->stream))
         return fail(SPK_ERR_HIP, std::string("zero-sum rounding launch failed for ") + L.d.name);
       wsrc = wround;
     }
@@ -698,7 +696,7 @@ extern "C" int spk_model_set_fp8_blocks(spk_model* m, const unsigned char* flags
   m->fp8_blocks.assign(flags, flags + n_blocks);
   m->fp8_calibrated = false;     // roles are assigned by the next calibration
   m->fp8_packed = false;
-  m->shadow_t = -1;
+  m->shadow_t_h[0] = m->shadow_t_h[1] = -1;
   return SPK_OK;
 }
 
@@ -860,8 +858,10 @@ int spk_plan(spk_model* m, int n, int h, int w, bool pad) {
   for (const Layer& L : m->layers) {
     if (L.d.kind != SPK_OP_SE) continue;
     const TDim& d = m->tdims[L.d.src];
-    se_floats = std::max(se_floats, (size_t)n * ((64 + 1) * d.c + L.d.k));
+    se_floats = std::max(se_floats, (size_t)((64 + 1) * d.c + L.d.k));
   }
+  m->se_stride = se_floats;   // per image: a chunk of images [img0, img0 + nb) works in its own slice
+  se_floats *= (size_t)n;
   m->se_off = total;
   total += align256(se_floats * 4);
   m->logits_off = total;
@@ -903,13 +903,12 @@ static bool stem_pool_fused(const spk_model* m, const Layer& L) {
 
 // eval: does the block-closing conv L absorb its shortcut conv in this forward?
 static bool dual_active(const spk_model* m, const Layer& L) {
-  return m->fuse_ds && L.dual_src >= 0 && L.dual_ok && m->infer_dt == DT_F16 && !m->precise_res && !m->force_unfused &&
-         !m->side;
+  return m->fuse_ds && L.dual_src >= 0 && L.dual_ok && m->infer_dt == DT_F16 && !m->precise_res && !m->force_unfused;
 }
 
 // eval: may the block-closing conv L also compute the conv that reads its output (single fp16 weight images only)?
 static bool chain_possible(const spk_model* m, const Layer& L) {
-  if (!m->chain || m->no_chain_now || L.chain_next < 0 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused || m->side)
+  if (!m->chain || m->no_chain_now || L.chain_next < 0 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused)
     return false;
   const Layer& Q = m->layers[L.chain_next];
   if (layer_split(m, L) || layer_split(m, Q)) return false;
@@ -1027,8 +1026,8 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   if (L.d.dst < (int)m->stale.size()) m->stale[L.d.dst] = 0;
   if (L.mode == CONV_MODE_STEM3) {
     const float* sc = m->scale_bias + L.sb_off;
-    if (spk_launch_stem3x3((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                           (bf16_t*)m->T(L.d.dst), nb, in.h, in.w, in.w, o.h, o.w, L.d.cout, L.cout_p, L.d.relu,
+    if (spk_launch_stem3x3((const bf16_t*)m->TI(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                           (bf16_t*)m->TI(L.d.dst), nb, in.h, in.w, in.w, o.h, o.w, L.d.cout, L.cout_p, L.d.relu,
                            m->infer_dt, m->stream))
       return fail(SPK_ERR_HIP, std::string("stem launch failed for ") + L.d.name);
     return SPK_OK;
@@ -1201,10 +1200,13 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
       const float ys = fp8_scale_of(L.amax_out);
       m->t_fp8_scale[L.d.dst] = ys;
       // the trunk as e4m3 bytes when the previous block's project conv left them (same bytes as converting here)
-      const bool shadow = m->shadow_t == L.d.src && m->fp8_shadow;
-      if (spk_launch_pw_fp8(shadow ? (const void*)m->fp8_shadow : m->T(L.d.src), shadow ? 1 : 0, m->w8pack + L.w8_off,
-                            m->T(L.d.dst), 1, nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p, nullptr, 0, in.h * in.w,
-                            nb * o.h * o.w, kpad, L.cout_p, shadow ? m->shadow_stride : in.c, o.c, L.d.relu,
+      const bool shadow = m->shadow_t_h[m->half] == L.d.src && m->fp8_shadow;
+      // (the shadow holds the images of this chunk at its own row stride)
+      const void* xsrc = shadow ? (const void*)(m->fp8_shadow + (size_t)m->img0 * in.h * in.w * m->shadow_stride_h[m->half])
+                                : m->TI(L.d.src);
+      if (spk_launch_pw_fp8(xsrc, shadow ? 1 : 0, m->w8pack + L.w8_off,
+                            m->TI8(L.d.dst), 1, nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p, nullptr, 0, in.h * in.w,
+                            nb * o.h * o.w, kpad, L.cout_p, shadow ? m->shadow_stride_h[m->half] : in.c, o.c, L.d.relu,
                             1.f / fp8_scale_of(L.amax_in), 1.f / ys, m->stream))
         return fail(SPK_ERR_HIP, std::string("fp8 expand conv launch failed for ") + L.d.name);
       return SPK_OK;
@@ -1212,41 +1214,41 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
     case 2: {   // depthwise on e4m3; pool partials for the squeeze-excitation gate as in the fp16 kernel
       const float ys = fp8_scale_of(L.amax_out);
       m->t_fp8_scale[L.d.dst] = ys;
-      float* partial = (float*)((char*)m->arena + m->se_off);
+      float* partial = m->SE();
       const float s_in = fp8_scale_of(L.amax_in);
       const int chunks[2] = {spk_dw_chunks(nb, o.h * ((o.w + 1) / 2), in.c),
                              spk_dwconv_lds_chunks(1, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride)};
       auto run = [&](int v) {
         if (v)
           return spk_launch_dwconv_lds(
-              1, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst), partial, nb, in.h, in.w, in.c,
+              1, m->TI8(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->TI8(L.d.dst), partial, nb, in.h, in.w, in.c,
               o.h, o.w, L.d.k, L.d.stride, L.d.relu, s_in, 1.f / ys, m->stream);
-        return spk_launch_dwconv_fp8((const unsigned char*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                                     (unsigned char*)m->T(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k,
+        return spk_launch_dwconv_fp8((const unsigned char*)m->TI8(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                                     (unsigned char*)m->TI8(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k,
                                      L.d.stride, L.d.relu, chunks[0], s_in, 1.f / ys, m->stream);
       };
       const int v = dw_choose(1, nb, in.h, in.w, in.c, L.d.k, L.d.stride, m->stream, run, chunks);
-      m->cur_dw_chunks = chunks[v];
+      m->dw_chunks_h[m->half] = chunks[v];
       if (run(v) != 0)
         return fail(SPK_ERR_HIP, std::string("fp8 depthwise launch failed for ") + L.d.name);
       return SPK_OK;
     }
     case 3: {   // squeeze-excitation: the gates only; the project conv multiplies them into its A operand
-      float* partial = (float*)((char*)m->arena + m->se_off);
-      const int chunks = m->cur_dw_chunks;
+      float* partial = m->SE();
+      const int chunks = m->dw_chunks_h[m->half];
       float* gate = partial + (size_t)nb * chunks * in.c;
       if (spk_launch_se(nullptr, nullptr, partial, chunks, gate, m->P(L.p_w), m->P(L.p_b), m->dwpack + L.wpack_off,
                         m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k, DT_F16, m->stream))
         return fail(SPK_ERR_HIP, std::string("squeeze-excitation launch failed for ") + L.d.name);
-      m->cur_gate = gate;
-      m->cur_gate_stride = in.c;
+      m->gate_h[m->half] = gate;
+      m->gate_stride_h[m->half] = in.c;
       m->t_fp8_scale[L.d.dst] = 0.f;   // not materialised
       return SPK_OK;
     }
     default: {  // 4 project: A = the depthwise output (e4m3) x gate; fp16 trunk out (+ shortcut)
       int se_src = -1;
       for (const Layer& S : m->layers) if (S.fp8_role == 3 && S.d.dst == L.d.src) se_src = S.d.src;
-      if (se_src < 0 || !m->cur_gate) return fail(SPK_ERR_STATE, "fp8 project conv without its squeeze-excitation gate");
+      if (se_src < 0 || !m->gate_h[m->half]) return fail(SPK_ERR_STATE, "fp8 project conv without its squeeze-excitation gate");
       const TDim& e = m->tdims[se_src];
       const int kpad = (L.d.cin + 63) / 64 * 64;
       // the next block's expand conv reads this output: leave it an e4m3 copy (one buffer, re-used block after block -
@@ -1254,7 +1256,7 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
       unsigned char* y8 = nullptr;
       int y8_stride = 0;
       float y8_inv = 0.f;
-      m->shadow_t = -1;
+      m->shadow_t_h[m->half] = -1;
       const char* sh_env = getenv("SPK_FP8_SHADOW");   // 0: the expand convs convert the fp16 trunk themselves (same result)
       for (const Layer& E : m->layers)
         if (E.fp8_role == 1 && E.d.src == L.d.dst && !(sh_env && atoi(sh_env) == 0)) {
@@ -1268,16 +1270,16 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
             HIP_TRY(hipMalloc((void**)&m->fp8_shadow, need));
             m->fp8_shadow_bytes = need;
           }
-          y8 = m->fp8_shadow;
+          y8 = m->fp8_shadow + (size_t)m->img0 * o.h * o.w * y8_stride;
           y8_inv = 1.f / fp8_scale_of(E.amax_in);
           break;
         }
-      if (spk_launch_pw_fp8(m->T(se_src), 1, m->w8pack + L.w8_off, m->T(L.d.dst), 0,
-                            L.d.res >= 0 ? (const bf16_t*)m->T(L.d.res) : nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p,
-                            m->cur_gate, m->cur_gate_stride, e.h * e.w, nb * o.h * o.w, kpad, L.cout_p, e.c, o.c, L.d.relu,
+      if (spk_launch_pw_fp8(m->TI8(se_src), 1, m->w8pack + L.w8_off, m->TI(L.d.dst), 0,
+                            L.d.res >= 0 ? (const bf16_t*)m->TI(L.d.res) : nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p,
+                            m->gate_h[m->half], m->gate_stride_h[m->half], e.h * e.w, nb * o.h * o.w, kpad, L.cout_p, e.c, o.c, L.d.relu,
                             1.f, 1.f, m->stream, y8, y8_stride, y8_inv))
         return fail(SPK_ERR_HIP, std::string("fp8 project conv launch failed for ") + L.d.name);
-      if (y8) { m->shadow_t = L.d.dst; m->shadow_stride = y8_stride; }
+      if (y8) { m->shadow_t_h[m->half] = L.d.dst; m->shadow_stride_h[m->half] = y8_stride; }
       m->t_fp8_scale[L.d.dst] = 0.f;
       return SPK_OK;
     }
@@ -1292,7 +1294,7 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
     case SPK_OP_CONV: return run_conv_eval(m, L, nb);
     case SPK_OP_DWCONV: {
       const float* sc = m->scale_bias + L.sb_off;
-      float* partial = (float*)((char*)m->arena + m->se_off);
+      float* partial = m->SE();
       // the pool partial sums of the squeeze-excitation gate that follows are a by-product
       const bool f16 = m->infer_dt == DT_F16;
       const int chunks[2] = {spk_dw_chunks(nb, o.h * ((o.w + 3) / 4), in.c),
@@ -1300,14 +1302,14 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       auto run = [&](int v) {
         if (v)
           return spk_launch_dwconv_lds(
-              0, m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->T(L.d.dst), partial, nb, in.h, in.w, in.c,
+              0, m->TI(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p, m->TI(L.d.dst), partial, nb, in.h, in.w, in.c,
               o.h, o.w, L.d.k, L.d.stride, L.d.relu, 1.f, 1.f, m->stream);
-        return spk_launch_dwconv((const bf16_t*)m->T(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
-                                 (bf16_t*)m->T(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride,
+        return spk_launch_dwconv((const bf16_t*)m->TI(L.d.src), m->dwpack + L.wpack_off, sc, sc + L.cout_p,
+                                 (bf16_t*)m->TI(L.d.dst), partial, nb, in.h, in.w, in.c, o.h, o.w, L.d.k, L.d.stride,
                                  L.d.relu, m->infer_dt, m->stream);
       };
       const int v = dw_choose(0, nb, in.h, in.w, in.c, L.d.k, L.d.stride, m->stream, run, chunks);
-      m->cur_dw_chunks = chunks[v];
+      m->dw_chunks_h[m->half] = chunks[v];
       if (run(v) != 0)
         return fail(SPK_ERR_UNSUPPORTED, std::string("depthwise conv launch failed (fp16 eval only) for ") + L.d.name);
       return SPK_OK;
@@ -1317,10 +1319,10 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       bool from_dw = false;
       for (const Layer& Q : m->layers) from_dw |= (Q.d.kind == SPK_OP_DWCONV && Q.d.dst == L.d.src);
       if (!from_dw) return fail(SPK_ERR_UNSUPPORTED, "squeeze-excitation must follow a depthwise conv");
-      float* partial = (float*)((char*)m->arena + m->se_off);
-      const int chunks = m->cur_dw_chunks;   // as the depthwise launch that just ran
+      float* partial = m->SE();
+      const int chunks = m->dw_chunks_h[m->half];   // as the depthwise launch that just ran
       float* scale = partial + (size_t)nb * chunks * in.c;
-      if (spk_launch_se((const bf16_t*)m->T(L.d.src), (bf16_t*)m->T(L.d.dst), partial, chunks, scale, m->P(L.p_w),
+      if (spk_launch_se((const bf16_t*)m->TI(L.d.src), (bf16_t*)m->TI(L.d.dst), partial, chunks, scale, m->P(L.p_w),
                         m->P(L.p_b), m->dwpack + L.wpack_off, m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,
                         m->infer_dt, m->stream))
         return fail(SPK_ERR_UNSUPPORTED, std::string("squeeze-excitation launch failed (fp16 eval only) for ") + L.d.name);
@@ -1350,88 +1352,14 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
   return fail(SPK_ERR_UNSUPPORTED, "unknown layer kind");
 }
 
-// All layers of one eval forward.  Shortcut convs fork onto the side stream (they only need the block input,
-// which every earlier launch on the main stream has produced) and join before the conv that adds their output:
-// Measured (ResNet-50, batch 256, round 2): 5.40 ms with the fork against 5.30 ms on one stream - the branches
-// already keep several blocks per CU resident and the two grids only contend - so it is OFF unless
-// SPK_SIDE_STREAM=1 asks for it.
-// Prefix micro-batching: the leading layers whose tensors exceed the 256 MiB Infinity Cache at the full batch (ResNet-50,
-// batch 256: stem, max-pool and the 56^2 stage, 103-411 MB per tensor) run chunk by chunk of `mb` images, so that a
-// chunk's tensors (13-51 MB at 32 images) are still on die when the next layer reads them; the deeper layers, whose
-// tensors fit anyway and whose M is small, keep the full batch (chunking THEM costs tile fill).  Only plain conv /
-// max-pool layers without remainder tensors qualify.  SPK_PREFIX_MB=<images> (0 = off), SPK_PREFIX_BYTES=<bytes>.
-// Measured (round 2, ResNet-50 batch 256): 5.62 ms with 32-image chunks, 5.57 ms with 64, against 5.51 ms without:
-// the stage-1 layers already stream at 4.1-4.5 TB/s and the cache does not serve them faster, so it stays OFF.
-static int prefix_layers(const spk_model* m, int nb, int* mb_out) {
-  static const int mb_env = getenv("SPK_PREFIX_MB") ? atoi(getenv("SPK_PREFIX_MB")) : 0;
-  static const double limit = getenv("SPK_PREFIX_BYTES") ? atof(getenv("SPK_PREFIX_BYTES")) : 128e6;
-  *mb_out = mb_env;
-  if (mb_env <= 0 || nb <= mb_env || m->precise_res || m->fp8) return 0;
-  int p = 0;
-  for (const Layer& L : m->layers) {
-    if (L.d.kind != SPK_OP_CONV && L.d.kind != SPK_OP_MAXPOOL) break;
-    if (L.d.kind == SPK_OP_CONV && L.mode == CONV_MODE_STEM3) break;
-    const TDim& o = m->tdims[L.d.dst];
-    if ((double)nb * o.h * o.w * o.c * 2 < limit) break;
-    ++p;
-  }
-  // a chunked layer may only read tensors produced inside the prefix (or the input image)
-  for (int i = 0; i < p; ++i) {
-    const Layer& L = m->layers[i];
-    auto inside = [&](int t) {
-      if (t <= 0) return true;
-      for (int j = 0; j < p; ++j) if (m->layers[j].d.dst == t) return true;
-      return false;
-    };
-    if (!inside(L.d.src) || (L.d.res >= 0 && !inside(L.d.res))) return 0;
-  }
-  return p;
-}
-
+// All layers of one eval forward, in graph order on the handle's stream.  (Two round-2 experiments lived here behind
+// environment switches and are gone since round 4, both measured slower on ResNet-50 at batch 256 - DESIGN.md section 5:
+// the shortcut convs of a block forked onto a side stream, 5.40 vs 5.30 ms; the leading layers run in 32-64 image chunks so
+// that their tensors stay in the 256 MiB Infinity Cache, 5.57-5.62 vs 5.51 ms.)
 static int run_layers_eval(spk_model* m, int nb) {
-  static const bool two = getenv("SPK_SIDE_STREAM") && atoi(getenv("SPK_SIDE_STREAM")) != 0;
   m->last_eval_nb = nb;
-  m->shadow_t = -1;
-  bool any = false;
-  for (const Layer& L : m->layers) any |= L.side_branch;
-  if (!two || !any) {
-    int mb = 0;
-    const int p = prefix_layers(m, nb, &mb);
-    if (p > 0) {
-      for (int i0 = 0; i0 < nb; i0 += mb) {
-        m->img0 = i0;
-        for (int i = 0; i < p; ++i) {
-          const int r = spk_run_layer_eval(m, m->layers[i], std::min(mb, nb - i0));
-          if (r != SPK_OK) { m->img0 = 0; return r; }
-        }
-      }
-      m->img0 = 0;
-    }
-    for (size_t i = (size_t)p; i < m->layers.size(); ++i) SPK_TRY(spk_run_layer_eval(m, m->layers[i], nb));
-    return SPK_OK;
-  }
-  if (!m->side) {
-    HIP_TRY(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&m->fork, hipEventDisableTiming));
-  }
-  hipStream_t main_s = m->stream;
-  for (Layer& L : m->layers) {
-    if (L.side_branch) {
-      if (!L.join) HIP_TRY(hipEventCreateWithFlags(&L.join, hipEventDisableTiming));
-      HIP_TRY(hipEventRecord(m->fork, main_s));
-      HIP_TRY(hipStreamWaitEvent(m->side, m->fork, 0));
-      m->stream = m->side;
-      const int r = spk_run_layer_eval(m, L, nb);
-      m->stream = main_s;
-      if (r != SPK_OK) return r;
-      HIP_TRY(hipEventRecord(L.join, m->side));
-      continue;
-    }
-    if (L.d.kind == SPK_OP_CONV && L.d.res >= 0)
-      for (const Layer& Q : m->layers)
-        if (Q.side_branch && Q.d.dst == L.d.res && Q.join) HIP_TRY(hipStreamWaitEvent(main_s, Q.join, 0));
-    SPK_TRY(spk_run_layer_eval(m, L, nb));
-  }
+  m->shadow_t_h[0] = m->shadow_t_h[1] = -1;
+  for (size_t i = 0; i < m->layers.size(); ++i) SPK_TRY(spk_run_layer_eval(m, m->layers[i], nb));
   return SPK_OK;
 }
 
@@ -1463,10 +1391,8 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
   // forks before the first layer and joins after the last.  Per-image results do not depend on the split.  Measured
   // (ResNet-50, batch 256): 4.52 -> 4.29 ms.  SPK_EVAL_STREAMS=1 keeps one stream.
   static const int n_streams = getenv("SPK_EVAL_STREAMS") ? atoi(getenv("SPK_EVAL_STREAMS")) : 2;
-  static const bool side_env = getenv("SPK_SIDE_STREAM") && atoi(getenv("SPK_SIDE_STREAM")) != 0;
-  if (n_streams >= 2 && !m->effnet && !m->fp8 && !m->precise_res && !side_env && n >= 64 && n <= mb) {
-    int pmb = 0;
-    if (prefix_layers(m, n, &pmb) == 0) {
+  if (n_streams >= 2 && !m->precise_res && n >= 64 && n <= mb) {
+    {
       if (!m->half_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&m->half_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&m->half_fork, hipEventDisableTiming));
@@ -1483,7 +1409,7 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
       HIP_TRY(hipEventRecord(m->half_fork, main_s));
       HIP_TRY(hipStreamWaitEvent(m->half_stream, m->half_fork, 0));
       m->last_eval_nb = n;
-      m->shadow_t = -1;
+      m->shadow_t_h[0] = m->shadow_t_h[1] = -1;
       int rc = SPK_OK;
       for (int hf = 0; hf < 2 && rc == SPK_OK; ++hf) {
         m->img0 = off[hf];
@@ -1496,8 +1422,10 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
         for (int hf = 0; hf < 2 && rc == SPK_OK; ++hf) {
           m->img0 = off[hf];
           m->stream = str[hf];
+          m->half = hf;   // what a layer leaves for the next one of ITS chain (pool-partial rows, gates, e4m3 shadow)
           rc = spk_run_layer_eval(m, m->layers[i], cnt[hf]);
         }
+      m->half = 0;
       for (int hf = 0; hf < 2 && rc == SPK_OK; ++hf) {
         m->img0 = off[hf];
         m->stream = str[hf];
@@ -1575,9 +1503,10 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
   if (m->infer_dt != DT_F16) return fail(SPK_ERR_STATE, "calibrate_act_means needs the fp16 eval path");
   if (m->n_means == 0) return fail(SPK_ERR_UNSUPPORTED, "the graph has no convolution to calibrate");
   HIP_TRY(hipSetDevice(m->device));
-  std::vector<int> gen;   // generic convs, graph order
+  std::vector<int> gen;   // generic convs and the 7x7 stem, graph order
   for (size_t i = 0; i < m->layers.size(); ++i)
-    if (m->layers[i].d.kind == SPK_OP_CONV && m->layers[i].mode == CONV_MODE_GENERIC) gen.push_back((int)i);
+    if (m->layers[i].d.kind == SPK_OP_CONV && (m->layers[i].mode == CONV_MODE_GENERIC || m->layers[i].mode == CONV_MODE_STEM))
+      gen.push_back((int)i);
   if (reset || m->cal_sum.size() != m->n_means) {
     m->cal_sum.assign(m->n_means, 0.0);
     m->cal_rows.assign(gen.size(), 0.0);
@@ -1589,11 +1518,11 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
   int rc = spk_commit(m);
   if (rc == SPK_OK) rc = spk_plan(m, n, h, w);
   float *part = nullptr, *mean_dev = nullptr;
-  std::vector<float> host(m->n_means);
+  std::vector<float> host(m->n_means + 8);
   if (rc == SPK_OK) {
     int cmax = 8;
     for (int li : gen) cmax = std::max(cmax, m->tdims[m->layers[li].d.src].c);
-    if (hipMalloc((void**)&part, (size_t)256 * cmax * 4) != hipSuccess || hipMalloc((void**)&mean_dev, m->n_means * 4) != hipSuccess)
+    if (hipMalloc((void**)&part, (size_t)256 * cmax * 4) != hipSuccess || hipMalloc((void**)&mean_dev, (m->n_means + 8) * 4) != hipSuccess)
       rc = fail(SPK_ERR_HIP, "hipMalloc(calibration scratch) failed");
   }
   const int mb = micro_batch(m, n);
@@ -1612,13 +1541,21 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
     for (size_t gi = 0; gi < gen.size() && rc == SPK_OK; ++gi) {
       const Layer& L = m->layers[gen[gi]];
       const TDim& in = m->tdims[L.d.src];
+      if (L.mode == CONV_MODE_STEM) {
+        // the NHWC4 input image (row pitch padded to an even width with zero pixels): pixel PAIRS as rows of 8 values, into
+        // the 8 spare floats behind the vector; folded to per-channel means on the host below
+        if (spk_launch_chan_mean((const bf16_t*)m->T(0), part, mean_dev + m->n_means, (size_t)nb * in.h * in.w / 2, 8,
+                                 m->infer_dt, m->stream))
+          rc = fail(SPK_ERR_HIP, "channel-mean launch failed");
+        continue;
+      }
       if (in.c != L.d.cin || !in.bf16) { rc = fail(SPK_ERR_UNSUPPORTED, std::string("calibration: unexpected input layout at ") + L.d.name); break; }
       if (spk_launch_chan_mean((const bf16_t*)m->T(L.d.src), part, mean_dev + L.mu_off, (size_t)nb * in.h * in.w, in.c,
                                m->infer_dt, m->stream))
         rc = fail(SPK_ERR_HIP, "channel-mean launch failed");
     }
     if (rc != SPK_OK) break;
-    if (hipMemcpyAsync(host.data(), mean_dev, m->n_means * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
+    if (hipMemcpyAsync(host.data(), mean_dev, (m->n_means + 8) * 4, hipMemcpyDeviceToHost, m->stream) != hipSuccess ||
         hipStreamSynchronize(m->stream) != hipSuccess) {
       rc = fail(SPK_ERR_HIP, "reading the calibration means failed");
       break;
@@ -1626,6 +1563,13 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
     for (size_t gi = 0; gi < gen.size(); ++gi) {
       const Layer& L = m->layers[gen[gi]];
       const TDim& in = m->tdims[L.d.src];
+      if (L.mode == CONV_MODE_STEM) {   // mean over the w real pixels of a row: the pair means carry the zero pad pixel
+        const double rows = (double)nb * in.h * w, fix = (double)in.w / (double)w;
+        for (int c = 0; c < L.d.cin; ++c)
+          m->cal_sum[L.mu_off + c] += 0.5 * ((double)host[m->n_means + c] + (double)host[m->n_means + 4 + c]) * fix * rows;
+        m->cal_rows[gi] += rows;
+        continue;
+      }
       const double rows = (double)nb * in.h * in.w;
       for (int c = 0; c < L.d.cin; ++c) m->cal_sum[L.mu_off + c] += (double)host[L.mu_off + c] * rows;
       m->cal_rows[gi] += rows;
@@ -1641,7 +1585,7 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
     const Layer& L = m->layers[gen[gi]];
     for (int c = 0; c < L.d.cin; ++c) host[L.mu_off + c] = (float)(m->cal_sum[L.mu_off + c] / m->cal_rows[gi]);
   }
-  return spk_model_set_act_means(m, host.data(), (int64_t)host.size());
+  return spk_model_set_act_means(m, host.data(), (int64_t)m->n_means);
 }
 
 extern "C" int spk_forward_infer(spk_model* m, const void* x, int n, int h, int w, int layout,

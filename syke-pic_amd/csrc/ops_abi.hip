@@ -114,6 +114,43 @@ extern "C" int spk_op_conv_dgrad(const void* dy, const float* w_ohwi, void* dx, 
   return SPK_OK;
 }
 
+// Data gradient of a stride-1 conv whose epilogue also makes the BatchNorm-backward sums of the layer that PRODUCED the
+// conv's input (conv_igemm.hip, spk_set_bnb), followed by that layer's finalize + apply with the reduce pass skipped:
+// the launches a training step makes for (consumer conv dgrad, producer BatchNorm backward).  dx (+)= conv_transpose(dy, w)
+// is the gradient g of the producer's output; raw / mask / mean / invstd / gamma are the producer's; dy_prod receives the
+// gradient of the producer's raw conv output, dgamma / dbeta its parameter gradients.
+extern "C" int spk_op_conv_dgrad_bn_backward(const void* dy, const float* w_ohwi, void* dx, int accumulate, const void* raw,
+                                             const unsigned char* mask, const float* mean, const float* invstd,
+                                             const float* gamma, float* dgamma, float* dbeta, void* dy_prod, int n, int h,
+                                             int w, int cin, int cout, int k, int pad, int relu, const void* res_src,
+                                             const unsigned char* res_bits, void* stream) {
+  if (!dy || !w_ohwi || !dx || !raw || !mean || !invstd || !gamma || !dy_prod || n < 1 || (relu && !mask))
+    return ofail(SPK_ERR_ARG, "op_conv_dgrad_bn_backward: bad arguments");
+  if (cin % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int oh = h + 2 * pad - k + 1, ow = w + 2 * pad - k + 1, M = n * h * w;
+  Scratch sc;
+  bf16_t* wdg = sc.get<bf16_t>((size_t)cin * k * k * cout);
+  float* part = sc.get<float>((size_t)((M + 60) / 61) * 2 * cin);
+  float* coef = sc.get<float>((size_t)3 * cin);
+  float* tmp = sc.get<float>((size_t)cin * 2 * 64);
+  if (!wdg || !part || !coef || !tmp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pack_dgrad(w_ohwi, wdg, cout, k * k, cin, s), "pack_dgrad");
+  BnbFuse fz;
+  fz.raw = (const bf16_t*)raw; fz.mask = relu ? mask : nullptr; fz.mean = mean; fz.invstd = invstd; fz.partials = part; fz.tiles = 0;
+  fz.res_src = (const bf16_t*)res_src; fz.res_bits = res_bits;
+  if ((res_src != nullptr) != (res_bits != nullptr) || (res_src && accumulate))
+    return ofail(SPK_ERR_ARG, "op_conv_dgrad_bn_backward: res_src and res_bits go together and replace accumulate");
+  const int r = spk_conv_dgrad_all((const bf16_t*)dy, wdg, (bf16_t*)dx, accumulate != 0, n, oh, ow, cout, h, w, cin, k, 1, pad,
+                                   s, &fz);
+  if (r != SPK_OK) return r;
+  if (fz.tiles < 1) return ofail(SPK_ERR_HIP, "the dgrad launch reported no partial rows");
+  O_TRY(spk_launch_bn_bwd((const bf16_t*)dx, mask, (const bf16_t*)raw, mean, invstd, gamma, part, coef, dgamma, dbeta,
+                          (bf16_t*)dy_prod, nullptr, 0, M, cin, relu, tmp, s, fz.tiles), "bn_bwd");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "op_conv_dgrad_bn_backward: kernel failed");
+  return SPK_OK;
+}
+
 extern "C" int spk_op_conv_wgrad(const void* x, const void* dy, float* dw_ohwi, int n, int h, int w, int cin, int cout,
                                  int k, int stride, int pad, void* stream) {
   if (!x || !dy || !dw_ohwi || n < 1) return ofail(SPK_ERR_ARG, "op_conv_wgrad: bad arguments");

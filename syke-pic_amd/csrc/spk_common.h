@@ -80,7 +80,8 @@ template <int DT> __device__ __forceinline__ f32x4_t mfma16(const u32x4_t a, con
 //   minor), activations NHWC bf16, weights [Cout][K] bf16.
 // Epilogue: v = acc*scale[c] + bias[c] (+ residual) (ReLU) -> bf16.
 // ---------------------------------------------------------------------------
-enum { CONV_MODE_GENERIC = 0, CONV_MODE_STEM = 1, CONV_MODE_DGRAD = 2, CONV_MODE_STEM3 = 3 /* 3x3/2 direct stem */ };
+enum { CONV_MODE_GENERIC = 0, CONV_MODE_STEM = 1, CONV_MODE_DGRAD = 2, CONV_MODE_STEM3 = 3 /* 3x3/2 direct stem */,
+       CONV_MODE_DGRAD_BNB = 4 /* kernel-internal: DGRAD + the BatchNorm-backward sums of the producer (spk_set_bnb) */ };
 
 struct ConvArgs {
   const bf16_t* x;      // [N,H,W,Cin]   (stem mode: Cin stored = 4)
@@ -111,7 +112,28 @@ struct ConvArgs {
   // (y is not written).  Needs relu, no stats.
   bf16_t* pool_y;
   int pool_ho, pool_wo;
+  // DGRAD mode with `stats` set (round 4): the tensor this launch completes, y = dL/d(activation t), is the input of the
+  // BatchNorm backward of the layer P that produced t, and the epilogue also emits P's reduction - per row tile the
+  // per-channel sums of dz = y * relu_mask and dz * xhat into `stats` ([m_tiles][2][Cout], the layout of the forward
+  // statistics), from the fp32 values BEFORE they are rounded to 16 bits: P's stand-alone reduce pass (one more read of y
+  // and of P's raw output) is not launched.  A data gradient has no BatchNorm fold, remainder tensors or pooling, so the
+  // operands travel in those fields (the struct - and with it every forward kernel's code - stays as it was):
+  //   scale = P's batch mean [Cout], bias = 1/sqrt(var + eps) [Cout], res_lo = P's raw conv output [N,Ho,Wo,Cout],
+  //   pool_y = ReLU bits of P's output, one per element (null: no ReLU);
+  //   y_lo (optional) = ReLU bits that mask the `res` operand: res is then the output gradient of the block-closing conv
+  //   whose shortcut this tensor is, and res * bit the shortcut gradient its BatchNorm backward did not write.
+  //   See spk_set_bnb().
 };
+
+static inline void spk_set_bnb(ConvArgs& a, float* partials, const bf16_t* raw, const unsigned char* relu_bits,
+                               const float* mean, const float* invstd, const unsigned char* res_bits = nullptr) {
+  a.stats = partials;
+  a.scale = mean;
+  a.bias = invstd;
+  a.res_lo = raw;
+  a.pool_y = (bf16_t*)relu_bits;
+  a.y_lo = (bf16_t*)res_bits;
+}
 
 // returns 0 on success; fills *m_tiles with the number of row tiles used
 // (needed to size/finalize the stats partials)
@@ -298,10 +320,12 @@ int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift,
                         bf16_t* a, unsigned char* mask, size_t numel, int C, int relu, hipStream_t s);
 int spk_bn_bwd_blocks(int M, int C, int* rows_per_block);
 // `mask`: one ReLU bit per element ([M][C/8] bytes) written by spk_launch_bn_apply
+// pre_blocks > 0: `partials` already holds pre_blocks rows of [2][C] sums (written by the dgrad epilogue that produced g,
+// ConvArgs::bnb_raw): the reduce pass is skipped
 int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* mask, const bf16_t* y, const float* mean,
                       const float* invstd, const float* gamma, float* partials, float* coef,
                       float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
-                      int C, int relu, float* tmp, hipStream_t s);
+                      int C, int relu, float* tmp, hipStream_t s, int pre_blocks = 0);
 int spk_launch_maxpool_idx(const bf16_t* x, bf16_t* y, unsigned char* idx, int n, int h, int w, int c,
                            int k, int stride, int pad, int ho, int wo, hipStream_t s);
 int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* gx, int n, int h, int w,

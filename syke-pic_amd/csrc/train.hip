@@ -79,6 +79,7 @@ struct TrainState {
   int cap_n = 0, cap_h = 0, cap_w = 0;
   std::vector<size_t> goff;   // gradient tensor per activation id
   size_t dy_off = 0, idx_off = 0, part_off = 0, coef_off = 0, slab_off = 0, tmp_off = 0;
+  size_t fpart_off = 0;    // BatchNorm-backward partial sums written by the dgrad epilogue of the consumer layer
   size_t se_tmp_off = 0;   // squeeze-excitation scratch shared by the layers (pool partials, gate / hidden gradients)
   // Weight gradients on a second stream (ResNets): wgrad(i) needs only the layer's input activation and dy(i), so it runs
   // beside dgrad(i) and the HBM-bound BatchNorm backward of the next layer instead of in front of them.  dy is double
@@ -271,6 +272,7 @@ static int plan_train(spk_model* m, int n, int h, int w) {
   t->dy_off = total;      total += al256(max_conv);
   t->dy2_off = total;     total += al256(max_conv);
   t->part_off = total;    total += al256(max_part * 4);
+  t->fpart_off = total;   total += al256(max_part * 4);
   t->coef_off = total;    total += al256(max_c * 3 * 4);
   t->tmp_off = total;     total += al256(max_c * 2 * 64 * 4);
   t->slab_off = total;    total += al256(max_slab * 4);
@@ -374,14 +376,19 @@ static void fill_conv(ConvArgs& a, const bf16_t* x, const bf16_t* w, bf16_t* y, 
 // ---------------------------------------------------------------------------
 // dx (+)= conv_transpose(dy, w): dy [n,oh,ow,cout], wdg = the [Cin][kh][kw][Cout] bf16 image, dx [n,ih,iw,cin]
 int spk_conv_dgrad_all(const bf16_t* dy, const bf16_t* wdg, bf16_t* dx, bool accumulate, int n, int oh, int ow,
-                       int cout, int ih, int iw, int cin, int k, int stride, int pad, hipStream_t s) {
+                       int cout, int ih, int iw, int cin, int k, int stride, int pad, hipStream_t s, BnbFuse* fuse) {
   ConvArgs a;
   fill_conv(a, dy, wdg, dx, n, oh, ow, cout, ih, iw, cin, k, stride, pad, k * k * cout);
   a.res = accumulate ? (const bf16_t*)dx : nullptr;
   if (stride == 1) {
-    K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, nullptr), "conv dgrad");
+    if (fuse) {
+      spk_set_bnb(a, fuse->partials, fuse->raw, fuse->mask, fuse->mean, fuse->invstd, fuse->res_src ? fuse->res_bits : nullptr);
+      if (fuse->res_src) a.res = fuse->res_src;
+    }
+    K_TRY(spk_conv_launch(a, CONV_MODE_DGRAD, s, fuse ? &fuse->tiles : nullptr), "conv dgrad");
     return SPK_OK;
   }
+  if (fuse) return tfail(SPK_ERR_ARG, "the fused BatchNorm reduction needs a single-launch (stride 1) data gradient");
   if (stride != 2) return tfail(SPK_ERR_UNSUPPORTED, "conv stride must be 1 or 2 on the training path");
   // one launch per output parity class; a class that no tap can reach (1x1 stride 2: three of four) is all zeros
   bool need_zero = false;
@@ -635,6 +642,56 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
   };
   for (const Layer& Q : m->layers)
     needs[Q.d.dst] = trainable(Q) || needs[Q.d.src] || (Q.d.kind == SPK_OP_CONV && Q.d.res >= 0 && needs[Q.d.res]);
+  // BatchNorm-backward reductions that ride on the data-gradient kernel of the consumer (conv_igemm.hip, bnb_raw): when the
+  // stride-1 dgrad of layer i is the LAST writer of dL/dt (no consumer of t comes earlier in the graph) and t is the output
+  // of conv layer P, its epilogue holds the complete fp32 gradient and emits P's per-channel sums; P's own reduce pass -
+  // one more read of the gradient and of P's raw output - is skipped.  fused_tiles[P] = partial rows waiting in `fpart`.
+  // SPK_BNB_FUSE: bit 0 = 1x1 consumers that accumulate into a trunk gradient, bit 1 = other 1x1 consumers, bit 2 = 3x3
+  // consumers; 0 = never (every BatchNorm backward runs its own reduce pass).  Default 3, measured per category on one box
+  // (ResNet-50 step, ms): none 23.54 | trunk 23.11 | other 1x1 23.48 | 3x3 23.77 | trunk + other 1x1 23.07 | all 23.11 -
+  // the trunk tensors are where the dropped pass is large (4 of a block's 6 tensor units) and the 1x1 data gradient short;
+  // a 3x3 data gradient is MFMA-bound with one block per CU, and the longer epilogue costs more than the pass it replaces
+  static const int bnb_mask = getenv("SPK_BNB_FUSE") ? atoi(getenv("SPK_BNB_FUSE")) : 3;
+  const bool bnb_on = bnb_mask != 0;
+  std::vector<int> fused_tiles(nl, 0);
+  // deferred[t] = i: the block-closing conv i did NOT write its shortcut gradient dz into dL/dt; the fused data gradient of
+  // t's other consumer (the block's first 1x1 conv) reads dz from its source - conv i's output gradient and ReLU bits - and
+  // writes the complete tensor once (one write and one read of every identity-block trunk gradient less)
+  static const bool defer_on = !getenv("SPK_BNB_DEFER") || atoi(getenv("SPK_BNB_DEFER")) != 0;
+  std::vector<int> deferred(m->n_tensors, -1);
+  int fpart_owner = -1;
+  float* fpart = (float*)((char*)t->arena + t->fpart_off);
+  auto fuse_target = [&](int i) -> int {   // producer layer whose reduction dgrad(i) can carry, or -1
+    const Layer& L = m->layers[i];
+    if (!bnb_on || m->effnet || L.d.stride != 1 || fpart_owner >= 0) return -1;
+    const int cat = L.d.k == 1 ? (has_grad[L.d.src] || deferred[L.d.src] >= 0 ? 1 : 2) : 4;
+    if (!(bnb_mask & cat)) return -1;
+    int prod = -1;
+    for (int q = 0; q < i; ++q) {
+      const Layer& Q = m->layers[q];
+      if (Q.d.src == L.d.src || (Q.d.kind == SPK_OP_CONV && Q.d.res == L.d.src)) return -1;   // an earlier consumer writes later
+      if (Q.d.dst == L.d.src) prod = q;
+    }
+    if (prod < 0 || m->layers[prod].d.kind != SPK_OP_CONV || m->layers[prod].d.relu > 1) return -1;
+    return prod;
+  };
+  // may block-closing conv i leave its shortcut gradient to the data gradient of the tensor's other consumer?
+  auto can_defer = [&](int i) -> bool {
+    const Layer& L = m->layers[i];
+    if (!defer_on || !(bnb_mask & 1) || m->effnet || L.d.res < 0 || !L.d.relu || has_grad[L.d.res] || !needs[L.d.res]) return false;
+    const int tr = L.d.res;
+    int other = -1, count = 0, prod = -1;
+    for (int q = 0; q < nl; ++q) {
+      const Layer& Q = m->layers[q];
+      if (Q.d.dst == tr) prod = q;
+      if (Q.d.src == tr || (Q.d.kind == SPK_OP_CONV && Q.d.res == tr)) { ++count; if (q != i) other = q; }
+    }
+    if (count != 2 || other < 0 || other > i || prod < 0 || prod > other) return false;
+    const Layer& Q = m->layers[other];
+    const Layer& P = m->layers[prod];
+    return Q.d.kind == SPK_OP_CONV && Q.mode == CONV_MODE_GENERIC && Q.d.src == tr && Q.d.k == 1 && Q.d.stride == 1 &&
+           P.d.kind == SPK_OP_CONV && P.d.relu <= 1;
+  };
   int cur_bucket = 0;
   for (int i = nl - 1; i >= 0; --i) {
     Layer& L = m->layers[i];
@@ -688,6 +745,11 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         const Param& pg = m->params[L.p_g];
         const Param& pb = m->params[L.p_b];
         bf16_t* g_res = L.d.res >= 0 && needs[L.d.res] ? (bf16_t*)t->G(L.d.res) : nullptr;
+        const bool defer = L.d.kind == SPK_OP_CONV && g_res && can_defer(i);
+        if (defer) {   // the shortcut gradient is picked up at its source by the data gradient that completes dL/d(res)
+          g_res = nullptr;
+          deferred[L.d.res] = i;
+        }
         float* dgam = pg.requires_grad ? t->gbuf + pg.off : nullptr;
         float* dbet = pb.requires_grad ? t->gbuf + pb.off : nullptr;
         int slot = 0;
@@ -698,8 +760,11 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           if (t->dy_busy[slot]) HIP_TRY(hipStreamWaitEvent(s, t->ev_dy_free[slot], 0));
         }
         if (!m->effnet) {
-          K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st, st + C, m->P(L.p_g), part, coef,
-                                  dgam, dbet, dy, g_res, g_res ? has_grad[L.d.res] : 0, M, C, L.d.relu, tmp, s), "bn bwd");
+          const int pre = fused_tiles[i];   // sums already made by the dgrad that completed this layer's output gradient
+          K_TRY(spk_launch_bn_bwd((const bf16_t*)t->G(L.d.dst), t->MASK(i), t->RAW(i), st, st + C, m->P(L.p_g),
+                                  pre ? fpart : part, coef, dgam, dbet, dy, g_res, g_res ? has_grad[L.d.res] : 0, M, C,
+                                  L.d.relu, tmp, s, pre), "bn bwd");
+          if (pre) { fused_tiles[i] = 0; fpart_owner = -1; }
         } else {
           const float* rs = t->conv[i].rs_off ? (const float*)((char*)t->arena + t->conv[i].rs_off) : nullptr;
           const bf16_t* g = (const bf16_t*)t->G(L.d.dst);
@@ -750,8 +815,31 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         }
         if (L.d.src != 0 && needs[L.d.src]) {
           // data gradient: implicit GEMM over the dgrad weight image (stride 2: one launch per parity class)
+          const int pi = fuse_target(i);
+          const int dsrc = deferred[L.d.src];
+          if (dsrc >= 0 && pi < 0)
+            return tfail(SPK_ERR_STATE, std::string("deferred shortcut gradient of ") + m->layers[dsrc].d.name + " has no fused data gradient to land in");
+          BnbFuse fz;
+          fz.res_src = nullptr;
+          fz.res_bits = nullptr;
+          if (pi >= 0) {
+            const Layer& P = m->layers[pi];
+            float* stp = t->stats + t->conv[pi].stat_off;
+            fz.raw = t->RAW(pi);
+            fz.mask = P.d.relu ? t->MASK(pi) : nullptr;
+            fz.mean = stp;
+            fz.invstd = stp + in.c;
+            fz.partials = fpart;
+            fz.tiles = 0;
+            if (dsrc >= 0) {
+              fz.res_src = (const bf16_t*)t->G(m->layers[dsrc].d.dst);
+              fz.res_bits = t->MASK(dsrc);
+              deferred[L.d.src] = -1;
+            }
+          }
           SPK_TRY(spk_conv_dgrad_all(dy, t->wpack + t->conv[i].wdg_off, (bf16_t*)t->G(L.d.src), has_grad[L.d.src] != 0, n,
-                                     o.h, o.w, C, in.h, in.w, in.c, L.d.k, L.d.stride, L.d.pad, s));
+                                     o.h, o.w, C, in.h, in.w, in.c, L.d.k, L.d.stride, L.d.pad, s, pi >= 0 ? &fz : nullptr));
+          if (pi >= 0 && fz.tiles > 0) { fused_tiles[pi] = fz.tiles; fpart_owner = pi; }
           mark(m, PH_CONV_DGRAD);
           has_grad[L.d.src] = 1;
         }

@@ -685,15 +685,19 @@ int spk_bn_bwd_blocks(int M, int C, int* rows_per_block) {
 int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* a, const bf16_t* y, const float* mean,
                       const float* invstd, const float* gamma, float* partials, float* coef,
                       float* dgamma, float* dbeta, bf16_t* dy, bf16_t* g_res, int res_accumulate, int M,
-                      int C, int relu, float* tmp, hipStream_t s) {
+                      int C, int relu, float* tmp, hipStream_t s, int pre_blocks) {
   int rpb;
   int nb = spk_bn_bwd_blocks(M, C, &rpb);
-  static const bool tiled = !getenv("SPK_BN_CTILES") || atoi(getenv("SPK_BN_CTILES")) != 0;   // 0: one tile (round 2)
-  const int c8 = C / 8, cts = tiled ? (c8 + 31) / 32 : 1, tile = (c8 + cts - 1) / cts;
-  const int tpr = tile < 256 ? tile : 256;
-  const size_t lds = (size_t)(256 / tpr) * 2 * tile * 8 * sizeof(float);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, cts), dim3(256), lds, s, g, a, y, mean, invstd, partials,
-                     M, C, relu, rpb);
+  if (pre_blocks > 0) {
+    nb = pre_blocks;   // the sums came with the gradient (conv_igemm.hip dgrad epilogue)
+  } else {
+    static const bool tiled = !getenv("SPK_BN_CTILES") || atoi(getenv("SPK_BN_CTILES")) != 0;   // 0: one tile (round 2)
+    const int c8 = C / 8, cts = tiled ? (c8 + 31) / 32 : 1, tile = (c8 + cts - 1) / cts;
+    const int tpr = tile < 256 ? tile : 256;
+    const size_t lds = (size_t)(256 / tpr) * 2 * tile * 8 * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, cts), dim3(256), lds, s, g, a, y, mean, invstd, partials,
+                       M, C, relu, rpb);
+  }
   const float* fin = presum(partials, &nb, C, tmp, s);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, fin, nb, C,
                      (double)M, gamma, invstd, dgamma, dbeta, coef);

@@ -75,6 +75,7 @@ SYMBOLS = {
     "spk_model_get_act_means": (C.c_int, [_P, _P, C.c_int64]),
     "spk_model_set_act_means": (C.c_int, [_P, _P, C.c_int64]),
     "spk_model_set_zero_sum": (C.c_int, [_P, C.c_int]),
+    "spk_op_conv_dgrad_bn_backward": (C.c_int, [_P, _P, _P, C.c_int] + [_P] * 8 + [C.c_int] * 8 + [_P, _P, _P]),
     "spk_op_conv1x1_chain": (C.c_int, [_P] * 10 + [C.c_int] * 8 + [_P]),
     "spk_op_zero_sum_round": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "spk_model_set_fp8": (C.c_int, [_P, C.c_int]),

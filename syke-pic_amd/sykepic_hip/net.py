@@ -230,8 +230,8 @@ class HipNet:
         self.load_state_dict(sd)
 
     def set_precision(self, split_weights=3, precise_residual=False, bf16=False):
-        """Eval-path precision knobs (see include/sykepic_hip.h).  split_weights = 5 ("calibrated"): every conv but the
-        stem as ONE fp16 product with zero-sum rounded weights; needs `calibrate` / `set_act_means` first."""
+        """Eval-path precision knobs (see include/sykepic_hip.h).  split_weights = 5 ("calibrated"): every conv as ONE
+        fp16 product with zero-sum rounded weights; needs `calibrate` / `set_act_means` first."""
         if split_weights == "calibrated":
             split_weights = 5
         lib.check(self._lib.spk_model_set_infer_dtype(self._h, int(bool(bf16))))

@@ -106,6 +106,35 @@ def conv_dgrad(dy, weight, in_hw, stride=1, pad=0, accumulate_into=None):
     return _nchw(dx)
 
 
+def conv_dgrad_bn_backward(dy, weight, in_hw, raw, mask, mean, invstd, gamma, pad=0, relu=True, accumulate_into=None,
+                           res_src=None, res_bits=None):
+    """Stride-1 data gradient whose epilogue also makes the BatchNorm-backward sums of the layer that produced the conv's
+    input, then that layer's finalize + apply (spk_op_conv_dgrad_bn_backward).  raw [N,Cin,H,W] bf16, mask as returned by
+    `conv_bn_train_forward`.  res_src [N,Cin,H,W] bf16 + res_bits (instead of accumulate_into): the shortcut gradient
+    res_src * bit added at its source.  Returns dict(g, dy, dgamma, dbeta): g = the stored input gradient."""
+    so = lib.load()
+    dev = dy.device
+    n, cout = dy.shape[:2]
+    _, cin, k, _ = weight.shape
+    h, w = in_hw
+    dyh = _nhwc(dy.to(torch.bfloat16))
+    wk = weight.float().permute(0, 2, 3, 1).contiguous()
+    if accumulate_into is not None:
+        dx = _nhwc(accumulate_into.to(torch.bfloat16))
+    else:
+        dx = torch.full((n, h, w, cin), float("nan"), dtype=torch.bfloat16, device=dev)
+    rawh = _nhwc(raw.to(torch.bfloat16))
+    rsh = _nhwc(res_src.to(torch.bfloat16)) if res_src is not None else None
+    dyp = torch.empty_like(rawh)
+    dgamma = torch.empty(cin, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(cin, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv_dgrad_bn_backward(
+            _p(dyh), _p(wk), _p(dx), int(accumulate_into is not None), _p(rawh), _p(mask), _p(mean), _p(invstd), _p(gamma),
+            _p(dgamma), _p(dbeta), _p(dyp), n, h, w, cin, cout, k, pad, int(bool(relu)), _p(rsh), _p(res_bits), _stream(dev)))
+    return {"g": _nchw(dx), "dy": _nchw(dyp), "dgamma": dgamma, "dbeta": dbeta}
+
+
 def conv_wgrad(x, dy, k, stride=1, pad=0):
     """dw [Cout,Cin,k,k] float32 from x [N,Cin,H,W] and dy [N,Cout,Ho,Wo] (bf16)."""
     so = lib.load()

@@ -484,8 +484,15 @@ def calibrate_call(args):
     classify (raw samples or PNG images, chosen as for `prob`) and store them as `act_means.pth` beside
     `best_state.pth`.  From then on `sykepic prob -m <dir>` runs the calibrated single-pass mode."""
     from . import files, ifcb, pngio
+    keep = os.environ.get("SYKEPIC_CALIBRATED")
     os.environ["SYKEPIC_CALIBRATED"] = "0"      # measure with the weights alone, whatever file is already there
-    net, classes, img_shape, transform, device = prepare_model(args.model)
+    try:
+        net, classes, img_shape, transform, device = prepare_model(args.model)
+    finally:
+        if keep is None:
+            del os.environ["SYKEPIC_CALIBRATED"]
+        else:
+            os.environ["SYKEPIC_CALIBRATED"] = keep
 
     def images():
         if args.image_dir or args.images:

@@ -110,7 +110,8 @@ def test_bench_two_ranks_like_the_driver(tmp_path):
     d, t = res["dist"], res["train"]["dist"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and [r for r, _ in d["ranks_seen"]] == [0, 1]
     assert t["world_size"] == 2 and t["params_equal"] is True and t["overlap"] is False
-    assert t["allreduce_bytes"] == 4 * 11_347_186 and t["allreduce_ms"] > 0     # ResNet-18 + head, fp32 gradients
+    # ResNet-18 + head = 11,347,186 fp32 gradients in 66 tensors, each padded to a multiple of 64 floats in the flat buffer
+    assert 4 * 11_347_186 <= t["allreduce_bytes"] <= 4 * (11_347_186 + 64 * 66) and t["allreduce_ms"] > 0
 
 
 def test_bench_two_ranks_efficientnet_training(tmp_path):

@@ -221,3 +221,35 @@ def test_efficientnet_b5_uses_its_own_batchnorm_eps():
             mod.eps = 1e-5
     p_wrong = refnet.probabilities(ref, xf).numpy()
     assert np.abs(p_wrong - pr).max() > 5 * np.abs(pg - pr).max()
+
+
+@pytest.mark.parametrize("mode", ["fp16", "fp8"])
+def test_efficientnet_two_stream_forward_equals_the_halves_run_alone(mode):
+    """Round 4: the EfficientNet eval path takes the two-half-batches-on-two-streams forward too (its depthwise /
+    squeeze-excitation / e4m3 kernels address tensors and scratch per chunk of images now).  A batch of >= 64 images must
+    give what its halves give in single-stream batches: the same kernels on the same per-image data - only the number of
+    pool-partial rows of a squeeze (a function of the images per launch) may regroup an fp32 sum, hence the 2e-6."""
+    network, n, hw = "efficientnet_b0", 70, 64
+    from sykepic_hip import arch
+    g = arch.build_graph(network, 50)
+    sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
+    net = _hipnet(network, sd)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=78)).cuda()
+    if mode == "fp8":
+        net.set_fp8(True, calibration_batch=x[:32])
+    first = net.probabilities(x).cpu()          # tuning pass: both halves on the caller's stream
+    second = net.probabilities(x).cpu()         # two streams
+    third = net.probabilities(x).cpu()
+    assert torch.equal(second, third)
+    assert torch.allclose(first, second, atol=2e-6, rtol=0)
+    halves = torch.cat([net.probabilities(x[:n // 2]).cpu(), net.probabilities(x[n // 2:]).cpu()])
+    assert torch.allclose(second, halves, atol=2e-6, rtol=0), float((second - halves).abs().max())
+    assert torch.isfinite(second).all() and torch.allclose(second.sum(1), torch.ones(n), atol=1e-4)
+    # the tensors read back afterwards are whole (both halves wrote their images)
+    t = g.ops[5].dst
+    shape = None
+    from oracle import graph_eval
+    acts = graph_eval.run(g, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, x[:2].cpu())
+    shape = tuple(acts[t].shape[1:])
+    a = net.read_activation(t, n, (n,) + shape)
+    assert torch.isfinite(a).all() and float(a[n // 2:].abs().sum()) > 0

@@ -335,21 +335,30 @@ def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
     # reference's fp32 forward on a random-weight net with batch statistics over 8 images: the CPU oracle with bf16
     # storage and EXACT float32 backpropagation - no GPU kernel involved - is itself only at cosine 0.95 to fp32 autograd
     # on whole tensors there (test_gradients_vs_fp32_autograd), and a 64-element slice is noisier than a tensor.
-    # Measured on those slices: cosine 0.936-0.978, norm ratio 0.81-1.13, signs 0.80-0.98; asserted: cosine >= 0.90,
-    # norm +- 35 %, signs >= 0.75.  (These slices are chaotic, not just noisy: re-associating ONE fp32 sum of the
-    # BatchNorm-backward reduction - two rows per loop iteration instead of one - moved the stem conv's ratio from 0.81
-    # to 0.75.)  (The backward kernels are pinned at the GPU's own operating point by
+    # Measured on those slices over the realisations seen so far: cosine 0.894-0.983, norm ratio 0.81-1.13, signs
+    # 0.80-0.98; asserted: every slice cosine >= 0.85 AND their mean >= 0.93, norm +- 35 %, signs >= 0.75.  (These slices
+    # are chaotic, not just noisy: re-associating ONE fp32 sum of the BatchNorm-backward reduction - two rows per loop
+    # iteration instead of one - moved the stem conv's ratio from 0.81 to 0.75 in round 3; taking the reduction's sums
+    # from the fp32 gradient before it is rounded to bf16 (round 4, csrc/conv_igemm.hip: closer to exact
+    # backpropagation, see test_backward_matches_the_bf16_emulating_oracle) moved layer1's conv slice from 0.936 to 0.894
+    # and the stem conv's from 0.94 to 0.983.  One 64-element slice says "same direction" at either value; the mean over
+    # the deep slices is the stable statistic.)  (The backward kernels are pinned at the GPU's own operating point by
     # test_backward_matches_the_bf16_emulating_oracle; this test adds that sign and scale of every update follow the
     # reference's through its whole unfreeze schedule.)
+    deep = []
     for epoch, k, a, ratio in report:
         near = k.startswith(("head.", "base.7.1."))
         if optim_name == "Adam":
             assert a >= (0.97 if near else 0.75), f"epoch {epoch} {k}: update signs agree on {a:.2f} of the elements"
             assert 0.85 <= ratio <= 1.15, (epoch, k, ratio)
         else:
-            assert a >= (0.98 if near else 0.90), f"epoch {epoch} {k}: update cosine {a:.4f}"
+            assert a >= (0.98 if near else 0.85), f"epoch {epoch} {k}: update cosine {a:.4f}"
             lo, hi = (0.95, 1.05) if near else (0.65, 1.35)
             assert lo <= ratio <= hi, f"epoch {epoch} {k}: update norm ratio {ratio:.3f}"
+            if not near:
+                deep.append(a)
+    if optim_name != "Adam":
+        assert deep and float(np.mean(deep)) >= 0.93, f"mean update cosine of the deep-base slices {np.mean(deep):.4f}"
     assert moved >= 12      # head + BN slices move in every phase, the conv slices from their unfreeze epoch on
     assert np.allclose([gp["lr"] for gp in opt.param_groups], gold["group_lr"][0])
     assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == gold["group_sizes"].tolist()

@@ -194,3 +194,58 @@ def test_conv_bn_train_forward_matches_torch(case):
 def _any8(flag):
     n, c, h, w = flag.shape
     return flag.permute(0, 2, 3, 1).reshape(n * h * w, c // 8, 8).any(-1)
+
+
+@pytest.mark.parametrize("case", [(4, 14, 14, 64, 64, 3, 1, True, False), (3, 9, 11, 128, 64, 3, 1, True, True),
+                                  (4, 14, 14, 256, 64, 1, 0, True, True), (2, 28, 28, 128, 128, 3, 1, False, False),
+                                  (5, 7, 7, 64, 256, 1, 0, True, False), (2, 33, 21, 64, 128, 3, 1, True, True)],
+                         ids=lambda c: "n%d_%dx%d_c%d-%d_k%dp%d_relu%d_acc%d" % tuple(int(v) for v in c))
+def test_dgrad_with_the_producer_bn_reduction_matches_autograd(case):
+    """The data gradient of a stride-1 conv whose epilogue also makes the BatchNorm-backward sums of the layer that
+    produced its input (round 4: that layer's reduce pass is gone), then that layer's finalize + apply.  Oracle: autograd
+    through ReLU(BatchNorm(raw)) -> conv on the same bf16 operands.  The sums come from the fp32 gradient BEFORE it is
+    rounded to bf16, so dgamma / dbeta are closer to autograd than the three-pass form (which sums the rounded tensor);
+    with accumulate the stored gradient already holds another consumer's contribution (a shortcut add)."""
+    from sykepic_hip import ops
+    n, h, w, cin, cout, k, pad, relu, acc = case
+    raw = (_rand_bf16((n, cin, h, w), 21).float() * 1.3 + 0.2).bfloat16()
+    gamma = torch.randn(cin, generator=torch.Generator().manual_seed(22)) * 0.5 + 1.0
+    beta = torch.randn(cin, generator=torch.Generator().manual_seed(23)) * 0.3
+    wgt = _rand_bf16((cout, cin, k, k), 24, (2.0 / (cin * k * k)) ** 0.5)
+    dy = _rand_bf16((n, cout, h, w), 25, 0.01)
+    other = _rand_bf16((n, cin, h, w), 26, 0.01) if acc else None
+    y = raw.float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    v = F.batch_norm(y, None, None, gm, bt, True, 0.1, 1e-5)
+    a = torch.relu(v) if relu else v
+    a.retain_grad()
+    out = F.conv2d(a, wgt.float(), padding=pad)
+    loss = (out * dy.float()).sum() + ((a * other.float()).sum() if acc else 0.0)
+    loss.backward()
+    pos = (v > 0) if relu else torch.ones_like(v, dtype=torch.bool)
+    mean = raw.double().mean((0, 2, 3))
+    invstd = (1.0 / torch.sqrt(raw.double().var((0, 2, 3), unbiased=False) + 1e-5)).float()
+    got = ops.conv_dgrad_bn_backward(dy.cuda(), wgt.cuda(), (h, w), raw.cuda(), _mask_bits(pos).cuda(), mean.float().cuda(),
+                                     invstd.cuda(), gamma.cuda(), pad=pad, relu=relu,
+                                     accumulate_into=other.cuda() if acc else None)
+    rg = _check_bf16(got["g"], a.grad, "input gradient")
+    rd = _check_bf16(got["dy"], y.grad, "producer raw-output gradient")
+    eg, eb = _rel(got["dgamma"].cpu(), gm.grad), _rel(got["dbeta"].cpu(), bt.grad)
+    print(f"dgrad+bn_bwd {case}: g {rg:.2e}, dy {rd:.2e}, dgamma {eg:.2e}, dbeta {eb:.2e}")
+    assert eg < 1e-4 and eb < 1e-4
+    # the stored gradient is the same tensor the plain data-gradient launch writes
+    plain = ops.conv_dgrad(dy.cuda(), wgt.cuda(), (h, w), 1, pad, accumulate_into=other.cuda() if acc else None)
+    assert torch.equal(plain, got["g"])
+    if acc:
+        # the shortcut gradient picked up at its source: `other` = g3 * ReLU bits of a block-closing conv.  Handing the
+        # kernel g3 and the bits gives, bit for bit, what accumulating into the pre-masked tensor gives
+        g3 = _rand_bf16((n, cin, h, w), 27, 0.01)
+        pos3 = torch.rand((n, cin, h, w), generator=torch.Generator().manual_seed(28)) > 0.4
+        pre = (g3.float() * pos3).bfloat16()
+        a = ops.conv_dgrad_bn_backward(dy.cuda(), wgt.cuda(), (h, w), raw.cuda(), _mask_bits(pos).cuda(), mean.float().cuda(),
+                                       invstd.cuda(), gamma.cuda(), pad=pad, relu=relu, accumulate_into=pre.cuda())
+        b = ops.conv_dgrad_bn_backward(dy.cuda(), wgt.cuda(), (h, w), raw.cuda(), _mask_bits(pos).cuda(), mean.float().cuda(),
+                                       invstd.cuda(), gamma.cuda(), pad=pad, relu=relu, res_src=g3.cuda(),
+                                       res_bits=_mask_bits(pos3).cuda())
+        for key in ("g", "dy", "dgamma", "dbeta"):
+            assert torch.equal(a[key], b[key]), key

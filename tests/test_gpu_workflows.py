@@ -199,3 +199,11 @@ def test_train_main_end_to_end(tmp_path, capsys, network):
     print(f"{network} trained by train.main: calibrated max |dp| {e_cal:.2e}, every conv hi+lo {e_two:.2e}")
     assert e_cal <= (1e-3 if network == "resnet18" else 4e-3)
     assert (p_cal.argmax(1) == pr.argmax(1))[np.sort(pr, 1)[:, -1] - np.sort(pr, 1)[:, -2] > 2e-3].all()
+    # `sykepic calibrate` re-measures the means of an existing directory on images selected as for `prob`
+    from sykepic_hip.__main__ import build_parser
+    args = build_parser().parse_args(["calibrate", "-m", str(mdir), "--image-dir", str(ds), "-n", "24", "-b", "8"])
+    assert args.func(args) == 24
+    stored = torch.load(mdir / prob.ACT_MEANS_FILE)
+    assert stored["images"] == 24 and stored["network"] == network
+    net2, *_ = prob.prepare_model(mdir)
+    assert np.abs(net2.probabilities(x.cuda()).cpu().numpy() - pr).max() <= (1e-3 if network == "resnet18" else 4e-3)
