@@ -58,11 +58,14 @@ def run_train_bf16(graph, state, x, eps=1e-5):
     autograd through this graph checks the backward KERNELS to ~1e-2 instead
     of being dominated by mask flips of a pure-fp32 forward.
     state: {key: tensor (requires_grad for parameters)}.  Returns acts."""
-    acts = {0: _bf16_st(x)}
+    acts = {0: _bf16_st(x * 255.0) / 255.0}   # (csrc/spk_common.h SPK_INPUT_SCALE: pixel values x 255 are exact in bf16)
     for op in graph.ops:
         a = acts[op.src]
         if op.kind == arch.OP_CONV:
-            y32 = F.conv2d(a, _bf16_st(state[op.name + ".weight"]), None, op.stride, op.pad)
+            w = state[op.name + ".weight"]
+            # (the 7x7 stem's weights are packed as bf16(w / 255): its input holds pixel values x 255)
+            wb = _bf16_st(w / INPUT_SCALE) * INPUT_SCALE if op.src == 0 and op.k == 7 else _bf16_st(w)
+            y32 = F.conv2d(a, wb, None, op.stride, op.pad)
             mean = y32.mean((0, 2, 3), keepdim=True)
             var = y32.var((0, 2, 3), unbiased=False, keepdim=True)
             yr = _bf16_st(y32)
@@ -103,7 +106,7 @@ def run_train_forced(graph, state, x, forced, eps=1e-5, row_scale=None):
     def force(v, t):
         return v + (forced[t].to(v.dtype) - v).detach() if t in forced else v
 
-    acts = {0: _bf16_st(x)}
+    acts = {0: _bf16_st(x * 255.0) / 255.0}   # (csrc/spk_common.h SPK_INPUT_SCALE: pixel values x 255 are exact in bf16)
     for op in graph.ops:
         a = acts[op.src]
         if op.kind in (arch.OP_CONV, arch.OP_DWCONV):
@@ -130,6 +133,19 @@ def run_train_forced(graph, state, x, forced, eps=1e-5, row_scale=None):
             v = a
         acts[op.dst] = force(v, op.dst)
     return acts
+
+
+INPUT_SCALE = 255.0   # the HIP path stores pixel values x 255 in 16 bits (exact for the k / 255 values ToTensor gives)
+
+
+def _r16_input(x):
+    """the input as the HIP path sees it: bf16(x * 255) / 255 (csrc/spk_common.h SPK_INPUT_SCALE)"""
+    return (x * INPUT_SCALE).bfloat16().float() / INPUT_SCALE
+
+
+def _r16_stem_w(w):
+    """the 7x7 stem's training weights as packed: bf16(w / 255) (the input holds pixel values x 255), in input units"""
+    return (w / INPUT_SCALE).bfloat16().float() * INPUT_SCALE
 
 
 def _r16(t):
@@ -165,7 +181,7 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
     state: {key: float32 tensor}.  Returns dict(logits, loss, acts, grads {state key: tensor},
     act_grads {tensor id: tensor})."""
     rg = _r16 if round_grads else (lambda t: t)
-    acts = {0: _r16(x)} if x is not None else {}
+    acts = {0: _r16_input(x)} if x is not None else {}
     if first_op > 0:
         for op in graph.ops[first_op:]:
             for t in (op.src, op.res):
@@ -177,7 +193,7 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
             continue
         a = acts[op.src]
         if op.kind == arch.OP_CONV:
-            wb = _r16(state[op.name + ".weight"])
+            wb = _r16_stem_w(state[op.name + ".weight"]) if op.src == 0 and op.k == 7 else _r16(state[op.name + ".weight"])
             y32 = F.conv2d(a, wb, None, op.stride, op.pad)
             mean = y32.double().mean((0, 2, 3))
             var = y32.double().var((0, 2, 3), unbiased=False)
@@ -231,7 +247,7 @@ def train_step_bf16(graph, state, x, y, eps=1e-5, round_grads=True, forced=None,
     for t in {o.dst for o in graph.ops if o.kind == arch.OP_CONV}:
         users = [j for j, o in enumerate(graph.ops) if o.src == t or (o.kind == arch.OP_CONV and o.res == t)]
         if users and graph.ops[min(users)].kind == arch.OP_CONV and graph.ops[min(users)].src == t \
-                and graph.ops[min(users)].stride == 1:
+                and graph.ops[min(users)].stride == 1 and graph.ops[min(users)].k == 1:   # (default SPK_BNB_FUSE=3: 1x1 consumers)
             pre_round_sums.add(t)
 
     def put(t, val, dgrad=False):  # first consumer writes, later ones add and round again

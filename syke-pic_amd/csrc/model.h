@@ -207,5 +207,6 @@ int spk_conv_dgrad_all(const bf16_t* dy, const bf16_t* wdg, bf16_t* dx, bool acc
 size_t spk_conv_wgrad_slab_floats(int M, int cin, int cout, int k, bool stem);
 int spk_conv_wgrad_slabs(const bf16_t* x, const bf16_t* dy, float* slabs, int n, int ih, int iw, int cin, int oh,
                          int ow, int cout, int k, int stride, int pad, bool stem, hipStream_t s);
-int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cout, int k, bool stem, hipStream_t s);
+int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cout, int k, bool stem, hipStream_t s,
+                          float scale = 1.0f);
 void spk_train_mark_dirty(spk_model* m);

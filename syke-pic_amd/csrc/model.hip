@@ -551,6 +551,11 @@ int spk_commit(spk_model* m) {
     if (spk_launch_bn_fold(m->P(L.p_g), m->P(L.p_b), m->P(L.p_mean), m->P(L.p_var), m->bn_eps, sc, bi,
                            L.d.cout, m->stream))
       return fail(SPK_ERR_HIP, "bn_fold launch failed");
+    // the stems read pixel values x 255 (exact in 16 bits, spk_common.h SPK_INPUT_SCALE): their fp32 epilogue scale takes
+    // the factor back
+    if (L.d.kind == SPK_OP_CONV && (L.mode == CONV_MODE_STEM || L.mode == CONV_MODE_STEM3) &&
+        spk_launch_scale_inplace(sc, 1.0f / SPK_INPUT_SCALE, L.d.cout, m->stream))
+      return fail(SPK_ERR_HIP, "stem scale launch failed");
     int r;
     // the weights every image of this layer is packed from: the fp32 master, or its zero-sum rounded copy (values that
     // ARE fp16 numbers, so each pack kernel's own conversion is exact): master layout [cout][tap][cin], one balanced
@@ -1415,7 +1420,7 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
         m->img0 = off[hf];
         m->stream = str[hf];
         const char* xi = (const char*)x + (size_t)off[hf] * image_stride_bytes(m->in_chans, h, w, dtype);
-        if (spk_launch_to_nhwc4(xi, layout, dtype, cnt[hf], m->in_chans, h, w, (bf16_t*)m->TI(0), m->infer_dt, m->stream))
+        if (spk_launch_to_nhwc4(xi, layout, dtype, cnt[hf], m->in_chans, h, w, (bf16_t*)m->TI(0), m->infer_dt, m->stream, SPK_INPUT_SCALE))
           rc = fail(SPK_ERR_HIP, "input conversion launch failed");
       }
       for (size_t i = 0; i < m->layers.size() && rc == SPK_OK; ++i)
@@ -1444,7 +1449,7 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
   for (int i0 = 0; i0 < n; i0 += mb) {
     const int nb = std::min(mb, n - i0);
     const char* xi = (const char*)x + (size_t)i0 * image_stride_bytes(m->in_chans, h, w, dtype);
-    if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream))
+    if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream, SPK_INPUT_SCALE))
       return fail(SPK_ERR_HIP, "input conversion launch failed");
     SPK_TRY(run_layers_eval(m, nb));
     HIP_TRY(hipMemcpyAsync(logits_dev + (size_t)i0 * m->num_classes, m->T(last),
@@ -1532,7 +1537,7 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
     const char* xi = (const char*)x + (size_t)i0 * image_stride_bytes(m->in_chans, h, w, dtype);
     m->act_dt = m->infer_dt;
     m->t_fp8_scale.assign(m->n_tensors, 0.f);
-    if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream)) {
+    if (spk_launch_to_nhwc4(xi, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream, SPK_INPUT_SCALE)) {
       rc = fail(SPK_ERR_HIP, "input conversion launch failed");
       break;
     }
@@ -1566,7 +1571,8 @@ extern "C" int spk_model_calibrate_act_means(spk_model* m, const void* x, int n,
       if (L.mode == CONV_MODE_STEM) {   // mean over the w real pixels of a row: the pair means carry the zero pad pixel
         const double rows = (double)nb * in.h * w, fix = (double)in.w / (double)w;
         for (int c = 0; c < L.d.cin; ++c)
-          m->cal_sum[L.mu_off + c] += 0.5 * ((double)host[m->n_means + c] + (double)host[m->n_means + 4 + c]) * fix * rows;
+          m->cal_sum[L.mu_off + c] += 0.5 * ((double)host[m->n_means + c] + (double)host[m->n_means + 4 + c]) * fix * rows /
+                                      (double)SPK_INPUT_SCALE;
         m->cal_rows[gi] += rows;
         continue;
       }
@@ -1703,7 +1709,7 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
   std::vector<double> ms(nl + 1, 0.0);
   for (int it = 0; it < iters + 1; ++it) {  // first pass is a warm-up
     HIP_TRY(hipEventRecord(ev[0], m->stream));
-    if (spk_launch_to_nhwc4(x, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream))
+    if (spk_launch_to_nhwc4(x, layout, dtype, nb, m->in_chans, h, w, (bf16_t*)m->T(0), m->infer_dt, m->stream, SPK_INPUT_SCALE))
       return fail(SPK_ERR_HIP, "input conversion launch failed");
     HIP_TRY(hipEventRecord(ev[1], m->stream));
     for (int i = 0; i < nl; ++i) {

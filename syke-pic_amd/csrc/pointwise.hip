@@ -13,7 +13,7 @@ namespace {
 // one thread = one output pixel (4 bf16 channels = 8 B)
 template <typename T, bool NHWC, int DT>
 __global__ void to_nhwc4_kernel(const T* __restrict__ x, bf16_t* __restrict__ out, int n, int c,
-                                int h, int w, int wp) {
+                                int h, int w, int wp, float mul) {
   const size_t total = (size_t)n * h * wp;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
        i += (size_t)gridDim.x * blockDim.x) {
@@ -27,7 +27,7 @@ __global__ void to_nhwc4_kernel(const T* __restrict__ x, bf16_t* __restrict__ ou
         if (ch < c) {
           const size_t src = NHWC ? (((size_t)img * h + y) * w + px) * c + ch
                                   : (((size_t)img * c + ch) * h + y) * w + px;
-          v[ch] = sizeof(T) == 1 ? (float)x[src] * (1.0f / 255.0f) : (float)x[src];
+          v[ch] = (float)x[src] * mul;   // (u8: mul = scale / 255, exactly 1 for scale 255)
         }
       }
     }
@@ -129,14 +129,14 @@ __global__ void pack_generic_kernel(const float* __restrict__ w, bf16_t* __restr
 // t-1 (tap 0 is the zero that 16-B-aligns the pixel pairs), row 7 / ch 3 zero.
 template <int DT>
 __global__ void pack_stem_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int cout,
-                                 int kh, int kw, int cin, int splitw) {
+                                 int kh, int kw, int cin, int splitw, float wscale) {
   const int total = cout * 256;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int ch = i & 3, t = (i >> 2) & 7, r = (i >> 5) & 7, co = i >> 8;
   float v = 0.f;
   const int s = t - 1;
-  if (r < kh && s >= 0 && s < kw && ch < cin) v = w[(((size_t)co * kh + r) * kw + s) * cin + ch];
+  if (r < kh && s >= 0 && s < kw && ch < cin) v = w[(((size_t)co * kh + r) * kw + s) * cin + ch] * wscale;
   const unsigned short hi = to_h16<DT>(v);
   out[i] = hi;
   if (splitw) out[total + i] = to_h16<DT>(v - h16_to_f32<DT>(hi));
@@ -156,24 +156,24 @@ inline int grid_for(size_t total, int block) {
 
 template <typename T, bool NHWC>
 static void launch_to_nhwc4(const void* x, bf16_t* out, int n, int c, int h, int w, int wp, int dt, int g,
-                            hipStream_t s) {
+                            hipStream_t s, float mul) {
   DT_DISPATCH(dt,
-              hipLaunchKernelGGL((to_nhwc4_kernel<T, NHWC, DT_BF16>), dim3(g), dim3(256), 0, s, (const T*)x, out, n, c, h, w, wp),
-              hipLaunchKernelGGL((to_nhwc4_kernel<T, NHWC, DT_F16>), dim3(g), dim3(256), 0, s, (const T*)x, out, n, c, h, w, wp));
+              hipLaunchKernelGGL((to_nhwc4_kernel<T, NHWC, DT_BF16>), dim3(g), dim3(256), 0, s, (const T*)x, out, n, c, h, w, wp, mul),
+              hipLaunchKernelGGL((to_nhwc4_kernel<T, NHWC, DT_F16>), dim3(g), dim3(256), 0, s, (const T*)x, out, n, c, h, w, wp, mul));
 }
 
 int spk_launch_to_nhwc4(const void* x, int layout, int dtype, int n, int c, int h, int w,
-                        bf16_t* out, int dt, hipStream_t s) {
+                        bf16_t* out, int dt, hipStream_t s, float scale) {
   if (c < 1 || c > 4) return -1;
   const int wp = (w + 1) & ~1;
   const size_t total = (size_t)n * h * wp;
   const int g = grid_for(total, 256);
   if (dtype == 0) {
-    if (layout == 0) launch_to_nhwc4<float, false>(x, out, n, c, h, w, wp, dt, g, s);
-    else launch_to_nhwc4<float, true>(x, out, n, c, h, w, wp, dt, g, s);
+    if (layout == 0) launch_to_nhwc4<float, false>(x, out, n, c, h, w, wp, dt, g, s, scale);
+    else launch_to_nhwc4<float, true>(x, out, n, c, h, w, wp, dt, g, s, scale);
   } else if (dtype == 2) {
-    if (layout == 0) launch_to_nhwc4<unsigned char, false>(x, out, n, c, h, w, wp, dt, g, s);
-    else launch_to_nhwc4<unsigned char, true>(x, out, n, c, h, w, wp, dt, g, s);
+    if (layout == 0) launch_to_nhwc4<unsigned char, false>(x, out, n, c, h, w, wp, dt, g, s, scale / 255.0f);
+    else launch_to_nhwc4<unsigned char, true>(x, out, n, c, h, w, wp, dt, g, s, scale / 255.0f);
   } else {
     return -1;
   }
@@ -208,15 +208,24 @@ int spk_launch_bn_fold(const float* g, const float* b, const float* mean, const 
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+__global__ void scale_inplace_kernel(float* __restrict__ x, float f, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= f;
+}
+int spk_launch_scale_inplace(float* x, float f, int n, hipStream_t s) {
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, f, n);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
-                            int mode, int dt, int splitw, hipStream_t s) {
+                            int mode, int dt, int splitw, hipStream_t s, float stem_wscale) {
   if (mode == CONV_MODE_STEM) {
     if (kh > 7 || kw > 7 || cin > 4) return -1;
     const int total = cout * 256;
     const int g = (total + 255) / 256;
     DT_DISPATCH(dt,
-                hipLaunchKernelGGL(pack_stem_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, w_krsc, out, cout, kh, kw, cin, splitw),
-                hipLaunchKernelGGL(pack_stem_kernel<DT_F16>, dim3(g), dim3(256), 0, s, w_krsc, out, cout, kh, kw, cin, splitw));
+                hipLaunchKernelGGL(pack_stem_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, w_krsc, out, cout, kh, kw, cin, splitw, stem_wscale),
+                hipLaunchKernelGGL(pack_stem_kernel<DT_F16>, dim3(g), dim3(256), 0, s, w_krsc, out, cout, kh, kw, cin, splitw, stem_wscale));
   } else {
     const size_t n = (size_t)cout * kh * kw * cin;
     const int g = grid_for(n, 256);

@@ -229,8 +229,16 @@ int spk_launch_chan_mean(const bf16_t* x, float* part, float* mean, size_t rows,
 // Pointwise / pooling / packing kernels (pointwise.hip)
 // ---------------------------------------------------------------------------
 // image batch -> NHWC bf16 with channels padded to 4 (stem input)
+// `scale`: what a pixel VALUE (a float as given, or k / 255 for uint8) is multiplied with before the 16-bit rounding.
+// The model executors pass SPK_INPUT_SCALE = 255: the reference's inputs are k / 255 (ToTensor), which no 16-bit float
+// holds exactly, while the integers 0..255 are exact in fp16 AND bf16 - the stem kernels take the factor back in fp32
+// (eval: folded BatchNorm scale / 255; training: stem weights / 255 at packing, weight gradient / 255).  Measured on
+// trained nets (tests/diagnostics/input_rounding.py): against the fp32 oracle the eval path was 1.2e-3 off on the worst of
+// 256 images, 7.6e-5 against the oracle fed the fp16-rounded pixels - the input rounding WAS the error.
+#define SPK_INPUT_SCALE 255.0f
 int spk_launch_to_nhwc4(const void* x, int layout, int dtype, int n, int c, int h, int w,
-                        bf16_t* out, int dt, hipStream_t s);
+                        bf16_t* out, int dt, hipStream_t s, float scale = 1.0f);
+int spk_launch_scale_inplace(float* x, float f, int n, hipStream_t s);
 int spk_launch_maxpool(const bf16_t* x, bf16_t* y, int n, int h, int w, int c, int k, int stride,
                        int pad, int ho, int wo, int dt, hipStream_t s);
 int spk_launch_gavgpool(const bf16_t* x, float* y, int n, int hw, int c, int dt, hipStream_t s);
@@ -253,7 +261,7 @@ int spk_launch_se(const bf16_t* x, bf16_t* y, const float* partial, int chunks, 
                   const float* b1, const float* w2t, const float* b2, int n, int hw, int c, int c_p, int sq, int dt,
                   hipStream_t s);
 int spk_launch_pack_weights(const float* w_krsc, bf16_t* out, int cout, int kh, int kw, int cin,
-                            int mode, int dt, int splitw, hipStream_t s);
+                            int mode, int dt, int splitw, hipStream_t s, float stem_wscale = 1.0f);
 // fp8 (e4m3) mode of the MBConv interior (pw_fp8.hip)
 int spk_launch_pw_fp8(const void* x, int a_fp8, const unsigned char* w, void* y, int out_fp8, const bf16_t* res,
                       const float* scale, const float* bias, const float* gate, int gate_stride, int hw, int M, int Kpad,
@@ -335,9 +343,9 @@ int spk_launch_colsum(const float* dy, float* db, int n, int c, hipStream_t s);
 int spk_launch_dropout_fwd(const float* x, float* y, unsigned char* mask, size_t n, float p, unsigned long long seed,
                            hipStream_t s);
 int spk_launch_dropout_bwd(const float* gy, const unsigned char* mask, float* gx, size_t n, float p, hipStream_t s);
-int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s);
+int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s, float scale = 1.0f);
 int spk_launch_stem_wgrad_unpack(const float* slabs, float* out, int cout, int kh, int kw, int cin,
-                                 int splits, hipStream_t s);
+                                 int splits, hipStream_t s, float scale = 1.0f);
 int spk_launch_pack_dgrad(const float* w, bf16_t* out, int cout, int taps, int cin, hipStream_t s);
 int spk_launch_opt_multi(int kind, float* p, const float* g, float* m, float* v, const OptTable& t,
                          float b1, float b2, float eps, float wd, float momentum, float gscale, float alpha,

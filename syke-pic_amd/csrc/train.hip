@@ -332,7 +332,7 @@ static int repack_weights(spk_model* m) {
     }
     if (L.mode == CONV_MODE_STEM) {
       K_TRY(spk_launch_pack_weights(m->P(L.p_w), t->wpack + t->conv[i].wfwd_off, L.d.cout, L.d.k, L.d.k, L.d.cin,
-                                    L.mode, DT_BF16, 0, m->stream), "pack_weights");
+                                    L.mode, DT_BF16, 0, m->stream, 1.0f / SPK_INPUT_SCALE), "pack_weights");
       continue;
     }
     for (int kind = 0; kind < 2; ++kind) {
@@ -435,12 +435,13 @@ int spk_conv_wgrad_slabs(const bf16_t* x, const bf16_t* dy, float* slabs, int n,
 }
 
 // ... and their fixed-order sum into gw ([Cout][kh][kw][Cin] fp32)
-int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cout, int k, bool stem, hipStream_t s) {
+int spk_conv_wgrad_reduce(const float* slabs, float* gw, int M, int cin, int cout, int k, bool stem, hipStream_t s,
+                          float scale) {
   const int ktot = stem ? 256 : k * k * cin;
   int sp, pps;
   spk_wgrad_plan(M, cout, ktot, &sp, &pps);
   if (stem)
-    K_TRY(spk_launch_stem_wgrad_unpack(slabs, gw, cout, k, k, cin, sp, s), "stem wgrad unpack");
+    K_TRY(spk_launch_stem_wgrad_unpack(slabs, gw, cout, k, k, cin, sp, s, scale), "stem wgrad unpack");
   else
     K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)cout * ktot, sp, s), "wgrad reduce");
   return SPK_OK;
@@ -484,7 +485,9 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
 
   // ------------------------------ forward ------------------------------
   mark(m, -1);
-  K_TRY(spk_launch_to_nhwc4(x, layout, dtype, n, m->in_chans, h, w, (bf16_t*)m->T(0), DT_BF16, s), "to_nhwc4");
+  // pixel values x 255: exact in bf16 (k / 255 is not: 8 mantissa bits put the input 0.2-0.4 % off); the stem's packed
+  // weights carry 1 / 255 and its weight gradient is scaled back (spk_common.h SPK_INPUT_SCALE)
+  K_TRY(spk_launch_to_nhwc4(x, layout, dtype, n, m->in_chans, h, w, (bf16_t*)m->T(0), DT_BF16, s, SPK_INPUT_SCALE), "to_nhwc4");
   mark(m, PH_INPUT);
   for (int i = 0; i < nl; ++i) {
     Layer& L = m->layers[i];
@@ -498,7 +501,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
         int m_tiles = 0;
         if (L.mode == CONV_MODE_STEM3) {
           K_TRY(spk_launch_stem3_train_fwd((const bf16_t*)m->T(0), m->P(L.p_w), t->RAW(i), n, in.h, w, in.w, L.d.cin,
-                                           L.d.cout, C, o.h, o.w, s), "stem3 fwd");
+                                           L.d.cout, C, o.h, o.w, s, 1.0f / SPK_INPUT_SCALE), "stem3 fwd");
           K_TRY(spk_launch_col_stats(t->RAW(i), part, M, C, &m_tiles, s), "col_stats");
         } else {
           ConvArgs a;
@@ -852,7 +855,8 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
             K_TRY(spk_launch_stem3_wgrad((const bf16_t*)m->T(0), dy, slabs, n, in.h, w, in.w, L.d.cin, L.d.cout, C, o.h,
                                          o.w, &nbk, ws3), "stem3 wgrad");
             mark(m, PH_CONV_WGRAD);
-            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)L.d.cout * 9 * L.d.cin, nbk, ws3), "stem3 wgrad reduce");
+            K_TRY(spk_launch_slab_reduce(slabs, gw, (size_t)L.d.cout * 9 * L.d.cin, nbk, ws3, 1.0f / SPK_INPUT_SCALE),
+                  "stem3 wgrad reduce");
             if (side_on) {
               HIP_TRY(hipEventRecord(t->ev_dy_free[slot], ws3));
               t->dy_busy[slot] = true;
@@ -874,7 +878,7 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
             K_TRY(spk_launch_slab_reduce_sub(slabs, gw, L.d.cout, L.d.k * L.d.k, L.d.cin, C, cin_t, sp, ws),
                   "wgrad reduce (padded)");
           } else {
-            SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, cin_t, C, L.d.k, stem, ws));
+            SPK_TRY(spk_conv_wgrad_reduce(slabs, gw, M, cin_t, C, L.d.k, stem, ws, stem ? 1.0f / SPK_INPUT_SCALE : 1.0f));
           }
           if (side_on) {
             HIP_TRY(hipEventRecord(t->ev_dy_free[slot], ws));

@@ -20,7 +20,7 @@ int spk_launch_bna_bwd_apply(const bf16_t* g, const bf16_t* raw, const float* sc
                              hipStream_t s);
 int spk_launch_sd_rowscale(float* rs, int n, float p, unsigned long long seed, hipStream_t s);
 int spk_launch_stem3_train_fwd(const bf16_t* x, const float* w, bf16_t* y, int n, int h, int wd, int wstride, int cin,
-                               int cout, int C, int ho, int wo, hipStream_t s);
+                               int cout, int C, int ho, int wo, hipStream_t s, float out_scale = 1.0f);
 int spk_stem3_wgrad_blocks(int M, int* pix_per_block);
 int spk_launch_stem3_wgrad(const bf16_t* x, const bf16_t* dy, float* partials, int n, int h, int wd, int wstride,
                            int cin, int cout, int C, int ho, int wo, int* blocks, hipStream_t s);

@@ -369,7 +369,7 @@ __global__ void sd_rowscale_kernel(float* __restrict__ rs, int n, float p, unsig
 constexpr int STEM_PX = 4;
 __global__ __launch_bounds__(256) void stem3_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ wgt,
                                                         bf16_t* __restrict__ y, int n, int h, int wd, int wstride,
-                                                        int cin, int cout, int C, int ho, int wo) {
+                                                        int cin, int cout, int C, int ho, int wo, float out_scale) {
   extern __shared__ float ws[];  // [9][4][C]
   for (int i = threadIdx.x; i < 36 * C; i += 256) {
     const int co = i % C, ci = (i / C) & 3, tap = i / (4 * C);
@@ -428,7 +428,11 @@ __global__ __launch_bounds__(256) void stem3_fwd_kernel(const bf16_t* __restrict
       }
 #pragma unroll
     for (int u = 0; u < STEM_PX; ++u)
-      if (ow0 + u < wo) *(u32x4_t*)(y + ((((size_t)img * ho + oh) * wo) + ow0 + u) * C + cc * 8) = pack8(acc[u]);
+      if (ow0 + u < wo) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[u][j] *= out_scale;   // (the input holds pixel values x 255: exact products, one scale)
+        *(u32x4_t*)(y + ((((size_t)img * ho + oh) * wo) + ow0 + u) * C + cc * 8) = pack8(acc[u]);
+      }
   }
 }
 
@@ -1290,10 +1294,10 @@ int spk_launch_sd_rowscale(float* rs, int n, float p, unsigned long long seed, h
 }
 
 int spk_launch_stem3_train_fwd(const bf16_t* x, const float* w, bf16_t* y, int n, int h, int wd, int wstride, int cin,
-                               int cout, int C, int ho, int wo, hipStream_t s) {
+                               int cout, int C, int ho, int wo, hipStream_t s, float out_scale) {
   const size_t total = (size_t)n * ho * ((wo + STEM_PX - 1) / STEM_PX) * (C / 8);
   hipLaunchKernelGGL(stem3_fwd_kernel, dim3(grid_of(total, 256)), dim3(256), (size_t)36 * C * 4, s, x, w, y, n, h, wd,
-                     wstride, cin, cout, C, ho, wo);
+                     wstride, cin, cout, C, ho, wo, out_scale);
   return LAUNCH_OK();
 }
 

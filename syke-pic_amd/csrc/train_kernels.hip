@@ -371,7 +371,7 @@ __global__ void colsum_kernel(const float* __restrict__ dy, float* __restrict__ 
 // keep 8 loads in flight per thread (the slabs are read exactly once); they
 // are combined in a fixed tree, so the result is reproducible.
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, size_t n,
-                                   int splits) {
+                                   int splits, float scale) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
        i += (size_t)gridDim.x * blockDim.x) {
     float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -381,13 +381,13 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, float* __res
       for (int u = 0; u < 8; ++u) p[u] += slabs[(size_t)(k + u) * n + i];
     }
     for (int u = 0; k < splits; ++k, ++u) p[u] += slabs[(size_t)k * n + i];
-    out[i] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    out[i] = (((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]))) * scale;
   }
 }
 
 // stem wgrad image [Cout][8 rows][8 taps][4 ch] (x splits) -> [Cout][7][7][3]
 __global__ void stem_wgrad_unpack_kernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                         int cout, int kh, int kw, int cin, int splits) {
+                                         int cout, int kh, int kw, int cin, int splits, float scale) {
   const int total = cout * kh * kw * cin;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -395,7 +395,7 @@ __global__ void stem_wgrad_unpack_kernel(const float* __restrict__ slabs, float*
   const size_t src = (size_t)co * 256 + r * 32 + (s + 1) * 4 + ci;
   float t = 0.f;
   for (int k = 0; k < splits; ++k) t += slabs[(size_t)k * cout * 256 + src];
-  out[i] = t;
+  out[i] = t * scale;
 }
 
 // master fp32 [Cout][kh][kw][Cin] -> bf16 dgrad image [Cin][kh][kw][Cout]
@@ -749,16 +749,16 @@ int spk_launch_colsum(const float* dy, float* db, int n, int c, hipStream_t s) {
   return LAUNCH_OK();
 }
 
-int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, slabs, out, n, splits);
+int spk_launch_slab_reduce(const float* slabs, float* out, size_t n, int splits, hipStream_t s, float scale) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, slabs, out, n, splits, scale);
   return LAUNCH_OK();
 }
 
 int spk_launch_stem_wgrad_unpack(const float* slabs, float* out, int cout, int kh, int kw, int cin,
-                                 int splits, hipStream_t s) {
+                                 int splits, hipStream_t s, float scale) {
   const int total = cout * kh * kw * cin;
   hipLaunchKernelGGL(stem_wgrad_unpack_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slabs, out,
-                     cout, kh, kw, cin, splits);
+                     cout, kh, kw, cin, splits, scale);
   return LAUNCH_OK();
 }
 

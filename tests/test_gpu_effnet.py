@@ -12,7 +12,9 @@ from sykepic_hip import synth
 pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
 # fresh images at the reference's base 1.3 (measured r2: median 2.0-2.6e-4, p90 1.6-2.1e-3, max 2.0-3.1e-3, top-1 32/32)
-BASE13_MEDIAN, BASE13_P90, BASE13_MAX = 5e-4, 4e-3, 1e-2
+# round 4 (exact pixel input): measured B0 1.3e-4 / 1.4e-3 / 4.6e-3, B4 1.1e-4 / 8.1e-4 / 2.8e-3 on these RANDOM-weight nets
+# (a trained EfficientNet-B0: median 1.5e-5, p90 5.8e-5, max 2.0e-4 - tests/test_gpu_trained.py)
+BASE13_MEDIAN, BASE13_P90, BASE13_MAX = 3e-4, 3e-3, 9e-3
 
 
 def _hipnet(network, sd):

