@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--layers-out", default="", help="write the per-layer table (JSON) here")
+    ap.add_argument("--no-kernel-profile", action="store_true",
+                    help="skip the per-layer / per-phase event profile behind `roofline` (for rocprofv3 traces: the last steps "
+                         "of the trace are then timed steps, not the single-stream profiling passes)")
     args = ap.parse_args()
     if args.precision is None:
         # the fastest mode that holds the parity tolerance: ResNets - calibrated single pass (tests/test_gpu_calibrated.py);
@@ -273,6 +276,15 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     if rank != 0:
         return None
 
+    if args.no_kernel_profile:
+        total_images = args.batch * world * args.steps
+        return {"metric": f"IFCB images/sec, {args.network} {args.size}x{args.size} {mode} step",
+                "value": round(total_images / dt, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "step_ms": step_ms,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+                "config": {"workload": f"{args.network}_{mode}_b{args.batch}x{world}_{args.size}x{args.size}x3_"
+                                       f"{args.classes}cls_head256-128", "precision": args.precision if mode == "infer" else "bf16"},
+                "roofline": None}
     # ---- roofline of the dominant kernel, HIP events on the launch stream ----
     layers_out = args.layers_out and (args.layers_out if mode == args.mode or args.mode == "both" and mode == "infer"
                                       else args.layers_out + "." + mode)

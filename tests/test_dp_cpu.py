@@ -242,3 +242,36 @@ def test_sharding_helpers():
     a, b = list(s0), list(s1)
     assert len(a) == len(b) == 6 and set(a) | set(b) == set(range(11))
     assert list(s0) != a                                      # reshuffled next epoch
+
+
+def _bench_record_worker(rank, world, port, out_dir):
+    for p in (ROOT, ROOT / "syke-pic_amd"):
+        sys.path.insert(0, str(p))
+    import torch.distributed as dist
+    import bench
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = bench.dist_record(dist, torch.device("cpu"), rank, world)
+
+    class Net:
+        def __init__(self, shift):
+            self.shift = shift
+
+        def state_dict(self):
+            return {"w": torch.arange(8.0) + self.shift, "bn.running_mean": torch.full((4,), float(rank)),
+                    "bn.num_batches_tracked": torch.tensor(rank)}
+    same = bench.replicas_equal(Net(0.0), dist)                  # BatchNorm buffers may differ between ranks: local statistics
+    differ = bench.replicas_equal(Net(1e-7 * rank), dist)        # one ulp-sized difference in a parameter is a divergence
+    torch.save({"rec": rec, "same": same, "differ": differ}, Path(out_dir) / f"b{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_bench_line_describes_the_job_it_measured(tmp_path):
+    """bench.py's `dist` record: backend, world size, one (rank, device) pair per rank, and the
+    replica check that compares a sha256 of every rank's parameters - rank-local BatchNorm statistics excluded."""
+    port = _free_port()
+    mp.spawn(_bench_record_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"b{r}.pt") for r in (0, 1))
+    for r in (r0, r1):
+        assert r["rec"] == {"backend": "gloo", "world_size": 2, "ranks_seen": [[0, "cpu"], [1, "cpu"]], "distinct_devices": 1}
+        assert r["same"] is True and r["differ"] is False

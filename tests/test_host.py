@@ -438,3 +438,79 @@ def test_vectorised_csv_rows_equal_the_percent_formatting(tmp_path):
     assert prob._format_rows(prob.ProbRows([1], np.float32([[np.nan] * 7])), 7) is None      # falls back to the row loop
     shuffled = prob.ProbRows(numbers[::-1], p[::-1]).sorted()
     assert np.array_equal(shuffled.numbers, numbers) and np.array_equal(shuffled.probs, p)
+
+
+def test_settings_table_reads_lazily_and_raises_like_configparser():
+    """config.KEYS is the train.ini contract as data: a key the chosen options never reach may be absent (as with the
+    reference's statement-by-statement reads), a missing required key raises configparser's own errors, optional keys
+    fall back to the reference's defaults, legacy model configs without `weights` mean "DEFAULT" (quirk Q7)."""
+    from configparser import ConfigParser, NoOptionError, NoSectionError
+    from sykepic_hip import config as C
+    cp = ConfigParser()
+    cp.read_string("""
+[dataset]
+path = /data/x
+split = 0.8,0.1,0.1
+min_N =
+max_N = 500
+exclude = a, b
+random_seed = 7
+[image]
+shape = 3,180,180
+batch_size = 64
+num_workers = 2
+augmentations = flip, zoom
+border = mode
+zoom_range = 0.9,1.1
+imagenet_normalization = no
+[model]
+network = resnet18
+head = 256,128
+dropout = 1,0.5;2,0.25
+[lr_warmup]
+use = no
+""")
+    s = C.Settings(cp)
+    assert s.dataset.split == (0.8, 0.1, 0.1) and s.dataset.min_N is None and s.dataset.max_N == 500
+    assert s.dataset.exclude == ["a", "b"] and s.dataset.oversample_until is None and s.dataset.external_test == ""
+    assert s.image.shape == (3, 180, 180) and s.image.imagenet_normalization is False
+    assert s.model.weights == "DEFAULT" and s.model.dropout == [(1, 0.5), (2, 0.25)] and s.model.head == (256, 128)
+    assert s.lr_warmup.use is False
+    with pytest.raises(NoOptionError):      # never reached by `augmentations = flip, zoom`, so only an explicit read fails
+        s.image.max_rotation
+    with pytest.raises(NoOptionError):
+        s.lr_warmup.factor_1
+    with pytest.raises(NoSectionError):
+        s.train.max_epochs
+    with pytest.raises(AttributeError):
+        s.image.no_such_key
+    train_t, eval_t = C.get_transforms(cp, s.image.shape)       # flip + zoom only: max_rotation is not needed
+    names = [type(t).__name__ for t in train_t.transforms]
+    assert names == ["Resize", "FlipHorizontal", "FlipVertical", "Zoom", "ToTensor"]
+    assert [type(t).__name__ for t in eval_t.transforms] == ["Resize", "ToTensor"]
+    cp.set("image", "imagenet_normalization", "maybe")
+    with pytest.raises(ValueError, match="Not a boolean"):
+        s.image.imagenet_normalization
+
+
+def test_zero_sum_rounding_restatement_properties():
+    """oracle/zero_sum.py (the CPU restatement the GPU kernel is compared with bit for bit): every output is an fp16
+    number on one side or the other of the weight, the mu-weighted sum of the rounding errors collapses, the squared
+    error of the row hardly grows, exactly representable weights are left alone."""
+    from oracle import zero_sum as oz
+    rng = np.random.default_rng(3)
+    for rows, n, period in ((6, 576, 64), (4, 147, 3), (3, 64, 64)):
+        w = (rng.uniform(-1, 1, (rows, n)) * np.sqrt(6.0 / n)).astype(np.float32)
+        w[0, :4] = [0.0, 0.5, -0.25, 2.0 ** -10]
+        mu = rng.uniform(0.05, 1.0, period).astype(np.float32)
+        q = oz.zero_sum_round(w, mu, period)
+        near = w.astype(np.float16).astype(np.float32)
+        assert np.array_equal(q.astype(np.float16).astype(np.float32), q)
+        assert np.array_equal(q[0, :4], w[0, :4])
+        up = np.nextafter(near.astype(np.float16), np.float16(np.inf)).astype(np.float32)
+        dn = np.nextafter(near.astype(np.float16), np.float16(-np.inf)).astype(np.float32)
+        assert ((q == near) | (q == up) | (q == dn)).all()
+        assert (((q >= w) & (near <= w)) | ((q <= w) & (near >= w)) | (q == near)).all()   # a flip crosses the weight
+        s0, s1 = np.abs(oz.weighted_sum(w, near, mu, period)), np.abs(oz.weighted_sum(w, q, mu, period))
+        assert (s1 <= s0 + 1e-12).all() and np.sqrt((s1 ** 2).mean()) < 0.1 * np.sqrt((s0 ** 2).mean())
+        assert ((q - w) ** 2).sum() <= 1.1 * ((near - w) ** 2).sum()

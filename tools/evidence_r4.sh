@@ -20,7 +20,7 @@ trace() {   # name, mode, extra env assignments...
   local NAME=$1 MODE=$2; shift 2
   rm -rf gpurun_out/prof_${TAG}_${NAME}
   ( for kv in "$@"; do export "$kv"; done
-    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_${NAME} -- python3 bench.py --mode $MODE --no-cpu-baseline --steps 20 --warmup 5 > gpurun_out/${TAG}_${NAME}_under_rocprof.json 2> gpurun_out/${TAG}_${NAME}_rocprof.err )
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${TAG}_${NAME} -- python3 bench.py --mode $MODE --no-cpu-baseline --no-kernel-profile --steps 20 --warmup 5 > gpurun_out/${TAG}_${NAME}_under_rocprof.json 2> gpurun_out/${TAG}_${NAME}_rocprof.err )
   local f=$(find gpurun_out/prof_${TAG}_${NAME} -name "*kernel_stats.csv" | head -1)
   cp "$f" gpurun_out/${TAG}_${NAME}_kernel_stats.csv
   local t=$(find gpurun_out/prof_${TAG}_${NAME} -name "*kernel_trace.csv" | head -1)

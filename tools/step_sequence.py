@@ -6,7 +6,12 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 min_us = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "to_nhwc4" in r["Kernel_Name"]]
+marks = []
+for i, r in enumerate(rows):   # (two eval streams: one conversion per half batch, less than 100 us apart, open one step)
+    if "to_nhwc4" in r["Kernel_Name"]:
+        if marks and int(r["Start_Timestamp"]) - int(rows[marks[-1]]["Start_Timestamp"]) < 100_000 and i - marks[-1] < 4:
+            continue
+        marks.append(i)
 a, b = marks[-3], marks[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 queues = {}
