@@ -251,7 +251,8 @@ int launch_c3(const C3Args& a, hipStream_t s) {
   constexpr int NPB = 8 / WPP, BN = 32 * NPB, BM = 16 * MTW * WPP;
   if (a.Cout % BN) return -3;
   const int rmax = rows_max(BM, a.H, a.W);
-  const size_t lds = (size_t)2 * 8 * (((size_t)rmax * (a.W + 2) * 16 + 255) & ~(size_t)255);
+  // (one 64-channel chunk: one window stage, so two blocks of a CU take turns staging and multiplying)
+  const size_t lds = (size_t)(a.Cin > 64 ? 2 : 1) * 8 * (((size_t)rmax * (a.W + 2) * 16 + 255) & ~(size_t)255);
   if (lds > 160 * 1024) return -3;
   const int units = rmax * (a.W + 2) * 8;
   const int m_tiles = (a.M + BM - 1) / BM, n_tiles = a.Cout / BN;
@@ -263,13 +264,15 @@ int launch_c3(const C3Args& a, hipStream_t s) {
   };
   if (umax <= 4) return go(conv_c3_kernel<NB, MTW, WPP, 4>);
   if (umax <= 8) return go(conv_c3_kernel<NB, MTW, WPP, 8>);
+  if constexpr (MTW <= 6)
+    if (umax <= 12) return go(conv_c3_kernel<NB, MTW, WPP, 12>);
   return -3;
 }
 
 }  // namespace
 
 // cfg: pixel tiles per wave x waves per pair
-int spk_c3_num_configs() { return 8; }
+int spk_c3_num_configs() { return 11; }
 int spk_c3_launch(const C3Args& a, int cfg, hipStream_t s) {
   if (a.Cin % 64 || a.Cout % 64 || a.M <= 0 || a.dt != DT_F16) return -2;
   if ((size_t)a.M * a.Cout * 2 >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull) return -2;
@@ -283,6 +286,10 @@ int spk_c3_launch(const C3Args& a, int cfg, hipStream_t s) {
     case 5: return C3_GO(10, 1);   // 160 px x 256 couts
     case 6: return C3_GO(10, 2);   // 320 px x 128 couts
     case 7: return C3_GO(8, 4);    // 512 px x 64 couts
+    // the 64 / 128-channel layers only (ResNet-50 stages 1 and 2)
+    case 8: return a.Cout >= 256 ? -3 : C3_GO(4, 4);    // 256 px x 64 couts
+    case 9: return a.Cout >= 256 ? -3 : C3_GO(6, 4);    // 384 px x 64 couts
+    case 10: return a.Cout >= 256 ? -3 : C3_GO(7, 2);   // 224 px x 128 couts
     default: return -3;
   }
 #undef C3_GO

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // one LDS stage when the whole K fits in it (1x1 convs with Cin = 64):
   // half the LDS, twice the resident blocks for these HBM-bound layers
-  const int nbuf = a.K > BK ? 2 : 1;
+  // (and for the gated operand, PERSIST == 3: the next tile waits in the staging registers, not in a second stage)
+  const int nbuf = (a.K > BK && PERSIST != 3) ? 2 : 1;
   unsigned char* const sA = smem;                    // [nbuf][BM][128 B]   (DMA: stage s at s*STAGE_BYTES)
   unsigned char* const sB = smem + (DMA ? A_BYTES : nbuf * A_BYTES);   // [nbuf][NB*BN][128 B]
 
@@ -127,7 +128,16 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
 
   // PERSIST == 2 marks the instantiations for tensors whose stored channel count is not the GEMM's padded one
   // (EfficientNet widths); everywhere else the strides are compile-time equal to Cin / Cout and the checks vanish
-  constexpr bool PADC = PERSIST == 2;
+  // PERSIST == 3: PADC plus a per-(image, input channel) gate multiplied into the activation operand on its way from the
+  // staging registers to LDS (register-staged flavour, 1x1 convs): the squeeze-excitation scaling of an MBConv block
+  // applied by the project conv that reads it (spk_set_gate) - x * gate in fp32, rounded to 16 bits, exactly the
+  // tensor se_scale_kernel (effnet.hip) would have written and this kernel then read.
+  constexpr bool PADC = PERSIST >= 2;
+  constexpr bool GATE = PERSIST == 3;
+  static_assert(!GATE || (DMA == 0 && MODE == CONV_MODE_GENERIC), "gated operand: register-staged forward conv only");
+  const float* const gate = GATE ? (const float*)a.pool_y : nullptr;
+  int a_gate[GATE ? A_ITERS : 1];          // gate row of each staged row's image
+  f32x4_t rg[GATE ? A_ITERS : 1][2];       // gates of the tile in the staging registers
   const int cin_s = (PADC && a.cin_s > 0) ? a.cin_s : a.Cin;     // channels per stored input pixel
   const int cout_s = (PADC && a.cout_s > 0) ? a.cout_s : a.Cout;  // channels per stored output pixel
   auto set_tile = [&](int w) {
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         a_h0[i] = (m < a.M) ? h0 : -(1 << 20);
         a_w0[i] = w0;
         a_base[i] = ((img * a.H + h0) * a.W + w0) * cin_s + chunk * 8;
+        if (GATE) a_gate[i] = (img < a.N ? img : a.N - 1) * a.pool_ho;
       }
     }
 #pragma unroll
@@ -241,6 +252,15 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
         const unsigned off = ok ? (unsigned)((a_base[i] + tap_off) * 2) : 0x80000000u;
         put_a(rs, off, ra[i], dA + i * (ROWS_PER_PASS * ROW_BYTES));
       }
+      if (GATE) {
+        // (channel chunks past the stored width were loaded as zeros: any gate will do)
+        const int gc = kc0 + chunk * 8 < cin_s ? kc0 + chunk * 8 : cin_s - 8;
+#pragma unroll
+        for (int i = 0; i < A_ITERS; ++i) {
+          rg[i][0] = *(const f32x4_t*)(gate + a_gate[i] + gc);
+          rg[i][1] = *(const f32x4_t*)(gate + a_gate[i] + gc + 4);
+        }
+      }
       kc0 += BK;
       if (kc0 >= a.Cin) {
         kc0 = 0;
@@ -276,8 +296,15 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
 
   auto store_lds = [&](int buf, const u32x4_t (&ra)[A_ITERS], const u32x4_t (&rb)[B_ITERS]) {
 #pragma unroll
-    for (int i = 0; i < A_ITERS; ++i)
-      *(u32x4_t*)(sA + buf * A_BYTES + lds_off(srow + i * ROWS_PER_PASS, chunk)) = ra[i];
+    for (int i = 0; i < A_ITERS; ++i) {
+      u32x4_t v = ra[i];
+      if (GATE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          v[j] = pack2<DT>(lo_f32<DT>(v[j]) * rg[i][j >> 1][(2 * j) & 3], hi_f32<DT>(v[j]) * rg[i][j >> 1][(2 * j + 1) & 3]);
+      }
+      *(u32x4_t*)(sA + buf * A_BYTES + lds_off(srow + i * ROWS_PER_PASS, chunk)) = v;
+    }
 #pragma unroll
     for (int i = 0; i < B_ITERS; ++i)
       *(u32x4_t*)(sB + buf * B_BYTES + lds_off(srow + i * ROWS_PER_PASS, chunk)) = rb[i];
@@ -485,6 +512,16 @@ __global__ __launch_bounds__(WARPS_M* WARPS_N * 64, DMA == 3 ? 2 : 1) void conv_
       cs = cs + 1 == STAGES ? 0 : cs + 1;
     }
     __builtin_amdgcn_s_barrier();  // tile buffers are reused by the epilogue
+    } else if (PERSIST == 3) {
+      // one LDS stage (half the LDS: more resident blocks, whose phases overlap), the next tile's global loads in flight
+      // in the staging registers while this one is multiplied
+      for (int kt = 0; kt < KT; ++kt) {
+        store_lds(0, ra0, rb0);
+        __syncthreads();
+        if (kt + 1 < KT) issue_loads(kt + 1, ra0, rb0);
+        compute(0);
+        __syncthreads();
+      }
     } else {
       store_lds(0, ra0, rb0);
       __syncthreads();
@@ -684,7 +721,7 @@ int launch_one(const ConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
   const int stages = DMA == 4 ? 1 : ((!DMA || DMA >= 2) ? 2 : (stage <= 32768 ? 4 : (stage <= 49152 ? 3 : 2)));
   const size_t lds_full = stages * stage;
   const int kt = a.K / BKT;
-  const size_t lds = DMA == 3 ? lds_full : (kt < stages ? kt : stages) * stage;  // hybrid: both stages are written
+  const size_t lds = DMA == 3 ? lds_full : (PERSIST == 3 ? 1 : (kt < stages ? kt : stages)) * stage;  // hybrid: both stages are written
   auto k = conv_igemm_kernel<BM, BN, WARPS_M, WARPS_N, MODE, DT, SPLITW, DMA, PERSIST, BKT>;
   static std::atomic<unsigned long long> attr;
   (void)spk_lds_limit_once(attr, (const void*)k, (int)lds_full);
@@ -744,6 +781,13 @@ int launch_cfg(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out) {
     if (a.stats) SPK_GO(CONV_MODE_DGRAD_BNB, DT_BF16, 0);
     SPK_GO(CONV_MODE_DGRAD, DT_BF16, 0);
   }
+  if (a.dt == DT_F16 && a.pool_y) {
+    // gated activation operand (spk_set_gate): the register-staged flavour only
+    if (a.kh != 1 || a.stride != 1 || a.pad != 0 || a.dma != 0) return -3;
+    if (a.splitw) return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, 1, 0, 3>(a, s, m_tiles, n_tiles);
+    return launch_one<BM, BN, WARPS_M, WARPS_N, CONV_MODE_GENERIC, DT_F16, 0, 0, 3>(a, s, m_tiles, n_tiles);
+  }
+  if (a.pool_y) return -2;
   if (a.dt == DT_F16 && (a.cin_s > 0 || a.cout_s > 0)) {
     // stored channels != padded GEMM channels: the three flavours instantiated with the channel checks
 #define SPK_GO_PAD(SW)                                                                                        \
@@ -910,6 +954,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
   if (env_cfg() >= 0 || !autotune_on() || a.cfg >= 0) {
     const int cfg = a.cfg >= 0 ? a.cfg : (env_cfg() >= 0 ? env_cfg() : pick_cfg(a.M, a.Cout));
     if (a.dma < 0 && getenv("SPK_CONV_DMA")) a.dma = atoi(getenv("SPK_CONV_DMA"));  // flavour 0..4
+    if (mode == CONV_MODE_GENERIC && a.pool_y) a.dma = 0;   // gated operand: one flavour
     const int r = launch_with(a, mode, cfg, s, m_tiles_out);
     if (r != -3) return r;
     a.dma = 3;  // the forced flavour does not exist for this tile
@@ -917,7 +962,7 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
   }
   const int pad_cls = a.pad * 16 + (a.cls_ph >= 0 ? 1 + a.cls_ph * 2 + a.cls_pw : 0);
   const TuneKey key(mode, a.dt, a.splitw, a.H, a.W, a.Cin, a.Cout, a.kh, a.stride, pad_cls,
-                    a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y) + 2 * (a.cin_s > 0) + 4 * (a.cout_s > 0));
+                    a.stats != nullptr, (a.res != nullptr && (const void*)a.res != (const void*)a.y) + 2 * (a.cin_s > 0) + 4 * (a.cout_s > 0) + 8 * (mode == CONV_MODE_GENERIC && a.pool_y != nullptr));
   std::pair<int, int> chosen;
   bool have = false;
   {

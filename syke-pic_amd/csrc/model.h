@@ -53,6 +53,10 @@ struct Layer {
   int chained_by = -1;            // that conv: index of the block-closing conv
   bool chained_now = false;       // set by the block-closing conv's launch of the current forward: chain_next is done
   size_t mu_off = 0;              // generic convs: offset of this layer's cin input-channel means in spk_model::act_mean
+  // fp16 eval of an MBConv block: the squeeze-excitation layer computes its gates only and the project 1x1 conv that is
+  // the sole reader of its output multiplies them into its activation operand (conv_igemm.hip, spk_set_gate)
+  int gate_conv = -1;             // squeeze-excitation layer: index of that conv, or -1
+  int gate_from = -1;             // that conv: index of the squeeze-excitation layer
   int64_t nbt = 0;  // num_batches_tracked (host copy; exact int64)
   bool trunk_writer = false;  // output is (or is added to) the residual trunk: stem, block-closing conv, downsample
   bool inner3x3 = false;      // 3x3 conv in the middle of a bottleneck block (reads a 1x1 conv's output)
@@ -89,6 +93,7 @@ struct spk_model {
   bf16_t* wdual = nullptr;     // K-concatenated weight images of the fused (block-closing + shortcut) convs
   float* sdual = nullptr;      // their epilogue factors
   bool fuse_ds = true;         // SPK_FUSE_DS=0 turns the fusion off
+  bool fuse_se = true;         // fp16 eval: squeeze-excitation scaling inside the project conv (SPK_SE_FUSE=0: its own pass)
   int chain = 1;               // conv3 -> next conv1 chaining: 1 where it is faster (timed once per problem), SPK_CHAIN=0 never, 2 always
   bool no_chain_now = false;   // the chain tuner is timing the two-kernel alternative
   std::vector<char> stale;     // per tensor: the last eval forward did not write it (a fused-away shortcut tensor)

@@ -175,6 +175,7 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
   }
   if (const char* e = getenv("SPK_FUSE_STEM_POOL")) m->fuse_stem_pool = atoi(e) != 0;
   if (const char* e = getenv("SPK_FUSE_DS")) m->fuse_ds = atoi(e) != 0;
+  if (const char* e = getenv("SPK_SE_FUSE")) m->fuse_se = atoi(e) != 0;
   for (int oi : order) {
     Layer& L = m->layers[oi];
     const std::string nm = L.d.name, bn = L.d.bn;
@@ -247,7 +248,7 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
         wpack += (size_t)2 * L.d.cout * L.d.cin;
       }
       L.c3_ok = L.mode == CONV_MODE_GENERIC && L.d.k == 3 && L.d.stride == 1 && L.d.pad == 1 && L.cin_p == L.d.cin &&
-                L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 256 == 0;
+                L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 64 == 0;
       if (L.c3_ok) {
         L.wpw_off = wpack;
         wpack += (size_t)2 * L.d.cout * 9 * L.d.cin;
@@ -301,6 +302,23 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     m->n_means += (size_t)L.d.cin;
   }
   m->stale.assign(m->n_tensors, 0);
+  // squeeze-excitation -> project conv pairs whose scaling the conv can apply itself (fp16 eval)
+  for (size_t si = 0; si < m->layers.size(); ++si) {
+    Layer& S = m->layers[si];
+    if (S.d.kind != SPK_OP_SE) continue;
+    int readers = 0, ci = -1;
+    for (size_t j = 0; j < m->layers.size(); ++j) {
+      const Layer& Q = m->layers[j];
+      if (Q.d.src == S.d.dst || (Q.d.kind == SPK_OP_CONV && Q.d.res == S.d.dst)) { ++readers; ci = (int)j; }
+    }
+    if (readers != 1 || S.d.dst == m->layers.back().d.dst) continue;
+    Layer& P = m->layers[ci];
+    if (P.d.kind != SPK_OP_CONV || P.mode != CONV_MODE_GENERIC || P.d.k != 1 || P.d.stride != 1 || P.d.pad != 0 ||
+        P.d.src != S.d.dst)
+      continue;
+    S.gate_conv = ci;
+    P.gate_from = (int)si;
+  }
   if (hipMalloc((void**)&m->act_mean_dev, std::max<size_t>(m->n_means, 8) * 4) != hipSuccess ||
       hipMalloc((void**)&m->wpack, std::max<size_t>(wpack, 8) * 2) != hipSuccess ||
       hipMalloc((void**)&m->dwpack, std::max<size_t>(dwp, 8) * 4) != hipSuccess ||
@@ -1061,6 +1079,12 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   a.splitw = layer_split(m, L);
   a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
   a.w_bytes = (unsigned)((size_t)L.cout_p * L.kpad * 2 * (a.splitw ? 2 : 1));
+  if (L.gate_from >= 0 && m->stale[L.d.src] == 2) {
+    // the squeeze-excitation layer in front left its gates instead of the scaled tensor: read what IT read
+    if (!m->gate_h[m->half]) return fail(SPK_ERR_STATE, std::string("no squeeze-excitation gates for ") + L.d.name);
+    a.x = (const bf16_t*)m->TI(m->layers[L.gate_from].d.src);
+    spk_set_gate(a, m->gate_h[m->half], m->gate_stride_h[m->half]);
+  }
   if (stem_pool_fused(m, L)) {   // the max-pool layer that follows is computed here and skipped below
     const Layer& P = m->layers[L.fuse_pool];
     const TDim& po = m->tdims[P.d.dst];
@@ -1101,7 +1125,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     if (rd != SPK_OK) return rd;
     L.dual_ok = false;
   }
-  if (L.pw_ok && a.dt == DT_F16 && !a.res_lo && !a.y_lo && !a.cin_s && !a.cout_s) {
+  if (L.pw_ok && a.dt == DT_F16 && !a.res_lo && !a.y_lo && !a.cin_s && !a.cout_s && !a.pool_y) {
     PwConvArgs q;
     memset(&q, 0, sizeof q);
     q.x = a.x; q.wp = m->wpack + L.wpw_off; q.y = a.y; q.res = a.res; q.scale = a.scale; q.shift = a.bias;
@@ -1327,10 +1351,16 @@ int spk_run_layer_eval(spk_model* m, Layer& L, int nb) {
       float* partial = m->SE();
       const int chunks = m->dw_chunks_h[m->half];   // as the depthwise launch that just ran
       float* scale = partial + (size_t)nb * chunks * in.c;
-      if (spk_launch_se((const bf16_t*)m->TI(L.d.src), (bf16_t*)m->TI(L.d.dst), partial, chunks, scale, m->P(L.p_w),
-                        m->P(L.p_b), m->dwpack + L.wpack_off, m->P(L.p_b2), nb, in.h * in.w, L.d.cin, in.c, L.d.k,
-                        m->infer_dt, m->stream))
+      // the gates only when the project conv behind this layer multiplies them into its operand (SPK_SE_FUSE=0: never):
+      // the scaled tensor - one read and one write of the widest tensor of the block - is then not materialised
+      const bool gate_only = m->fuse_se && L.gate_conv >= 0 && m->infer_dt == DT_F16 && !m->force_unfused && !m->precise_res;
+      if (spk_launch_se(gate_only ? nullptr : (const bf16_t*)m->TI(L.d.src), gate_only ? nullptr : (bf16_t*)m->TI(L.d.dst),
+                        partial, chunks, scale, m->P(L.p_w), m->P(L.p_b), m->dwpack + L.wpack_off, m->P(L.p_b2), nb,
+                        in.h * in.w, L.d.cin, in.c, L.d.k, m->infer_dt, m->stream))
         return fail(SPK_ERR_UNSUPPORTED, std::string("squeeze-excitation launch failed (fp16 eval only) for ") + L.d.name);
+      m->gate_h[m->half] = gate_only ? scale : nullptr;
+      m->gate_stride_h[m->half] = in.c;
+      if (L.d.dst < (int)m->stale.size()) m->stale[L.d.dst] = gate_only ? 2 : 0;
       return SPK_OK;
     }
     case SPK_OP_MAXPOOL:
@@ -1630,7 +1660,7 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
   const size_t cnt = (size_t)n * d.h * d.w * d.c;
   if ((int64_t)((size_t)n * d.h * d.w * cl) != numel) return fail(SPK_ERR_ARG, "read_activation: size mismatch");
   HIP_TRY(hipSetDevice(m->device));
-  if (t < (int)m->stale.size() && m->stale[t] && m->last_eval_nb > 0) {
+  if (t < (int)m->stale.size() && m->stale[t] == 1 && m->last_eval_nb > 0) {
     // a shortcut conv that the last forward computed inside its block-closing conv: run it alone (its input is still there)
     for (Layer& L : m->layers)
       if (L.d.kind == SPK_OP_CONV && L.d.dst == t) {
@@ -1639,6 +1669,20 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
         m->force_unfused = false;
         if (r != SPK_OK) return r;
       }
+  }
+  if (t < (int)m->stale.size() && m->stale[t] == 2 && m->last_eval_nb > 0) {
+    // a squeeze-excitation output the last forward applied inside the project conv: the depthwise conv in front (for its
+    // pool partial sums) and the layer itself once more, this time writing the scaled tensor
+    for (Layer& S : m->layers)
+      if (S.d.kind == SPK_OP_SE && S.d.dst == t)
+        for (Layer& D : m->layers)
+          if (D.d.kind == SPK_OP_DWCONV && D.d.dst == S.d.src) {
+            m->force_unfused = true;
+            int r = spk_run_layer_eval(m, D, m->last_eval_nb);
+            if (r == SPK_OK) r = spk_run_layer_eval(m, S, m->last_eval_nb);
+            m->force_unfused = false;
+            if (r != SPK_OK) return r;
+          }
   }
   if (t == m->stale_stem_t && m->last_eval_nb > 0) {
     // the last forward computed stem + max-pool in one kernel and never wrote this tensor: run the stem layer alone
@@ -1782,7 +1826,7 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
       by = in_b + out_b;
       if (L.d.kind == SPK_OP_DWCONV || L.d.kind == SPK_OP_SE) {
         if (L.d.kind == SPK_OP_DWCONV) fl = 2.0 * nb * o.h * o.w * (double)L.d.cout * L.d.k * L.d.k;
-        else by = 3 * in_b;  // pooled once, read and written once by the scale pass
+        else by = L.d.dst < (int)m->stale.size() && m->stale[L.d.dst] == 2 ? 0.0 : 3 * in_b;  // pooled once, read and written once by the scale pass (none: gates only)
         snprintf(nm, sizeof nm, "%s", L.d.name);
       } else
       snprintf(nm, sizeof nm, "%s@base.%d",

@@ -135,6 +135,15 @@ static inline void spk_set_bnb(ConvArgs& a, float* partials, const bf16_t* raw, 
   a.y_lo = (bf16_t*)res_bits;
 }
 
+// Forward 1x1 conv (fp16 eval) whose activation operand is x[n, h, w, c] * gate[n * gate_stride + c]: the squeeze-
+// excitation scaling of an MBConv block, applied where the project conv stages its operand (fp32 product rounded to 16
+// bits - the tensor the stand-alone scale pass would have written).  The stem-only pooling fields carry the operands
+// (the struct - and with it every other kernel's code - stays as it was).
+static inline void spk_set_gate(ConvArgs& a, const float* gate, int gate_stride) {
+  a.pool_y = (bf16_t*)gate;
+  a.pool_ho = gate_stride;
+}
+
 // returns 0 on success; fills *m_tiles with the number of row tiles used
 // (needed to size/finalize the stats partials)
 int spk_conv_launch(const ConvArgs& a, int mode, hipStream_t s, int* m_tiles_out);

@@ -21,6 +21,9 @@ SHAPES = [
     (4, 3, 5, 128, 512),       # maps smaller than a pixel tile: every tile spans images
     (2, 1, 1, 64, 256),        # 1x1 maps: only the centre tap is inside the image
     (1, 56, 56, 64, 256),
+    (3, 56, 56, 64, 64),       # ResNet-50 stage 1 (one 64-channel chunk: one window stage, 64-cout blocks)
+    (5, 28, 28, 128, 128),     # stage 2
+    (2, 10, 6, 64, 128),
 ]
 
 

@@ -1,0 +1,10 @@
+#!/bin/bash
+mkdir -p gpurun_out/r4se
+timeout -k 10 600 python -m pytest tests/test_gpu_effnet.py -q -x -m gpu -k "squeeze or golden" > gpurun_out/r4se/test2.txt 2>&1
+grep -v amdgpu.ids gpurun_out/r4se/test2.txt | tail -5
+export SPK_TUNE_CACHE=$PWD/gpurun_out/r4se/tune2.txt
+for net in efficientnet_b4 efficientnet_b0; do for f in 1; do
+  SPK_SE_FUSE=$f timeout -k 10 300 python bench.py --network $net --batch 128 --precision mixed --mode infer --no-cpu-baseline --layers-out gpurun_out/r4se/layers2_${net}_f$f.json > gpurun_out/r4se/bench2_${net}_f$f.json 2>gpurun_out/r4se/bench2_${net}_f$f.err
+  python -c "
+import json; d=json.load(open('gpurun_out/r4se/bench2_${net}_f$f.json')); print('$net SE_FUSE=$f', d['value'], d['ms_per_step'])"
+done; done
