@@ -248,7 +248,7 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
         wpack += (size_t)2 * L.d.cout * L.d.cin;
       }
       L.c3_ok = L.mode == CONV_MODE_GENERIC && L.d.k == 3 && L.d.stride == 1 && L.d.pad == 1 && L.cin_p == L.d.cin &&
-                L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 64 == 0;
+                L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 256 == 0;
       if (L.c3_ok) {
         L.wpw_off = wpack;
         wpack += (size_t)2 * L.d.cout * 9 * L.d.cin;

@@ -78,28 +78,41 @@ __global__ void maxpool_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict_
   }
 }
 
-// one thread = 8 channels of one image; fp32 mean over hw pixels
+// block = 64 channel groups (8 channels each) of one image x 4 pixel slices: thread (q, cc) sums pixels q, q+4, ... in fp32,
+// the four slice sums are added in index order through LDS (a fixed grouping: an image's mean does not depend on the
+// batch it is in).  One thread walking all hw pixels of its channels (rounds 1-3) kept 12 % of the CUs busy on the 7x7
+// maps of a 128-image half batch with a 49-deep load chain each: 31 us for 26 MB.
 template <int DT>
-__global__ void gavgpool_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int n, int hw,
-                                int c) {
+__global__ __launch_bounds__(256) void gavgpool_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int n, int hw,
+                                                       int c) {
+  __shared__ float part[4][64][9];
   const int c8 = c >> 3;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * c8) return;
-  const int img = i / c8, cc = i % c8;
+  const int img = blockIdx.y, cc = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
   float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bf16_t* p = x + (size_t)img * hw * c + cc * 8;
-  for (int t = 0; t < hw; ++t) {
-    const u32x4_t v = *(const u32x4_t*)(p + (size_t)t * c);
+  if (cc < c8) {
+    const bf16_t* p = x + (size_t)img * hw * c + cc * 8;
+#pragma unroll 4
+    for (int t = q; t < hw; t += 4) {
+      const u32x4_t v = *(const u32x4_t*)(p + (size_t)t * c);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s[2 * j] += lo_f32<DT>(v[j]);
-      s[2 * j + 1] += hi_f32<DT>(v[j]);
+      for (int j = 0; j < 4; ++j) {
+        s[2 * j] += lo_f32<DT>(v[j]);
+        s[2 * j + 1] += hi_f32<DT>(v[j]);
+      }
     }
   }
-  const float inv = 1.0f / (float)hw;
-  float* o = y + (size_t)img * c + cc * 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = s[j] * inv;
+  for (int j = 0; j < 8; ++j) part[q][threadIdx.x & 63][j] = s[j];
+  __syncthreads();
+  // 512 outputs of the block, two per thread
+  const float inv = 1.0f / (float)hw;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int o = threadIdx.x + h * 256, g = o >> 3, j = o & 7;
+    const int gc = blockIdx.x * 64 + g;
+    if (gc < c8)
+      y[(size_t)img * c + gc * 8 + j] = (((part[0][g][j] + part[1][g][j]) + part[2][g][j]) + part[3][g][j]) * inv;
+  }
 }
 
 __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var,
@@ -193,11 +206,10 @@ int spk_launch_maxpool(const bf16_t* x, bf16_t* y, int n, int h, int w, int c, i
 
 int spk_launch_gavgpool(const bf16_t* x, float* y, int n, int hw, int c, int dt, hipStream_t s) {
   if (c % 8) return -1;
-  const int total = n * (c / 8);
-  const int g = (total + 255) / 256;
+  const dim3 g((c / 8 + 63) / 64, n);
   DT_DISPATCH(dt,
-              hipLaunchKernelGGL(gavgpool_kernel<DT_BF16>, dim3(g), dim3(256), 0, s, x, y, n, hw, c),
-              hipLaunchKernelGGL(gavgpool_kernel<DT_F16>, dim3(g), dim3(256), 0, s, x, y, n, hw, c));
+              hipLaunchKernelGGL(gavgpool_kernel<DT_BF16>, g, dim3(256), 0, s, x, y, n, hw, c),
+              hipLaunchKernelGGL(gavgpool_kernel<DT_F16>, g, dim3(256), 0, s, x, y, n, hw, c));
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
