@@ -38,6 +38,29 @@ __global__ void to_nhwc4_kernel(const T* __restrict__ x, bf16_t* __restrict__ ou
   }
 }
 
+// float NCHW planes, w % 4 == 0 (the benched 224x224 input): one thread = four pixels of a row - three 16-byte loads, two
+// 16-byte stores, 32-bit index arithmetic (blockIdx.y = image).  The general kernel above spends its time on three 64-bit
+// divisions per pixel: 3.7 TB/s on the 256 x 3 x 224 x 224 batch against ~5 for a copy.
+template <int DT>
+__global__ __launch_bounds__(256) void to_nhwc4_planes_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, int c,
+                                                              int hw, float mul) {
+  const int q = blockIdx.x * 256 + threadIdx.x;   // group of four pixels inside the image
+  if (q * 4 >= hw) return;
+  const float* xi = x + (size_t)blockIdx.y * c * hw + q * 4;
+  f32x4_t v[3];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) v[ch] = ch < c ? *(const f32x4_t*)(xi + (size_t)ch * hw) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+  u32x4_t o[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    o[p >> 1][(p & 1) * 2] = pack2<DT>(v[0][p] * mul, v[1][p] * mul);
+    o[p >> 1][(p & 1) * 2 + 1] = pack2<DT>(v[2][p] * mul, 0.f);
+  }
+  u32x4_t* d = (u32x4_t*)(out + ((size_t)blockIdx.y * hw + q * 4) * 4);
+  d[0] = o[0];
+  d[1] = o[1];
+}
+
 template <int DT>
 __device__ __forceinline__ void max8(u32x4_t& acc, const u32x4_t v) {
 #pragma unroll
@@ -181,6 +204,13 @@ int spk_launch_to_nhwc4(const void* x, int layout, int dtype, int n, int c, int 
   const int wp = (w + 1) & ~1;
   const size_t total = (size_t)n * h * wp;
   const int g = grid_for(total, 256);
+  if (dtype == 0 && layout == 0 && c <= 3 && w % 4 == 0 && n <= 65535 && ((size_t)x & 15) == 0) {
+    const dim3 gp((h * w / 4 + 255) / 256, n);
+    DT_DISPATCH(dt,
+                hipLaunchKernelGGL(to_nhwc4_planes_kernel<DT_BF16>, gp, dim3(256), 0, s, (const float*)x, out, c, h * w, scale),
+                hipLaunchKernelGGL(to_nhwc4_planes_kernel<DT_F16>, gp, dim3(256), 0, s, (const float*)x, out, c, h * w, scale));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   if (dtype == 0) {
     if (layout == 0) launch_to_nhwc4<float, false>(x, out, n, c, h, w, wp, dt, g, s, scale);
     else launch_to_nhwc4<float, true>(x, out, n, c, h, w, wp, dt, g, s, scale);
