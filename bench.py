@@ -65,7 +65,8 @@ def parse():
     args = ap.parse_args()
     if args.precision is None:
         # the fastest mode that holds the parity tolerance: ResNets - calibrated single pass (tests/test_gpu_calibrated.py);
-        # EfficientNets - the fp16 split rule (their 1x1 convs wait for HBM: one weight pass or two makes no difference)
+        # EfficientNets - `mixed`, which splits none of their convs (the weight rounding does not show beside the fp16
+        # rounding of their activations: tests/diagnostics/effnet_calibrated.py)
         args.precision = "mixed" if args.network.startswith("efficientnet") else "calibrated"
     return args
 

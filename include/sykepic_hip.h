@@ -146,7 +146,10 @@ int spk_model_set_infer_dtype(spk_model* m, int bf16);
  * precise_residual = 0).  split_weights = 2 splits only the convs that write
  * the residual trunk (stem, block-closing convs, downsample branches);
  * split_weights = 3 splits every conv except the 3x3 convs inside a residual
- * block (the lo-products that buy the least accuracy per MFMA cycle).
+ * block (the lo-products that buy the least accuracy per MFMA cycle) - and, on
+ * the EfficientNet graphs, no conv at all: their error is the fp16 rounding of
+ * the stored activations, the weight rounding does not show beside it
+ * (tests/diagnostics/effnet_calibrated.py; 1 still splits every conv).
  * split_weights = 1: every conv weight is carried as
  * hi + lo fp16 halves and both products are accumulated (2x MFMA work, weight
  * rounding error ~2^-22) — weight rounding is the dominant logit error at
