@@ -1,0 +1,30 @@
+#!/bin/bash
+# The counter half of tools/evidence_r4.sh alone (its first run of the final sources stopped in tools/pmc_traffic.py: the
+# step marks were matched on a kernel name that the input conversion no longer has).  Same box = same call as nothing else.
+set -e
+TAG=r04
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+export SPK_TUNE_CACHE=$PWD/gpurun_out/tune_${TAG}.txt
+rm -f $SPK_TUNE_CACHE
+python3 bench.py --mode both --no-cpu-baseline --steps 3 --warmup 2 > gpurun_out/${TAG}_warm.json 2> gpurun_out/${TAG}_warm.err
+export SPK_EVAL_STREAMS=1
+export SPK_WGRAD_STREAM=0
+for MODE in infer train; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/pmc_${TAG}_${MODE}_$C
+    rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_${TAG}_${MODE}_$C -- python3 bench.py --mode $MODE --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_${TAG}_${MODE}_$C.err
+    echo "pmc $MODE $C done"
+  done
+  F=$(find gpurun_out/pmc_${TAG}_${MODE}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+  W=$(find gpurun_out/pmc_${TAG}_${MODE}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  NAME=$([ $MODE = infer ] && echo infer_calibrated || echo train_bf16)
+  python3 tools/pmc_traffic.py "$F" "$W" gpurun_out/${TAG}_pmc_traffic_${NAME}.json $MODE > gpurun_out/${TAG}_pmc_traffic_${MODE}.log
+  rm -rf gpurun_out/pmc_${TAG}_${MODE}_FETCH_SIZE gpurun_out/pmc_${TAG}_${MODE}_WRITE_SIZE
+done
+rm -rf gpurun_out/pmc_${TAG}_sq
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_${TAG}_sq -- python3 bench.py --mode infer --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> gpurun_out/pmc_${TAG}_sq.err
+S=$(find gpurun_out/pmc_${TAG}_sq -name "*counter_collection.csv" | head -1)
+python3 tools/pmc_mfma.py "$S" gpurun_out/${TAG}_pmc_mfma_util_infer_calibrated.json > gpurun_out/${TAG}_pmc_mfma.log
+rm -rf gpurun_out/pmc_${TAG}_sq
+tail -n 4 gpurun_out/${TAG}_pmc_traffic_infer.log; tail -n 4 gpurun_out/${TAG}_pmc_mfma.log

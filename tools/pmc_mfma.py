@@ -15,7 +15,7 @@ for r in rows:
     d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"]})
     d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(disp)
-marks = [i for i in ids if "to_nhwc4_kernel" in disp[i]["name"]]
+marks = [i for i in ids if "to_nhwc4" in disp[i]["name"]]
 seg = [i for i in ids if marks[-2] <= i < marks[-1]]
 agg, n = collections.defaultdict(float), 0
 for i in seg:

@@ -44,7 +44,7 @@ def _git_head():
 def one_pass(path):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    marks = [i for i, r in enumerate(rows) if "to_nhwc4_kernel" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "to_nhwc4" in r["Kernel_Name"]]
     return rows[marks[-2]:marks[-1]]
 
 
@@ -53,8 +53,8 @@ def main():
     mode = sys.argv[4] if len(sys.argv) > 4 else "infer"
     f, w = one_pass(fetch), one_pass(write)
     is_conv = lambda r: any(k in r["Kernel_Name"] for k in KERNELS[mode])   # noqa: E731
-    cal_f = [float(r["Counter_Value"]) for r in f if "to_nhwc4_kernel" in r["Kernel_Name"]]
-    cal_w = [float(r["Counter_Value"]) for r in w if "to_nhwc4_kernel" in r["Kernel_Name"]]
+    cal_f = [float(r["Counter_Value"]) for r in f if "to_nhwc4" in r["Kernel_Name"]]
+    cal_w = [float(r["Counter_Value"]) for r in w if "to_nhwc4" in r["Kernel_Name"]]
     conv_f = [float(r["Counter_Value"]) for r in f if is_conv(r)]
     conv_w = [float(r["Counter_Value"]) for r in w if is_conv(r)]
     per_kernel = {}
