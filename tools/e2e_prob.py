@@ -37,6 +37,13 @@ cfg = (ROOT / "tests/golden/ref_data/config.ini").read_text().replace("network =
 (model / "config.ini").write_text(cfg)
 Args = namedtuple("Args", "raw samples image_dir images model out batch_size num_workers force")
 import os
+if os.environ.get("E2E_CALIBRATE"):
+    # what `sykepic calibrate -m MODEL -r RAW -n 2048` does: act_means.pth beside best_state.pth, after which `prob` runs
+    # the calibrated single-pass mode
+    CArgs = namedtuple("CArgs", "raw samples image_dir images model batch_size num_images")
+    t0 = time.perf_counter()
+    n_cal = prob.calibrate_call(CArgs(str(raw), None, None, None, str(model), 256, 2048))
+    print(f"calibrated on {n_cal} ROIs in {time.perf_counter() - t0:.2f} s", flush=True)
 for bs in (64, 512):
     out = tmp / f"out{bs}"
     prof = None
