@@ -78,7 +78,8 @@ class GradSync:
     """All-reduce of the library's flat gradient buffer.
 
     overlap=True (opt-in with SPK_DP_OVERLAP=1 until one RCCL run on >= 2 GPUs has shown gradients bit-equal to the
-    plain path - the builder's boxes have one GPU): the buffer is reduced in up to three slices
+    plain path - the builder's boxes have one GPU, where the mechanism itself runs over a one-rank RCCL group:
+    tests/test_gpu_dp.py): the buffer is reduced in up to three slices
     that the library reports back to front while the backward pass is still running (head + last stage first, the
     stem last; `spk_model_set_grad_ready_callback`): each slice's collective is enqueued on a communication
     stream behind an event, so the 96 MB of ResNet-50 gradients cross xGMI underneath the remaining dgrad / wgrad
@@ -95,9 +96,12 @@ class GradSync:
             self.flat = torch.as_tensor(_DevicePtr(ptr, numel), device=net.device)
         self._works, self._cb, self._comm = [], None, None
         self._covered, self._err = 0, None
+        self.waited = 0          # collectives the last all_reduce() waited for (overlapped path)
         if overlap is None:
             overlap = self.world > 1 and view is None and os.environ.get("SPK_DP_OVERLAP", "0") == "1"
-        if overlap and view is None and self.world > 1:
+        # (an explicit overlap=True installs the hook for a one-rank group too: tests/test_gpu_dp.py drives the whole
+        # mechanism - callback, communication stream, RCCL collectives, waits - on the single test GPU that way)
+        if overlap and view is None and dist is not None and dist.is_initialized():
             self._install(buckets)
 
     def _install(self, buckets):
@@ -133,19 +137,19 @@ class GradSync:
             self._cb = None
 
     def all_reduce(self, optimizer=None):
-        if self.world > 1:
-            if self._cb is not None:
-                works, covered, err = self._works, self._covered, self._err
-                self._works, self._covered, self._err = [], 0, None
-                if err is not None:
-                    raise RuntimeError("gradient all-reduce failed inside the backward pass") from err
-                if covered != self.flat.numel():   # the reported slices must tile the buffer exactly once
-                    raise RuntimeError(f"overlapped all-reduce covered {covered} of {self.flat.numel()} gradient "
-                                       "elements")
-                for w in works:     # makes the current stream wait for each collective
-                    w.wait()
-            else:
-                self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+        if self._cb is not None:
+            works, covered, err = self._works, self._covered, self._err
+            self._works, self._covered, self._err = [], 0, None
+            if err is not None:
+                raise RuntimeError("gradient all-reduce failed inside the backward pass") from err
+            if covered != self.flat.numel():   # the reported slices must tile the buffer exactly once
+                raise RuntimeError(f"overlapped all-reduce covered {covered} of {self.flat.numel()} gradient "
+                                   "elements")
+            for w in works:     # makes the current stream wait for each collective
+                w.wait()
+            self.waited = len(works)
+        elif self.world > 1:
+            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
 

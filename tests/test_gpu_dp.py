@@ -217,3 +217,58 @@ def test_tune_cache_persists_and_is_reused(tmp_path):
     assert not any(t in second.stderr for t in ("[spk tune]", "[spk tune 1x1]", "[spk tune 3x3]"))
     assert cache.read_text().splitlines() == lines              # nothing re-tuned, nothing appended
     assert np.array_equal(np.load(tmp_path / "a.npy"), np.load(tmp_path / "b.npy"))
+
+
+_ONE_RANK_RCCL = r"""
+import sys
+import numpy as np, torch, torch.distributed as dist
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/syke-pic_amd"]
+from sykepic_hip import arch, synth
+from sykepic_hip.dp import GradSync
+from sykepic_hip.net import HipNet
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], world_size=1, rank=0)
+g = arch.build_graph("resnet18", 10)
+sd = synth.synth_state_dict(arch.param_specs(g), seed=5, logit_gain=2.0)
+net = HipNet("resnet18", 10, weights=None)
+net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+x = torch.from_numpy(synth.synth_images(8, 3, 64, 64, seed=10)).cuda()
+y = torch.from_numpy(synth.synth_labels(8, 10, seed=11)).cuda()
+net.train()
+net.forward_backward(x, y)
+plain = GradSync(net, dist, overlap=False)
+plain.all_reduce()
+torch.cuda.synchronize()
+base = plain.flat.clone()
+sync = GradSync(net, dist, overlap=True)
+assert sync.overlapped
+for _ in range(3):
+    net.forward_backward(x, y)
+    sync.all_reduce()
+    torch.cuda.synchronize()
+    assert sync.waited == 3, sync.waited
+    assert torch.equal(sync.flat, base), float((sync.flat - base).abs().max())
+sync.close()
+assert not sync.overlapped
+net.forward_backward(x, y)
+sync.all_reduce()
+torch.cuda.synchronize()
+assert torch.equal(sync.flat, base)
+dist.destroy_process_group()
+print("ONE_RANK_RCCL_OK", int(base.numel()))
+"""
+
+
+def test_overlapped_all_reduce_runs_over_rccl_with_one_rank(tmp_path):
+    """The overlapped gradient exchange (dp.GradSync(overlap=True): the library reports three slices of the flat
+    gradient buffer back to front while the backward pass runs, each slice's all-reduce is enqueued on a communication
+    stream behind an event, all_reduce() waits for them) executed for real over RCCL - with the one rank this box
+    allows (two ranks on one device are refused; the 2-rank tests use gloo and cannot take this path, which needs device
+    tensors).  A one-rank sum is the identity: the gradients must come back bit for bit, every step, with exactly three
+    collectives waited for, and the plain path must work again after close().  What one rank cannot show is the
+    cross-rank sum itself: that is the driver's 2 / 4 / 8-GPU run (`params_equal` in the bench line)."""
+    script = tmp_path / "one_rank.py"
+    script.write_text(_ONE_RANK_RCCL)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), str(ROOT), str(_free_port())], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "ONE_RANK_RCCL_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
