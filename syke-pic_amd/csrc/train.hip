@@ -470,6 +470,9 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                     ", " + std::to_string(o.w) + "] at " + L.d.bn);
   }
   m->act_dt = DT_BF16;
+  // every activation is really written by this pass: spk_model_read_activation must not "recompute" tensors that an earlier
+  // EVAL forward on this handle left to a fused kernel (stem + pool, shortcut conv, squeeze-excitation scaling)
+  m->last_eval_nb = 0;
   float* part = (float*)((char*)t->arena + t->part_off);
   float* coef = (float*)((char*)t->arena + t->coef_off);
   float* tmp = (float*)((char*)t->arena + t->tmp_off);

@@ -530,3 +530,29 @@ def test_weights_argument_loads_a_local_backbone_checkpoint(tmp_path):
     assert float(sd["head.0.weight"].abs().max()) <= 512 ** -0.5 + 1e-7
     with pytest.raises(RuntimeError, match="not a resnet50 backbone"):
         HipNet("resnet50", 4, weights=str(path))
+
+
+@pytest.mark.parametrize("network,hw", [("resnet50", 64), ("efficientnet_b0", 64)])
+def test_activations_read_after_a_train_step_are_the_train_steps(network, hw):
+    """The eval path leaves some tensors to fused kernels (stem + max-pool, the shortcut conv inside the block-closing conv,
+    the squeeze-excitation scaling inside the project conv) and `read_activation` recomputes them on demand from the last
+    EVAL forward.  After a TRAINING pass on the same handle every tensor has really been written - in train mode, with
+    batch statistics - and must be returned as it is: an eval forward, then a train step, then every activation must
+    equal what a handle that never ran eval returns (the train step is bitwise reproducible)."""
+    n, classes = 6, 10
+    g, specs, ref, net = _pair(network, classes, seed=5)
+    _, _, _, fresh = _pair(network, classes, seed=5)
+    x = torch.from_numpy(synth.synth_images(n, 3, hw, hw, seed=10)).cuda()
+    y = torch.from_numpy(synth.synth_labels(n, classes, seed=11)).cuda()
+    net.eval()
+    p = net.probabilities(x)
+    assert torch.isfinite(p).all()
+    from oracle import graph_eval
+    shapes = {t: tuple(v.shape) for t, v in graph_eval.run(g, _torch_state(ref), x.cpu(), train=True).items()}
+    for h in (net, fresh):
+        h.train()
+        h.reset_stats()
+        h.forward_backward(x, y)
+    for op in g.ops:
+        a, b = net.read_activation(op.dst, n, shapes[op.dst]), fresh.read_activation(op.dst, n, shapes[op.dst])
+        assert torch.equal(a, b), f"{op.name or op.kind}: read back differs after an earlier eval forward"
