@@ -274,15 +274,22 @@ def test_squeeze_excitation_scaling_inside_the_project_conv_changes_no_bit(monke
     monkeypatch.setenv("SPK_SE_FUSE", "0")
     plain = _hipnet(network, sd)
     monkeypatch.delenv("SPK_SE_FUSE")
+    se_ops = [op for op in g.ops if op.kind == arch.OP_SE]
+    assert len(se_ops) == 16
     for nb in (n, 9):     # two streams (after the tuning pass) and a small single-stream batch
         pf = [fused.probabilities(x[:nb]).cpu() for _ in range(2)][-1]
         pp = [plain.probabilities(x[:nb]).cpu() for _ in range(2)][-1]
         assert torch.isfinite(pf).all()
         assert torch.equal(pf, pp), float((pf - pp).abs().max())
+        if nb == n:       # recomputed for the whole batch after a two-stream forward (both halves' images)
+            op = se_ops[5]
+            t = graph_eval.run(g, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, x[:1].cpu())[op.dst]
+            shape = (nb,) + tuple(t.shape[1:])
+            a, b = fused.read_activation(op.dst, nb, shape), plain.read_activation(op.dst, nb, shape)
+            assert torch.equal(a, b) and float(a[nb // 2:].abs().sum()) > 0
+            assert torch.equal(fused.probabilities(x[:nb]).cpu(), pf)       # and the next forward is undisturbed
     # the scaled tensors themselves: never written by the fused forward, recomputed when asked for
     acts = graph_eval.run(g, {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, x[:9].cpu())
-    se_ops = [op for op in g.ops if op.kind == arch.OP_SE]
-    assert len(se_ops) == 16
     for op in (se_ops[0], se_ops[7], se_ops[-1]):
         ref = acts[op.dst]
         got_f = fused.read_activation(op.dst, 9, tuple(ref.shape))
