@@ -140,9 +140,38 @@ def _default_tune_cache():
         d = os.path.join(base, "sykepic_hip")
         os.makedirs(d, exist_ok=True)
         if os.access(d, os.W_OK):
-            os.environ["SPK_TUNE_CACHE"] = os.path.join(d, f"tune-{st.st_size:x}-{int(st.st_mtime):x}.txt")
+            path = os.path.join(d, f"tune-{st.st_size:x}-{int(st.st_mtime):x}.txt")
+            os.environ["SPK_TUNE_CACHE"] = path
+            seed_tune_cache(path)
     except OSError:
         pass   # no writable cache directory: tune per process
+
+
+TUNE_SEED = Path(__file__).resolve().parent / "tune_seed_gfx950.txt"
+
+
+def seed_tune_cache(path, seed=None):
+    """A tuning cache that does not exist yet starts as a copy of the winners measured on one MI355X for the shapes of
+    the shipped benchmarks (`tune_seed_gfx950.txt`: comment lines are skipped by the loaders): the first `sykepic prob`
+    of a fresh installation then times nothing for those shapes; every other problem is tuned on first use and appended,
+    as before.  Every candidate of a problem computes the same values, so a seed can only cost speed on a machine that
+    would have chosen differently.  `SPK_TUNE_SEED=0` starts from an empty cache.  Returns True when it wrote the file."""
+    import os
+    seed = Path(seed) if seed is not None else TUNE_SEED
+    if os.environ.get("SPK_TUNE_SEED", "1").strip().lower() in ("0", "off", "no") or os.path.exists(path) or not seed.is_file():
+        return False
+    tmp = f"{path}.{os.getpid()}.tmp"
+    try:
+        with open(tmp, "w") as f:
+            f.write(seed.read_text())
+        os.replace(tmp, path)      # atomic: ranks of one job race for the same file, any winner is complete
+        return True
+    except OSError:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        return False
 
 
 def load():

@@ -514,3 +514,34 @@ def test_zero_sum_rounding_restatement_properties():
         s0, s1 = np.abs(oz.weighted_sum(w, near, mu, period)), np.abs(oz.weighted_sum(w, q, mu, period))
         assert (s1 <= s0 + 1e-12).all() and np.sqrt((s1 ** 2).mean()) < 0.1 * np.sqrt((s0 ** 2).mean())
         assert ((q - w) ** 2).sum() <= 1.1 * ((near - w) ** 2).sum()
+
+
+def test_a_new_tuning_cache_starts_from_the_shipped_seed(tmp_path, monkeypatch):
+    """lib.seed_tune_cache: a per-build tuning cache that does not exist yet is created as a copy of the shipped winners
+    (one MI355X, the benchmark shapes); an existing cache is never touched; SPK_TUNE_SEED=0 starts empty.  Every line of
+    the seed is a comment or one of the record kinds the C loaders parse (conv / wgrad / pw1x1 / pw2 / c3 / chain), with
+    choices inside the ranges the loaders accept."""
+    from sykepic_hip import lib
+    assert lib.TUNE_SEED.is_file()
+    kinds = {}
+    for line in lib.TUNE_SEED.read_text().splitlines():
+        if not line or line.startswith("#"):
+            continue
+        f = line.split()
+        kinds[f[0]] = kinds.get(f[0], 0) + 1
+        assert f[0] in ("conv", "wgrad", "pw1x1", "pw2", "c3", "chain"), line
+        assert all(v.lstrip("-").isdigit() for v in f[1:]), line
+        if f[0] == "conv":
+            assert len(f) == 16 and 0 <= int(f[14]) <= 6 and 0 <= int(f[15]) <= 6, line
+        if f[0] == "chain":
+            assert int(f[-1]) in (0, 1), line
+        assert len(line) < 250          # the loaders read lines into 256-byte buffers
+    assert kinds.get("conv", 0) > 50 and "pw1x1" in kinds
+    target = tmp_path / "tune-x.txt"
+    assert lib.seed_tune_cache(str(target)) is True
+    assert target.read_text() == lib.TUNE_SEED.read_text()
+    target.write_text("conv 0 1 0 1 2 3 4 5 6 7 8 9 10 0 0\n")
+    assert lib.seed_tune_cache(str(target)) is False and target.read_text().startswith("conv 0 1 0 1 2")
+    monkeypatch.setenv("SPK_TUNE_SEED", "0")
+    other = tmp_path / "tune-y.txt"
+    assert lib.seed_tune_cache(str(other)) is False and not other.exists()
