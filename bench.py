@@ -138,9 +138,17 @@ def host_cores():
     return max(1, min(cores, 64))
 
 
-def cpu_baseline(network, classes, size, mode, budget_s):
+PARITY_N = 32          # images of the timed batch that the oracle classifies too (the cpu_baseline leg's batch)
+PARITY_TOL = 1e-3      # north_star: probabilities within 1e-3 of the CPU reference
+TRAIN_LOSS_TOL = 2e-2  # bf16 training forward vs the fp32 oracle: relative loss error (tests/test_gpu_train.py bounds)
+TRAIN_LOGIT_TOL = 8e-2  # ... relative L2 of the logits
+
+
+def cpu_baseline(network, classes, size, mode, budget_s, x=None, y=None):
     """The reference's CPU path (torch fp32 NCHW kernels driven by the
-    net_pass / train-step logic) timed on this host; oracle = its restatement."""
+    net_pass / train-step logic) timed on this host; oracle = its restatement.
+    `x`, `y`: the first PARITY_N images / labels of the timed batch (host tensors).  Returns (record, reference outputs of
+    the first step on those images): probabilities for infer, (loss, logits) of the un-trained net for train."""
     from oracle import refnet
     from sykepic_hip import arch, synth
     cores = host_cores()
@@ -149,16 +157,19 @@ def cpu_baseline(network, classes, size, mode, budget_s):
     g = arch.build_graph(network, classes)
     sd = synth.synth_state_dict(arch.param_specs(g), seed=2)
     net = refnet.load_numpy_state(refnet.RefNet(network, classes), sd)
-    bs = 32
-    x = torch.from_numpy(synth.synth_images(bs, 3, size, size, seed=0))
-    y = torch.from_numpy(synth.synth_labels(bs, classes, seed=1))
+    bs = PARITY_N
+    if x is None:
+        x = torch.from_numpy(synth.synth_images(bs, 3, size, size, seed=0))
+        y = torch.from_numpy(synth.synth_labels(bs, classes, seed=1))
     if mode == "train":
         net.train()
         opt = torch.optim.Adam(net.parameters(), lr=1e-4)
         step = lambda: refnet.train_step(net, opt, x, y)  # noqa: E731
     else:
         step = lambda: refnet.probabilities(net, x)  # noqa: E731
-    step()  # warm-up
+    first = step()  # warm-up; its outputs are the parity reference
+    if mode == "train":
+        first = (first[0], first[2])
     t0 = time.perf_counter()
     iters = 0
     while True:
@@ -170,7 +181,32 @@ def cpu_baseline(network, classes, size, mode, budget_s):
     return {"value": round(bs * iters / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
             "cpu_model": cpu_model(),
             "sample": f"{iters} x batch {bs} of {network} {mode} fp32 NCHW on host CPU "
-                      f"({iters * bs} images, {dt:.1f} s)"}
+                      f"({iters * bs} images, {dt:.1f} s)"}, first
+
+
+def infer_parity(p_gpu, p_ref):
+    """max |p_gpu - p_cpu| and top-1 agreement of the TIMED precision mode, recorded in the same
+    run.  p_gpu: rows of the timed batch's forward (two streams, as timed); p_ref: the oracle on the same images."""
+    p_gpu, p_ref = p_gpu.double().cpu().numpy(), p_ref.double().numpy()
+    top = np.sort(p_ref, axis=1)
+    decided = top[:, -1] - top[:, -2] > 2 * PARITY_TOL      # a margin the tolerance cannot flip
+    agree = p_gpu.argmax(1) == p_ref.argmax(1)
+    err = float(np.abs(p_gpu - p_ref).max())
+    return {"max_abs_dp": float(f"{err:.3e}"), "top1_agree": round(float(agree.mean()), 4),
+            "top1_agree_decided": round(float(agree[decided].mean()), 4) if decided.any() else None,
+            "n": int(p_ref.shape[0]), "n_decided": int(decided.sum()), "tol": PARITY_TOL,
+            "ok": bool(err <= PARITY_TOL and agree[decided].all())}
+
+
+def train_parity(loss_gpu, logits_gpu, ref):
+    loss_ref, logits_ref = ref
+    rel_loss = abs(loss_gpu - loss_ref) / max(abs(loss_ref), 1e-12)
+    lg, lr_ = logits_gpu.double().cpu(), logits_ref.double()
+    rel_logits = float((lg - lr_).norm() / lr_.norm())
+    return {"loss_gpu": round(loss_gpu, 5), "loss_cpu": round(loss_ref, 5), "loss_rel_err": float(f"{rel_loss:.3e}"),
+            "logits_rel_l2": float(f"{rel_logits:.3e}"), "n": int(logits_ref.shape[0]),
+            "tol": {"loss_rel_err": TRAIN_LOSS_TOL, "logits_rel_l2": TRAIN_LOGIT_TOL},
+            "ok": bool(rel_loss <= TRAIN_LOSS_TOL and rel_logits <= TRAIN_LOGIT_TOL)}
 
 
 def device_id_string(dev):
@@ -205,6 +241,7 @@ def replicas_equal(net, dist):
 
 def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     """Times K steps of one mode; returns the result dict on rank 0."""
+    parity_gpu = None
     if mode == "train":
         from sykepic_hip.dp import GradSync
         from sykepic_hip.optim import HipOptimizer
@@ -216,14 +253,22 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
             {"params": [], "lr": 0.0}])
         sync = GradSync(net, dist) if world > 1 else None
         ar_marks = []   # (before, after) events around the gradient exchange of every step
+        if world == 1 and not args.no_cpu_baseline and rank == 0:
+            # parity of the training forward in the timed precision (bf16), BEFORE any optimizer step: loss and logits of
+            # the first PARITY_N images against the oracle's first step on them (compared below, next to cpu_baseline)
+            net.reset_stats()
+            lg = net.forward_backward(x[:PARITY_N], y[:PARITY_N], want_logits=True)
+            parity_gpu = (net.read_stats()[0] / PARITY_N, lg.float().cpu())
+            net.reset_stats()
 
         def step():
             net.forward_backward(x, y)
             if sync:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                cur = torch.cuda.current_stream(dev)   # the stream the library enqueues on (HipNet._stream) and the one
+                e0.record(cur)                         # the collective's wait is put on
                 sync.all_reduce(opt)
-                e1.record()
+                e1.record(cur)
                 ar_marks.append((e0, e1))
             opt.step()
         dtype = "bf16"
@@ -253,6 +298,8 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
         marks[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    if mode == "infer" and world == 1 and not args.no_cpu_baseline:
+        parity_gpu = step()[:PARITY_N].float().cpu()     # one more forward of the timed configuration (two streams)
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 3)  # noqa: E731
     step_ms = {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "min": round(per_step[0], 3)}
@@ -380,10 +427,31 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     }
     if dist_rec is not None:
         out["dist"] = dist_rec
+    if mode == "infer" and args.precision == "calibrated" and world == 1:
+        # what a model directory runs until it has activation means (`prob` measures them on its first batch): the default
+        # hi + lo split mode, timed like the headline
+        out["uncalibrated_ms_per_step"] = uncalibrated_ms(net, x, args)
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.network, args.classes, args.size, mode,
-                                           args.cpu_seconds if mode == "infer" else args.cpu_seconds / 2)
+        out["cpu_baseline"], ref = cpu_baseline(args.network, args.classes, args.size, mode,
+                                                args.cpu_seconds if mode == "infer" else args.cpu_seconds / 2,
+                                                x[:PARITY_N].float().cpu(), y[:PARITY_N].cpu())
+        out["parity"] = infer_parity(parity_gpu, ref) if mode == "infer" else train_parity(*parity_gpu, ref)
     return out
+
+
+def uncalibrated_ms(net, x, args):
+    net.set_precision(split_weights=3)
+    try:
+        for _ in range(max(args.warmup, 3)):      # (the first forward of a precision mode tunes its kernels on one stream)
+            net.probabilities(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            net.probabilities(x)
+        torch.cuda.synchronize()
+        return round((time.perf_counter() - t0) / args.steps * 1e3, 3)
+    finally:
+        net.set_precision("calibrated")
 
 
 def main():
@@ -438,7 +506,8 @@ def main():
     elif args.precision == "calibrated":
         # model preparation, outside the timed region: what `sykepic train` stores as act_means.pth next to best_state.pth
         net.eval()
-        net.calibrate(torch.from_numpy(synth.synth_images(32, 3, args.size, args.size, seed=9000 + rank)).to(dev))
+        # (the SAME images on every rank: the replicas of a multi-GPU line are one model)
+        net.calibrate(torch.from_numpy(synth.synth_images(32, 3, args.size, args.size, seed=9000)).to(dev))
         net.set_precision("calibrated")
     else:
         net.set_precision(split_weights={"mixed": 3, "precise": 1, "balanced": 2, "fast": 0}[args.precision])
@@ -460,7 +529,7 @@ def main():
     if args.network.startswith("efficientnet") and args.mode == "both":
         modes = ["infer"]   # BASELINE config 5 is an inference config; `--mode train` measures the MBConv training step
     results = []
-    failed = False
+    failed = parity_failed = False
     for m in modes:
         if rank == 0:
             print(f"[bench] {m}: {args.warmup} warm-up + {args.steps} timed steps", file=sys.stderr, flush=True)
@@ -480,14 +549,20 @@ def main():
         if len(results) > 1:
             t = results[1]
             out["train"] = {k: t[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "config", "roofline",
-                                              "dist", "error") if k in t}
+                                              "dist", "error", "parity") if k in t}
             if "cpu_baseline" in t:
                 out["train"]["cpu_baseline"] = t["cpu_baseline"]
         print(json.dumps(out), flush=True)
+        for r in results:
+            if isinstance(r, dict) and r.get("parity") and not r["parity"]["ok"]:
+                print(f"[bench] PARITY BROKEN: {r['parity']}", file=sys.stderr, flush=True)
+                parity_failed = True
     if dist is not None:
         dist.destroy_process_group()
     if failed:      # the headline line is out; the run still counts as failed
         sys.exit(3)
+    if parity_failed:   # a fast number whose results differ from the reference's is not a number
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -51,7 +51,8 @@ struct Layer {
   // output, as one kernel (conv_pw.hip, PwConvArgs::wpz): the trunk is written but not re-read by that conv
   int chain_next = -1;            // block-closing conv: index of the conv it can also compute, or -1
   int chained_by = -1;            // that conv: index of the block-closing conv
-  bool chained_now = false;       // set by the block-closing conv's launch of the current forward: chain_next is done
+  bool chained_now_h[2] = {false, false};   // set by the block-closing conv's launch of the current forward, per half-batch
+                                  // chain (index = spk_model::half): chain_next is done for THAT half
   size_t mu_off = 0;              // generic convs: offset of this layer's cin input-channel means in spk_model::act_mean
   // fp16 eval of an MBConv block: the squeeze-excitation layer computes its gates only and the project 1x1 conv that is
   // the sole reader of its output multiplies them into its activation operand (conv_igemm.hip, spk_set_gate)
@@ -140,6 +141,8 @@ struct spk_model {
   float* s8 = nullptr;
   unsigned char* fp8_shadow = nullptr;  // fp8 mode: e4m3 copy of the trunk tensor the last project conv wrote (pw_fp8.hip)
   size_t fp8_shadow_bytes = 0;
+  size_t fp8_shadow_img = 0;            // bytes per image of the shadow: the largest h * w * stride of any shadowed tensor; a chunk
+                                        // [img0, ...) starts at img0 * fp8_shadow_img in every block (disjoint slices per half-batch)
   // state one layer leaves for the next, per half-batch chain of the two-stream forward (index = spk_model::half)
   int half = 0;                      // which of the two chains the executor is enqueueing (0: the caller's stream)
   int dw_chunks_h[2] = {0, 0};       // pool-partial rows per image the depthwise layer that ran last wrote

@@ -1045,8 +1045,8 @@ static bool chain_args(spk_model* m, const Layer& L, PwConvArgs& q, int nb) {
 static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
-  if (L.chained_by >= 0 && !m->no_chain_now && m->layers[L.chained_by].chained_now) return SPK_OK;   // done by that launch
-  if (L.chain_next >= 0 && !m->no_chain_now) L.chained_now = false;
+  if (L.chained_by >= 0 && !m->no_chain_now && m->layers[L.chained_by].chained_now_h[m->half]) return SPK_OK;   // done by that launch
+  if (L.chain_next >= 0 && !m->no_chain_now) L.chained_now_h[m->half] = false;
   if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) {
     m->stale[L.d.dst] = 1;   // computed inside the block-closing conv's kernel; read_activation recomputes it on demand
     return SPK_OK;
@@ -1115,7 +1115,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     if (chain_possible(m, L)) {
       PwConvArgs qc = q;
       if (chain_args(m, L, qc, nb) && chain_choice(m, L, qc, nb) == 1 && spk_pw_chain_launch(qc, m->stream) == 0) {
-        L.chained_now = true;
+        L.chained_now_h[m->half] = true;
         return SPK_OK;
       }
       (void)hipGetLastError();
@@ -1140,7 +1140,7 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     if (chain_possible(m, L) && q.res) {
       PwConvArgs qc = q;
       if (chain_args(m, L, qc, nb) && chain_choice(m, L, qc, nb) == 1 && spk_pw_chain_launch(qc, m->stream) == 0) {
-        L.chained_now = true;
+        L.chained_now_h[m->half] = true;
         return SPK_OK;
       }
       (void)hipGetLastError();
@@ -1236,8 +1236,7 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
       // the trunk as e4m3 bytes when the previous block's project conv left them (same bytes as converting here)
       const bool shadow = m->shadow_t_h[m->half] == L.d.src && m->fp8_shadow;
       // (the shadow holds the images of this chunk at its own row stride)
-      const void* xsrc = shadow ? (const void*)(m->fp8_shadow + (size_t)m->img0 * in.h * in.w * m->shadow_stride_h[m->half])
-                                : m->TI(L.d.src);
+      const void* xsrc = shadow ? (const void*)(m->fp8_shadow + (size_t)m->img0 * m->fp8_shadow_img) : m->TI(L.d.src);
       if (spk_launch_pw_fp8(xsrc, shadow ? 1 : 0, m->w8pack + L.w8_off,
                             m->TI8(L.d.dst), 1, nullptr, m->s8 + L.s8_off + L.cout_p, sc + L.cout_p, nullptr, 0, in.h * in.w,
                             nb * o.h * o.w, kpad, L.cout_p, shadow ? m->shadow_stride_h[m->half] : in.c, o.c, L.d.relu,
@@ -1295,16 +1294,29 @@ static int run_layer_fp8(spk_model* m, Layer& L, int nb) {
       for (const Layer& E : m->layers)
         if (E.fp8_role == 1 && E.d.src == L.d.dst && !(sh_env && atoi(sh_env) == 0)) {
           y8_stride = (o.c + 15) / 16 * 16;
-          const size_t need = (size_t)m->cap_n * o.h * o.w * y8_stride;
-          if (need > m->fp8_shadow_bytes) {
+          // The copy of a chunk of images [img0, img0 + nb) starts at img0 * fp8_shadow_img in EVERY block, with
+          // fp8_shadow_img = the largest per-image size of any shadowed tensor of the graph (inside the chunk the rows are
+          // packed at the layer's own stride).  The two half-batch chains of the two-stream forward - ordered only by the
+          // fork and join events, one may run a block ahead of the other - therefore never touch each other's slices.
+          // (With a per-block base, half A's project conv of block k+1 wrote over the region where half B's block-k copy
+          // still waited for its expand conv whenever h * w * stride changed between the blocks.)
+          size_t img_bytes = 0;
+          for (const Layer& E2 : m->layers)
+            if (E2.fp8_role == 1) {
+              const TDim& t2 = m->tdims[E2.d.src];
+              img_bytes = std::max(img_bytes, (size_t)t2.h * t2.w * ((t2.c + 15) / 16 * 16));
+            }
+          const size_t need = (size_t)m->cap_n * img_bytes;
+          if (need > m->fp8_shadow_bytes || img_bytes != m->fp8_shadow_img) {
             HIP_TRY(hipStreamSynchronize(m->stream));
             if (m->fp8_shadow) HIP_TRY(hipFree(m->fp8_shadow));
             m->fp8_shadow = nullptr;
             m->fp8_shadow_bytes = 0;
             HIP_TRY(hipMalloc((void**)&m->fp8_shadow, need));
             m->fp8_shadow_bytes = need;
+            m->fp8_shadow_img = img_bytes;
           }
-          y8 = m->fp8_shadow + (size_t)m->img0 * o.h * o.w * y8_stride;
+          y8 = m->fp8_shadow + (size_t)m->img0 * m->fp8_shadow_img;
           y8_inv = 1.f / fp8_scale_of(E.amax_in);
           break;
         }
@@ -1808,8 +1820,8 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
         by = in_b + (double)nb * o.h * o.w * din.c * 2 + out_b + (double)L.d.cout * (L.d.cin + D.d.cin) * 2;
         snprintf(nm, sizeof nm, "%s+%s", L.d.name, D.d.name);
       }
-      if (L.chained_by >= 0 && m->layers[L.chained_by].chained_now) by = fl = 0;   // computed by the block-closing conv's launch
-      if (L.chain_next >= 0 && L.chained_now) {   // ... which also read that conv's weights and wrote its output
+      if (L.chained_by >= 0 && m->layers[L.chained_by].chained_now_h[0]) by = fl = 0;   // computed by the block-closing conv's launch
+      if (L.chain_next >= 0 && L.chained_now_h[0]) {   // ... which also read that conv's weights and wrote its output
         const Layer& Q = m->layers[L.chain_next];
         const TDim& zo = m->tdims[Q.d.dst];
         fl += 2.0 * nb * zo.h * zo.w * (double)Q.d.cout * Q.d.cin;

@@ -40,6 +40,11 @@ def roi_number(path):
     return int(name[name.rfind("_") + 1:])
 
 
+def _in_process_group():
+    import torch.distributed as td
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
 def net_pass(net, dataloader, device="cuda:0"):
     """[(roi, [p_class...]), ...] sorted by ROI number.
 
@@ -51,6 +56,8 @@ def net_pass(net, dataloader, device="cuda:0"):
     pending = []
     for batch in dataloader:
         x, paths = batch[0], batch[1]
+        if getattr(net, "_auto_calibration_dir", None) is not None and not _in_process_group():
+            auto_calibrate(net, x)
         probs = net.probabilities(x, SOFTMAX_EXP)  # async on the stream
         pending.append((tuple(roi_number(p) for p in paths), probs))
     for rois, probs in pending:  # one device->host copy per batch, after all launches
@@ -113,6 +120,8 @@ def net_pass_launch(net, batches, device="cuda:0"):
     net.eval()
     nums, outs = [], []
     for x, numbers in batches:
+        if getattr(net, "_auto_calibration_dir", None) is not None and not _in_process_group():
+            auto_calibrate(net, x)
         outs.append(net.probabilities(x, SOFTMAX_EXP))      # async on the stream
         nums.append(np.asarray(numbers, dtype=np.int64))
     return PendingRows(nums, outs)
@@ -180,26 +189,43 @@ def prepare_model(model_dir, device=None):
     device = torch.device(device or "cuda:0")
     net = get_network(config, len(classes), device=device, pretrained_ok=False)
     net.load_state_dict(torch.load(model_dir / "best_state.pth", map_location="cpu"))
-    use_act_means(net, model_dir)
+    if not use_act_means(net, model_dir):
+        arm_auto_calibration(net, model_dir)
     return net, classes, img_shape, eval_transform, device
 
 
-ACT_MEANS_FILE = "act_means.pth"   # next to best_state.pth: written by `sykepic train` / `sykepic calibrate`
+ACT_MEANS_FILE = "act_means.pth"   # next to best_state.pth: written by `sykepic train` / `sykepic calibrate` / the first `prob` run
+AUTO_CALIBRATION_IMAGES = 256
+AUTO_CALIBRATION_MIN = 32          # fewer images than this say too little about the channel means: wait for a larger batch
+
+
+def state_digest(model_dir):
+    """sha256 of `best_state.pth` as it lies on disk: ties an `act_means.pth` to the weights it was measured with."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(Path(model_dir) / "best_state.pth", "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 22), b""):
+            h.update(chunk)
+    return h.hexdigest()
 
 
 def use_act_means(net, model_dir):
-    """A model directory that carries activation means runs the calibrated single-pass mode (csrc/zero_sum.hip:
-    every conv one fp16 product, as accurate as hi + lo weights); one without them - every directory the reference
-    itself trained - runs the default split mode.  SYKEPIC_CALIBRATED=0 ignores the file."""
+    """A model directory that carries activation means OF ITS OWN WEIGHTS runs the calibrated single-pass mode
+    (csrc/zero_sum.hip: every conv one fp16 product, as accurate as hi + lo weights).  The sidecar stores the sha256 of
+    the `best_state.pth` it was measured with; a file whose digest differs (re-trained or copied weights), one without a
+    digest (written before round 5) or one of the wrong size is ignored - rounding against another model's means would
+    silently cost the accuracy the mode exists for.  SYKEPIC_CALIBRATED=0 ignores the file."""
     path = Path(model_dir) / ACT_MEANS_FILE
     if os.environ.get("SYKEPIC_CALIBRATED", "1") == "0" or not path.is_file():
         return False
     try:
         means = torch.load(path, map_location="cpu")
-        net.set_act_means(means["means"] if isinstance(means, dict) else means)
+        if not isinstance(means, dict) or means.get("state_sha256") != state_digest(model_dir):
+            raise ValueError("it was not measured with this best_state.pth")
+        net.set_act_means(means["means"])
         net.set_precision("calibrated")
     except Exception as e:  # noqa: BLE001 - a stale or foreign file must not stop classification
-        log.warning(f"{path.name} does not fit this model ({e}); using the default precision mode")
+        log.warning(f"{path.name} ignored ({e})")
         net.set_act_means(None)
         net.set_precision(split_weights=3)
         return False
@@ -208,7 +234,73 @@ def use_act_means(net, model_dir):
 
 
 def save_act_means(net, model_dir, n_images):
-    torch.save({"means": net.act_means(), "images": int(n_images), "network": net.graph.network}, Path(model_dir) / ACT_MEANS_FILE)
+    torch.save({"means": net.act_means(), "images": int(n_images), "network": net.graph.network,
+                "state_sha256": state_digest(model_dir)}, Path(model_dir) / ACT_MEANS_FILE)
+
+
+def drop_act_means(model_dir):
+    """Removes a sidecar that can no longer belong to the weights (new training run into the directory)."""
+    try:
+        (Path(model_dir) / ACT_MEANS_FILE).unlink()
+    except FileNotFoundError:
+        pass
+
+
+def arm_auto_calibration(net, model_dir):
+    """A model directory as the REFERENCE leaves it (`best_state.pth` only, probability.py:118-130) has no activation
+    means.  ResNets then measure them on the first <= 256 ROIs they are about to classify (`auto_calibrate`, called by
+    `net_pass` / `net_pass_launch` in front of the first forward), switch to the calibrated single-pass mode for
+    everything from that batch on, and leave the sidecar in the directory when it is writable, so that every later run
+    starts calibrated and classifies with the same rounded weights.  EfficientNets gain nothing from the mode (their
+    error is activation storage: DESIGN.md section 3) and keep the default.  SYKEPIC_AUTO_CALIBRATE=0 switches it off."""
+    if os.environ.get("SYKEPIC_AUTO_CALIBRATE", "1") == "0" or os.environ.get("SYKEPIC_CALIBRATED", "1") == "0":
+        return
+    if not net.graph.network.startswith("resnet"):
+        return
+    net._auto_calibration_dir = Path(model_dir)
+
+
+def auto_calibrate(net, x, dist=None):
+    """First batch of a `prob` run on an un-calibrated model directory: means from its first <= 256 images (the
+    calibration forward: every conv hi + lo, one stream), then the calibrated mode.  `x` None: this rank has no image.
+    Single process: called by `net_pass` / `net_pass_launch` in front of the first forward.  Under torch.distributed
+    (`dist` given, world > 1) it is a collective that `launch_sample` / `process_images` call on EVERY rank before their
+    forward passes, whatever the size of the rank's shard: rank 0 measures on ITS first images and every rank takes
+    rank 0's means - the replicas stay one model; if rank 0 has no image the step is retried with the next sample."""
+    model_dir = getattr(net, "_auto_calibration_dir", None)
+    if model_dir is None:
+        return False
+    from . import dp
+    rank, world = dp.rank_world(dist)
+    if world == 1 and (x is None or len(x) < AUTO_CALIBRATION_MIN):
+        return False
+    n = min(len(x), AUTO_CALIBRATION_IMAGES) if x is not None else 0
+    means = None
+    if rank == 0 and n >= AUTO_CALIBRATION_MIN:
+        try:
+            net.calibrate(x[:n])
+            means = net.act_means()
+        except Exception as e:  # noqa: BLE001 - an optimisation; the other ranks wait in the broadcast below
+            if world == 1:
+                raise
+            log.warning(f"activation means not measured ({e}); default precision mode")
+    if world > 1:
+        means, n = dp.broadcast_object((means, n), dist)
+        if means is not None and rank != 0:
+            net.set_act_means(means)
+    if means is None:
+        return False
+    net._auto_calibration_dir = None
+    net.set_precision("calibrated")
+    log.info(f"no {ACT_MEANS_FILE} in {model_dir}: activation means measured on the first {n} images, calibrated "
+             f"single-pass mode from here on")
+    if rank == 0:
+        try:
+            save_act_means(net, model_dir, n)
+            log.info(f"{ACT_MEANS_FILE} written: later runs start calibrated")
+        except OSError as e:
+            log.info(f"{ACT_MEANS_FILE} not written ({e}): the next run measures again")
+    return True
 
 
 def calibrate_model(net, batches, max_images=2048):
@@ -340,11 +432,15 @@ def launch_sample(sample_path, net, params, out_dir, force=False, dist=None, ahe
                 for b in range(lo, hi, step):
                     e = min(hi, b + step)
                     yield gs.batch(b, e, th, tw, code), gs.numbers[b:e]
+            if world > 1 and getattr(net, "_auto_calibration_dir", None) is not None:
+                auto_calibrate(net, gs.batch(lo, min(hi, lo + AUTO_CALIBRATION_IMAGES), th, tw, code) if hi > lo else None, dist)
             rows = net_pass_launch(net, gpu_batches(), params.device)
         else:
             rois = ifcb.read_rois(sample_path.with_suffix(".adc"), sample_path.with_suffix(".roi"))
             lo, hi = dp.shard_range(len(rois), rank, world)
             items = [(f"{sample}_{num:05d}.png", _as_chans(img, params.img_shape[0])) for num, img in rois[lo:hi]]
+            if world > 1 and getattr(net, "_auto_calibration_dir", None) is not None:
+                auto_calibrate(net, next(_batches(items, params.transform, AUTO_CALIBRATION_IMAGES))[0] if items else None, dist)
             rows = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
     except Exception as e:  # noqa: BLE001 - re-raised by complete_sample on every rank
         error = e
@@ -393,6 +489,8 @@ def process_images(img_paths, net, params, csv_path, force=False, dist=None):
     rows, error = [], None
     try:
         items = [(str(p), pngio.read_image(p, params.img_shape[0])) for p in img_paths[lo:hi]]
+        if world > 1 and getattr(net, "_auto_calibration_dir", None) is not None:
+            auto_calibrate(net, next(_batches(items, params.transform, AUTO_CALIBRATION_IMAGES))[0] if items else None, dist)
         rows = net_pass(net, _batches(items, params.transform, params.batch_size), params.device)
     except Exception as e:  # noqa: BLE001 - re-raised below on every rank
         error = e
@@ -494,6 +592,9 @@ def calibrate_call(args):
         else:
             os.environ["SYKEPIC_CALIBRATED"] = keep
 
+    from . import gpu_preprocess
+    on_gpu = not (args.image_dir or args.images) and gpu_preprocess.supported(transform, img_shape[0])
+
     def images():
         if args.image_dir or args.images:
             for p in (sorted(Path(args.image_dir).rglob("*.png")) if args.image_dir else [Path(q) for q in args.images]):
@@ -504,6 +605,17 @@ def calibrate_call(args):
                     yield _as_chans(img, img_shape[0])
 
     def batches():
+        if on_gpu:
+            # raw samples through the GPU preprocessing `prob` itself uses (.roi blob -> resized uint8 batches): the host
+            # transform - a Python restatement of cv2.resize, ~10 ms per ROI - was 21 of the 21.9 s that round 4's
+            # `sykepic calibrate` took for 2048 ROIs
+            th, tw = transform.target_dims
+            code = gpu_preprocess.border_code(transform)
+            for sp in (files.list_sample_paths(args.raw) if args.raw else [Path(q) for q in args.samples]):
+                gs = gpu_preprocess.SampleOnGpu(sp.with_suffix(".adc"), sp.with_suffix(".roi"), device)
+                for b in range(0, len(gs), args.batch_size):
+                    yield gs.batch(b, min(len(gs), b + args.batch_size), th, tw, code)
+            return
         chunk = []
         for img in images():
             chunk.append(transform(img))

@@ -109,6 +109,8 @@ def main(args):
     model_dir = mo.path / (mo.network + (f"_{model_id}" if model_id else ""))
     if chief:
         model_dir.mkdir(parents=True, exist_ok=mo.exist_ok)
+        from . import prob as _prob
+        _prob.drop_act_means(model_dir)   # exist_ok = yes: means of an earlier run do not belong to the weights about to be written
         model_data.save(model_dir)
         shutil.copy(args.config, model_dir / "config.ini")
     if dist is not None:
@@ -153,6 +155,7 @@ def main(args):
                 prob.save_act_means(net, model_dir, n_cal)
                 print(f"[INFO] Activation means of {n_cal} validation images saved to {prob.ACT_MEANS_FILE}")
         except Exception as e:  # noqa: BLE001 - an optimisation of later inference, never a reason to lose the run
+            prob.drop_act_means(model_dir)     # whatever is there now belongs to other weights
             print(f"[INFO] No activation means stored ({e})")
     tests = ([(None, model_data.test_loader)] if test_split else []) + \
             ([(Path(external_test).name, extra_loader)] if external_test else [])

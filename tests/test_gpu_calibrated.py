@@ -248,3 +248,43 @@ def test_chained_convs_do_not_change_a_bit():
         assert out.returncode == 0, out.stderr[-2000:]
         outs.append([ln for ln in out.stdout.splitlines() if ln.startswith("SHA")])
     assert len(outs[0]) == 4 and outs[0] == outs[1], (outs[0], outs[1])
+
+
+def test_chained_convs_decide_per_half_batch(tmp_path):
+    """the two-stream forward runs every layer for half 0 and then for half 1, and the chained-conv decision
+    (tuner cache keyed with the half's image count) may differ between the halves of an odd batch: n = 129 splits into 64
+    and 65 images.  With a tuner cache that says "two kernels" for 64 images and "chained" for 65, half 1's decision must
+    not make half 0 skip the conv its own launch did not compute (the flag is per half since round 5): the logits equal
+    the never-chained ones bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    cache = tmp_path / "tune.txt"
+    lines = []
+    for cin2, coutz in ((64, 64), (0, 64), (0, 128)):       # the three stage-1 pairs of ResNet-50 at 96 x 96 input (24 x 24)
+        lines += [f"chain 24 24 64 {cin2} {coutz} 64 0", f"chain 24 24 64 {cin2} {coutz} 65 1"]
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path[:0] = [{str(root)!r}, {str(root / 'syke-pic_amd')!r}]\n"
+        "from sykepic_hip import arch, synth\n"
+        "from sykepic_hip.net import HipNet\n"
+        "g = arch.build_graph('resnet50', 50)\n"
+        "sd = synth.synth_state_dict(arch.param_specs(g), seed=2)\n"
+        "net = HipNet('resnet50', 50, weights=None)\n"
+        "net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); net.eval()\n"
+        "net.calibrate(torch.from_numpy(synth.synth_images(16, 3, 96, 96, seed=9000)).cuda())\n"
+        "net.set_precision('calibrated')\n"
+        "x = torch.from_numpy(synth.synth_images(129, 3, 96, 96, seed=6)).cuda()\n"
+        "for it in range(3):\n"
+        "    z = net.forward(x).cpu().numpy()\n"
+        "    print('SHA', it, hashlib.sha256(z.tobytes()).hexdigest())\n")
+    outs = []
+    for chain in ("1", "0"):
+        cache.write_text("\n".join(lines) + "\n")
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPK_CHAIN=chain, SPK_TUNE_CACHE=str(cache)),
+                             capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs.append([ln.split()[2] for ln in out.stdout.splitlines() if ln.startswith("SHA")])
+    assert len(outs[0]) == 3 and len(set(outs[0] + outs[1])) == 1, (outs[0], outs[1])

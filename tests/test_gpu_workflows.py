@@ -72,6 +72,80 @@ def test_prob_call_on_reference_fixture(tmp_path, golden_dir):
     assert out_csvs[0].stat().st_mtime_ns == stamp
 
 
+def _synthetic_sample(raw_dir, name, n_roi, seed):
+    """An IFCB sample (.adc + .roi) of n_roi random-sized ROIs with a blob on a light background, as utils/ifcb.py reads
+    them (columns 16-18 of the .adc: width, height, byte offset)."""
+    rng = np.random.RandomState(seed)
+    adc, blobs, off = [], [], 0
+    for _ in range(n_roi):
+        h, w = int(rng.randint(24, 90)), int(rng.randint(30, 160))
+        img = np.clip(rng.normal(200, 6, (h, w)), 0, 255)
+        cy, cx, r = rng.randint(4, h - 4), rng.randint(4, w - 4), rng.randint(3, 12)
+        yy, xx = np.ogrid[:h, :w]
+        img[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = rng.randint(30, 120)
+        cols = ["0"] * 24
+        cols[15], cols[16], cols[17] = str(w), str(h), str(off)
+        adc.append(",".join(cols))
+        blobs.append(img.astype(np.uint8).reshape(-1))
+        off += h * w
+    raw_dir.mkdir(parents=True, exist_ok=True)
+    (raw_dir / f"{name}.adc").write_text("\n".join(adc) + "\n")
+    np.concatenate(blobs).tofile(raw_dir / f"{name}.roi")
+
+
+def test_prob_calibrates_a_reference_trained_directory_on_its_first_sample(tmp_path, golden_dir, caplog):
+    """a model directory as the REFERENCE leaves it (best_state.pth, config.ini, class_names.txt:
+    probability.py:118-130) has no act_means.pth.  `prob` measures the means on the first <= 256 ROIs it classifies,
+    switches to the calibrated single-pass mode (the benchmarked mode) and writes the sidecar; both the first sample - the
+    one calibrated on - and a later one are within 1e-3 of the oracle; a second process starts calibrated from the
+    sidecar and reproduces the CSVs byte for byte; a sidecar of OTHER weights is ignored."""
+    import logging
+    from oracle import refnet
+    from sykepic_hip import ifcb, prob
+    from sykepic_hip.config import get_img_shape, get_transforms
+    raw = tmp_path / "raw"
+    names = ["D20200101T000000_IFCB114", "D20200101T000100_IFCB114"]
+    _synthetic_sample(raw, names[0], 300, seed=1)
+    _synthetic_sample(raw, names[1], 90, seed=2)
+    model, sd = _model_dir(tmp_path, golden_dir)
+    assert not (model / prob.ACT_MEANS_FILE).exists()
+    out = tmp_path / "out"
+    with caplog.at_level(logging.INFO, logger="prob"):
+        prob.call(Args(str(raw), None, None, None, str(model), out, 64, 2, False))
+    assert any("calibrated single-pass mode from here on" in r.message for r in caplog.records)
+    side = torch.load(model / prob.ACT_MEANS_FILE)
+    assert side["images"] == 256 and side["state_sha256"] == prob.state_digest(model)
+    cfg = ConfigParser()
+    cfg.read(model / "config.ini")
+    _, ev = get_transforms(cfg, get_img_shape(cfg))
+    ref_net = refnet.load_numpy_state(refnet.RefNet("resnet18", 50), sd)
+    texts = {}
+    for name in names:
+        csv = out / "2020" / "01" / "01" / f"{name}.prob.csv"
+        texts[name] = csv.read_bytes()
+        rois = ifcb.read_rois(raw / f"{name}.adc", raw / f"{name}.roi")
+        x = torch.stack([ev(np.repeat(img[:, :, None], 3, axis=2)) for _, img in rois])
+        ref = refnet.probabilities(ref_net, x).numpy()
+        got = np.array([[float(v) for v in ln.split(",")[1:]] for ln in csv.read_text().splitlines()[1:]])
+        err = float(np.abs(got - ref).max())
+        print(f"{name}: {len(rois)} ROIs, calibrated on the first sample, max |dp| = {err:.2e}")
+        assert err <= 1e-3 + 5e-6
+        assert (got.argmax(1) == ref.argmax(1))[np.sort(ref, 1)[:, -1] - np.sort(ref, 1)[:, -2] > 2e-3].all()
+    # second run: starts calibrated from the sidecar, same bytes
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="prob"):
+        prob.call(Args(str(raw), None, None, None, str(model), out, 64, 2, True))
+    assert any("activation means from" in r.message for r in caplog.records)
+    for name in names:
+        assert (out / "2020" / "01" / "01" / f"{name}.prob.csv").read_bytes() == texts[name]
+    # other weights in the directory: the sidecar no longer belongs to them
+    g = arch.build_graph("resnet18", 50)
+    sd2 = synth.synth_state_dict(arch.param_specs(g), seed=3)
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd2.items()}, model / "best_state.pth")
+    net, *_ = prob.prepare_model(model)
+    assert getattr(net, "_auto_calibration_dir", None) is not None     # ignored: armed to measure again
+
+
 def test_prob_from_png_images(tmp_path, golden_dir):
     from sykepic_hip import ifcb, prob
     model, _ = _model_dir(tmp_path, golden_dir)
