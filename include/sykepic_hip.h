@@ -326,6 +326,15 @@ int spk_op_conv3x3(const void* x_dev, const float* w_dev, const float* bn_scale_
                    const void* res_dev, void* y_dev, int n, int h, int w, int cin, int cout, int relu, int split, int cfg,
                    void* hip_stream);
 int spk_op_conv3x3_num_configs(void);
+/* A whole identity bottleneck block of the eval path (torchvision Bottleneck.forward without downsample, reached through
+ * `net(x)`: /root/reference/sykepic/compute/probability.py:189): y = ReLU(BN3(W3 . ReLU(BN2(W2 * ReLU(BN1(W1 . x))))) + x).
+ * x, y: [n,h,w,4 cm] fp16 device tensors (y != x); fp32 device weights w1 [cm][4 cm], w2 [cm][3][3][cm], w3 [4 cm][cm];
+ * folded eval-BatchNorm scale / shift vectors.  fused != 0: one kernel (csrc/conv_bneck.hip), SPK_ERR_UNSUPPORTED when
+ * the shape has no instantiation; fused == 0: the three launches of the eval path.  iters > 0: *ms_out = mean time of one
+ * block over `iters` repetitions. */
+int spk_op_bottleneck(const void* x_dev, const float* w1_dev, const float* w2_dev, const float* w3_dev, const float* s1_dev,
+                      const float* b1_dev, const float* s2_dev, const float* b2_dev, const float* s3_dev, const float* b3_dev,
+                      void* y_dev, int n, int h, int w, int cm, int fused, int iters, float* ms_out, void* stream);
 /* Two chained 1x1 convs in ONE launch (round 4, csrc/conv_pw.hip): y = act(BN(W . x) + res) with cout = 256, then
  * z = actz(BNz(Wz . y)) computed from the output tile while it is still in registers - what the eval path runs for a
  * bottleneck's block-closing conv and the next block's first conv in the single-weight-image modes (the trunk y is

@@ -1,0 +1,401 @@
+// A whole identity bottleneck block of a ResNet-50/101/152 as ONE kernel for gfx950 (MI355X), eval path, fp16 storage,
+// single weight images (the calibrated / plain-fp16 modes):
+//     out = ReLU(BN3(conv3_1x1(ReLU(BN2(conv2_3x3(ReLU(BN1(conv1_1x1(x)))))))) + x)
+// - the three Conv2d + BatchNorm2d.eval() (+ ReLU) links of torchvision's `Bottleneck.forward` that the reference reaches
+// through `net(x)` (sykepic/compute/probability.py:189; SURVEY.md section 2.2, section 8d: "only reachable if activations
+// cross HBM ~ once each way").  As three launches the block moves x, y1 (write + up to 9 L2 re-reads), y2 (write + read),
+// x again (shortcut) and out through HBM / L2 and pays three grid tails; here the two mid tensors never leave the CU.
+//
+// One block = one band of R output rows of one image (R = H: a whole 14 x 14 image), 8 waves, two per SIMD (<= 256
+// registers each: past that hipcc splits the accumulators between VGPRs and AGPRs and shuffles them around every MFMA).
+//   phase 1  y1 = ReLU(BN1(W1 . x)) on the band's rows plus one halo row above and below.  x streams through an LDS ring in
+//            64-channel chunks by LDS-DMA (128-byte rows, 16-byte chunks XOR-swizzled at the SOURCE: conv_igemm.hip), the
+//            weights come straight from L2 in MFMA fragment order (pack_pw_kernel's image).  y1 lands in LDS as a WINDOW:
+//            plane q holds the 16-byte channel part q (8 channels) of every window position, positions at pitch W + 1 - the
+//            one extra column per row is zero and serves as the right padding of its row AND the left padding of the next -
+//            so that every 3x3 tap is a constant position offset and a fragment read at any tap is conflict-free
+//            (conv_c3.hip's layout).  Rows outside the image are zero.
+//   phase 2  y2 = ReLU(BN2(W2 * y1)): 9 taps x CM channels out of the window, weights from L2 in conv_c3.hip's fragment
+//            order (K order chunk -> tap -> half, the same sums as that kernel).  y2 overwrites the window.
+//   phase 3  out = ReLU(BN3(W3 . y2) + x), 4 passes of CM couts each; the shortcut rows of x are requested before a pass's K
+//            loop and land under it.
+// In every phase a wave owns 64 couts (two 32-cout pairs, permuted at pack time so that a lane's accumulators of a pair
+// are 8 CONSECUTIVE couts of one position: epilogues run from registers, conv_pw.hip) and one of WM = 512 / CM shares of the position
+// tiles; the ACTIVATION operand is read from LDS by all waves, each weight byte is loaded by exactly one wave of a cout
+// group.  K orders and epilogue arithmetic are those of conv_pw.hip / conv_c3.hip, so the block's output is bit-identical to
+// the three-launch path (tests/test_gpu_bneck.py).
+#include "spk_common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+typedef __attribute__((address_space(3))) const unsigned char* lds_u8_t;
+typedef __attribute__((address_space(3))) const u32x4_t* lds_u32x4_t;
+typedef __attribute__((address_space(3))) const f32x4_t* lds_f32x4_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+
+template <int CM_, int HW_, int R_>
+struct BnCfg {
+  static constexpr int CM = CM_, HW = HW_, R = R_;
+  static constexpr int C4 = 4 * CM;
+  static constexpr int WN = CM / 64, WM = 8 / WN;       // the 8 waves: along the couts x along the positions
+  static constexpr int WP = HW + 1;                     // window pitch
+  static constexpr int NROW = R + 2;                    // window rows: one halo row above, one below
+  static constexpr int P2 = R * WP;                     // output positions of a band at pitch WP (column HW is no output)
+  static constexpr int NT2 = (P2 + 15) / 16;
+  static constexpr int MTW = (NT2 + WM - 1) / WM;       // position tiles per wave, phases 2 and 3
+  static constexpr int RV = cmin(R + 2, HW);            // image rows a window can hold
+  static constexpr int P1 = RV * HW;                    // ... as compact positions (phase 1 computes real positions only)
+  static constexpr int NT1 = (P1 + 15) / 16;
+  static constexpr int MT1 = (NT1 + WM - 1) / WM;       // position tiles per wave, phase 1
+  // window positions: every tap of every (also the padding) output position of the tile grid stays inside
+  static constexpr int NVA = cmax(NROW * WP + 1, WM * MTW * 16 + 2 * WP + 2);
+  static constexpr int PLANE = (NVA * 16 + 255) & ~255;
+  static constexpr int WIN = (CM / 8) * PLANE;
+  static constexpr int DI = (WM * MT1 * 2 + 7) / 8;     // LDS-DMA instructions (8 rows x 128 B) per wave and x chunk
+  static constexpr int XSTAGE = DI * 8 * 1024;
+  static constexpr int NXS = 3 * XSTAGE <= cmax(WIN, 96 * 1024) ? 3 : 2;
+  static constexpr int TAB = 12 * CM * 4;               // BN tables: [s1 b1 | s2 b2 | s3 b3] = (2 + 2 + 8) CM floats
+  static constexpr int REGION = cmax(WIN, NXS * XSTAGE);
+  static constexpr int LDS = REGION + TAB;
+  static constexpr int NCH = C4 / 64;                   // x chunks
+  static constexpr int DEPTH = 4;                       // activation fragments in flight (ring of registers)
+  static_assert(CM == 64 || CM == 128 || CM == 256, "mid channels");
+  static_assert(HW % R == 0, "bands tile the image");
+  static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+// two clamped floats -> one dword of two fp16 values
+__device__ __forceinline__ unsigned int pack2h(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
+}
+
+template <int CM, int HW, int R>
+__global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
+  using K = BnCfg<CM, HW, R>;
+  constexpr int C4 = K::C4, WN = K::WN, WP = K::WP, MTW = K::MTW, MT1 = K::MT1, PLANE = K::PLANE, DI = K::DI;
+  constexpr int NXS = K::NXS, XSTAGE = K::XSTAGE, NCH = K::NCH, DEPTH = K::DEPTH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, p = lane & 15;
+  const int wn = wave % WN, wm = wave / WN;
+
+  // ---- block -> (image, band): blocks b and b + 8 share an XCD (round-robin dispatch), so an XCD takes a contiguous run
+  // of (image, band) items and the halo rows two neighbouring bands both read are an L2 hit for the second ----
+  constexpr int BPI = HW / R;
+  const int nblk = a.N * BPI;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+  const int img = lin / BPI, band = lin - img * BPI;
+  const int r0 = band * R;
+  const int rlo = r0 > 0 ? r0 - 1 : 0, rhi = r0 + R + 1 < HW ? r0 + R + 1 : HW;   // image rows [rlo, rhi) of the window
+  const int P1 = (rhi - rlo) * HW;                                                  // its real positions
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, CM * C4 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 9 * CM * CM * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, CM * C4 * 2, 0x00020000);
+
+  unsigned char* const win = smem;                       // x ring (phase 1), then the y1 window, then y2
+  float* const tab = (float*)(smem + K::REGION);         // [s1 | b1 | s2 | b2 | s3 | b3]
+  for (int c = tid; c < CM; c += 512) {
+    tab[c] = a.s1[c]; tab[CM + c] = a.b1[c];
+    tab[2 * CM + c] = a.s2[c]; tab[3 * CM + c] = a.b2[c];
+  }
+  for (int c = tid; c < C4; c += 512) { tab[4 * CM + c] = a.s3[c]; tab[4 * CM + C4 + c] = a.b3[c]; }
+
+  // weight fragments of this wave's 64 couts: [K step][pair][tile][lane][8] images, pairs 2 wn and 2 wn + 1
+  const unsigned w_lane = (unsigned)(2 * wn) * 2048 + lane * 16;
+
+  // =====================================================================================================================
+  // phase 1: y1 = ReLU(BN1(W1 . x)) on the window's real positions (compact index: row-major over image rows [rlo, rhi))
+  // =====================================================================================================================
+  {
+    // LDS-DMA of one 64-channel chunk: instruction ii = wave + 8 i covers rows 8 ii .. 8 ii + 7; lane l lands in row
+    // l / 8, slot l % 8 and therefore fetches the chunk whose swizzled slot that is
+    unsigned voff[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) {
+      const int row = 8 * (wave + 8 * i) + (lane >> 3);
+      const int pr = row / HW, pc = row - pr * HW;
+      const unsigned pix = (unsigned)((img * HW + rlo + pr) * HW + pc);
+      voff[i] = row < P1 ? pix * (unsigned)(C4 * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
+    }
+    auto dma = [&](int c, int stage) {
+#pragma unroll
+      for (int i = 0; i < DI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(win + stage * XSTAGE + (wave + 8 * i) * 1024), 16, (unsigned)voff[i],   // (the cast: hipcc 7.2 host pass silently drops the kernel when an lvalue array element is passed here)
+                                                 c * 128, 0, 0);
+    };
+    // activation fragment of position tile j, K step ks of a chunk: row 16 (wm MT1 + j) + p, chunk 4 ks + g, swizzled
+    // ((row >> 1) & 7 == (p >> 1) & 7: tiles start on multiples of 16)
+    // (K step 1 of a chunk = chunk 4 + g: slot (4 + g) ^ s = (g ^ s) ^ 4 - the byte offset xor 64)
+    const unsigned xlane = (unsigned)((wm * MT1 * 16 + p) * 128 + ((g ^ ((p >> 1) & 7)) << 4));
+    u32x4_t wa[2][2][4];   // [chunk parity][ks][tile of the wave's 64 couts]
+    auto load_w = [&](u32x4_t (&d)[2][4], int c) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          d[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(rw1, w_lane + t * 1024, (2 * c + ks) * (CM * 64), 0);
+    };
+    f32x4_t acc[MT1][4];
+#pragma unroll
+    for (int j = 0; j < MT1; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    load_w(wa[0], 0);
+    dma(0, 0);
+    if (NXS == 3) dma(1, 1);
+    auto chunk = [&](int c, const u32x4_t (&w)[2][4], u32x4_t (&wnext)[2][4]) {
+      // this wave's pieces of chunk c have landed once at most the next chunk's DMAs are outstanding; the barrier
+      // publishes everyone's pieces and proves everyone is done with chunk c - 1, whose stage is refilled at once
+      if (NXS == 3 && c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      load_w(wnext, c + 1 < NCH ? c + 1 : NCH - 1);
+      if (c + NXS - 1 < NCH) dma(c + NXS - 1, (c + NXS - 1) % NXS);
+      lds_u8_t xb0 = (lds_u8_t)win + (c % NXS) * XSTAGE + xlane;
+      lds_u8_t xb1 = (lds_u8_t)win + (c % NXS) * XSTAGE + (xlane ^ 64u);
+      asm volatile("" : "+v"(xb0), "+v"(xb1));
+      u32x4_t fr[DEPTH];
+      constexpr int UNITS = 2 * MT1;
+      auto addr = [&](int u) { return (u / MT1 ? xb1 : xb0) + (u % MT1) * 2048; };
+#pragma unroll
+      for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)addr(u);
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + DEPTH - 1 < UNITS) fr[(u + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)addr(u + DEPTH - 1);
+        const int j = u % MT1, ks = u / MT1;
+        // hard fences, not hints: left to itself hipcc keeps ONE fragment register set and reads each fragment right in
+        // front of its four MFMAs - a full LDS round trip exposed per unit (conv_c3.hip, conv_pw.hip)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(w[ks][t], fr[u % DEPTH], acc[j][t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int c = 0; c < NCH; c += 2) {
+      chunk(c, wa[0], wa[1]);
+      chunk(c + 1, wa[1], wa[0]);
+    }
+    __syncthreads();   // everyone is done with the x ring: the window takes its place
+
+    // zeros wherever the window has no image pixel: the shared padding column, rows outside the image, the tail
+    for (int u = tid; u < (CM / 8) * K::NVA; u += 512) {
+      const int pl = u / K::NVA, v = u - pl * K::NVA;
+      const int wr = v / WP, wc = v - wr * WP;
+      const int ir = r0 - 1 + wr;
+      if (!(wc >= 1 && ir >= 0 && ir < HW && wr < K::NROW)) *(u32x4_t*)(win + pl * PLANE + v * 16) = u32x4_t{0, 0, 0, 0};
+    }
+    // y1 from registers: lane holds couts 64 wn + 32 P + 8 g .. + 7 of position 16 (wm MT1 + j) + p = plane 8 wn + 4 P + g
+#pragma unroll
+    for (int j = 0; j < MT1; ++j) {
+      const int row = 16 * (wm * MT1 + j) + p;
+      const int pr = row / HW, pc = row - pr * HW;
+      const int v = (rlo + pr - (r0 - 1)) * WP + pc + 1;
+#pragma unroll
+      for (int P = 0; P < 2; ++P) {
+        lds_f32x4_t sp = (lds_f32x4_t)(tab + 64 * wn + 32 * P + 8 * g);
+        asm volatile("" : "+v"(sp));
+        const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[CM / 4], sh1 = sp[CM / 4 + 1];
+        u32x4_t ov;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ov[i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P][2 * i], sc0[2 * i], sh0[2 * i]), 0.f, 65504.f),
+                         __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P][2 * i + 1], sc0[2 * i + 1], sh0[2 * i + 1]), 0.f, 65504.f));
+          ov[2 + i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P + 1][2 * i], sc1[2 * i], sh1[2 * i]), 0.f, 65504.f),
+                             __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P + 1][2 * i + 1], sc1[2 * i + 1], sh1[2 * i + 1]), 0.f, 65504.f));
+        }
+        if (row < P1) *(u32x4_t*)(win + (8 * wn + 4 * P + g) * PLANE + v * 16) = ov;
+      }
+    }
+    __syncthreads();
+  }
+
+  // position tiles of this wave in phases 2 and 3: window-pitch positions 16 (wm MTW + j) + p
+  const unsigned plane_lane = (unsigned)(g * PLANE + (wm * MTW * 16 + p) * 16);
+
+  // =====================================================================================================================
+  // phase 2: y2 = ReLU(BN2(W2 * y1)), K order chunk (64 channels) -> tap -> half (conv_c3.hip's, bit for bit)
+  // =====================================================================================================================
+  {
+    constexpr int PW = 3;                      // weight K steps in flight (divides the 18 steps of a chunk)
+    constexpr int KSTEPS = (CM / 64) * 18;
+    u32x4_t wq[PW][4];
+    auto load_w = [&](u32x4_t (&d)[4], int step) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d[t] = __builtin_amdgcn_raw_buffer_load_b128(rw2, w_lane + t * 1024, step * (CM * 64), 0);
+    };
+    f32x4_t acc[MTW][4];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PW; ++s) load_w(wq[s], s);
+    for (int c = 0; c < CM / 64; ++c) {
+      lds_u8_t cb = (lds_u8_t)win + plane_lane + c * 8 * PLANE;
+      asm volatile("" : "+v"(cb));
+      constexpr int UNITS = 18 * MTW;
+      // unit u = (K step q of the chunk, position tile j): tap q / 2 shifts the positions, half q % 2 the planes
+      auto addr = [&](int u) {
+        const int q = u / MTW, j = u % MTW, tap = q >> 1, kk = q & 1;
+        return cb + kk * 4 * PLANE + (j * 16 + (tap / 3) * WP + (tap % 3)) * 16;
+      };
+      u32x4_t fr[DEPTH];
+#pragma unroll
+      for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)addr(u);
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + DEPTH - 1 < UNITS) fr[(u + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)addr(u + DEPTH - 1);
+        const int q = u / MTW, j = u % MTW;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(wq[q % PW][t], fr[u % DEPTH], acc[j][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == MTW - 1) {   // (past the last K step the same fragments are fetched again: no branch in the step)
+          const int step = c * 18 + q + PW;
+          load_w(wq[q % PW], step < KSTEPS ? step : KSTEPS - 1);
+        }
+      }
+    }
+    __syncthreads();   // everyone has read its last y1 fragment: y2 takes the window's place (positions at pitch WP)
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+#pragma unroll
+      for (int P = 0; P < 2; ++P) {
+        lds_f32x4_t sp = (lds_f32x4_t)(tab + 2 * CM + 64 * wn + 32 * P + 8 * g);
+        asm volatile("" : "+v"(sp));
+        const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[CM / 4], sh1 = sp[CM / 4 + 1];
+        u32x4_t ov;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ov[i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P][2 * i], sc0[2 * i], sh0[2 * i]), 0.f, 65504.f),
+                         __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P][2 * i + 1], sc0[2 * i + 1], sh0[2 * i + 1]), 0.f, 65504.f));
+          ov[2 + i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P + 1][2 * i], sc1[2 * i], sh1[2 * i]), 0.f, 65504.f),
+                             __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P + 1][2 * i + 1], sc1[2 * i + 1], sh1[2 * i + 1]), 0.f, 65504.f));
+        }
+        *(u32x4_t*)(win + plane_lane + (8 * wn + 4 * P) * PLANE + j * 256) = ov;
+      }
+    }
+    __syncthreads();
+  }
+
+  // =====================================================================================================================
+  // phase 3: out = ReLU(BN3(W3 . y2) + x), 4 passes of 64 WN couts; a wave's couts in pass q: 64 (q WN + wn) .. + 63
+  // =====================================================================================================================
+  {
+    constexpr int KS3 = CM / 32;
+    // output / shortcut row segments: position q = 16 (wm MTW + j) + p -> pixel (r0 + q / WP, q % WP), 8 couts from 8 g
+    unsigned yoff[MTW];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int q = 16 * (wm * MTW + j) + p;
+      const int orow = q / WP, ocol = q - orow * WP;
+      yoff[j] = (orow < R && ocol < HW) ? (unsigned)((img * HW + r0 + orow) * HW + ocol) * (unsigned)(C4 * 2) + (unsigned)(64 * wn + 8 * g) * 2
+                                        : 0x80000000u;
+    }
+    constexpr int RD = MTW < 4 ? MTW : 4;       // position tiles whose shortcut values are in flight
+    for (int pass = 0; pass < 4; ++pass) {
+      const int co = pass * 64 * WN;            // first cout of the pass (this wave: + 64 wn)
+      // shortcut values of the first RD tiles, requested now; the epilogue of tile j requests tile j + RD's into the
+      // registers it has just consumed.  (Loads take the pass's column offset as soffset; stores never do - conv_pw.hip's
+      // store-data hazard note - theirs goes into the vector offset.)
+      u32x4_t rq[RD][2];
+#pragma unroll
+      for (int j = 0; j < RD; ++j)
+#pragma unroll
+        for (int P = 0; P < 2; ++P) rq[j][P] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j] + P * 64, co * 2, 0);
+      u32x4_t wq[2][4];
+      auto load_w = [&](u32x4_t (&d)[4], int s) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          d[t] = __builtin_amdgcn_raw_buffer_load_b128(rw3, w_lane + t * 1024, (s * (C4 / 32) + pass * 2 * WN) * 2048, 0);
+      };
+      load_w(wq[0], 0);
+      f32x4_t acc[MTW][4];
+#pragma unroll
+      for (int j = 0; j < MTW; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      lds_u8_t sb = (lds_u8_t)win + plane_lane;   // one running base: K step s reads planes 4 s + g
+#pragma unroll
+      for (int s = 0; s < KS3; ++s) {
+        asm volatile("" : "+v"(sb));
+        load_w(wq[(s + 1) & 1], s + 1 < KS3 ? s + 1 : KS3 - 1);
+        u32x4_t fr[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)(sb + u * 256);
+#pragma unroll
+        for (int j = 0; j < MTW; ++j) {
+          if (j + DEPTH - 1 < MTW) fr[(j + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)(sb + (j + DEPTH - 1) * 256);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(wq[s & 1][t], fr[j % DEPTH], acc[j][t]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        sb += 4 * PLANE;
+      }
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) {
+        const unsigned yo = yoff[j] + (unsigned)(co * 2);
+#pragma unroll
+        for (int P = 0; P < 2; ++P) {
+          lds_f32x4_t sp = (lds_f32x4_t)(tab + 4 * CM + co + 64 * wn + 32 * P + 8 * g);
+          asm volatile("" : "+v"(sp));
+          const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[C4 / 4], sh1 = sp[C4 / 4 + 1];
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = __builtin_fmaf(acc[j][2 * P][r], sc0[r], sh0[r]);
+            v[4 + r] = __builtin_fmaf(acc[j][2 * P + 1][r], sc1[r], sh1[r]);
+          }
+          const u32x4_t q = rq[j % RD][P];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[2 * i] += lo_f32<DT_F16>(q[i]);
+            v[2 * i + 1] += hi_f32<DT_F16>(q[i]);
+          }
+          if (j + RD < MTW) rq[j % RD][P] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j + RD] + P * 64, co * 2, 0);
+          u32x4_t ov;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            ov[i] = pack2h(__builtin_amdgcn_fmed3f(v[2 * i], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[2 * i + 1], 0.f, 65504.f));
+          __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yo + P * 64, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int CM, int HW, int R>
+int launch_bneck(const BneckArgs& a, hipStream_t s) {
+  using K = BnCfg<CM, HW, R>;
+  static std::atomic<unsigned long long> attr;
+  if (!spk_lds_limit_once(attr, (const void*)&conv_bneck_kernel<CM, HW, R>, 160 * 1024)) return -1;
+  hipLaunchKernelGGL((conv_bneck_kernel<CM, HW, R>), dim3(a.N * (HW / R)), dim3(512), K::LDS, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+}  // namespace
+
+// 0 ok, -1 HIP error, -3 no kernel for this shape (the caller runs the three convs one by one)
+int spk_bneck_launch(const BneckArgs& a, hipStream_t s) {
+  if (a.N <= 0 || a.H != a.W || a.C4 != 4 * a.CM) return -3;
+  if ((size_t)a.N * a.H * a.W * a.C4 * 2 >= 0x80000000ull) return -3;
+  if (a.CM == 256 && a.H == 14) return launch_bneck<256, 14, 14>(a, s);
+  return -3;
+}

@@ -366,6 +366,84 @@ extern "C" int spk_op_conv3x3(const void* x, const float* w_ohwi, const float* b
 }
 extern "C" int spk_op_conv3x3_num_configs(void) { return spk_c3_num_configs(); }
 
+// A whole identity bottleneck block of the eval path on caller-provided buffers: x, y [n,h,w,4 cm] fp16; fp32 weights
+// w1 [cm][4 cm], w2 [cm][3][3][cm], w3 [4 cm][cm]; folded BatchNorm scale / shift per conv.  fused != 0: the one-kernel
+// form (conv_bneck.hip; SPK_ERR_UNSUPPORTED when it has no instantiation for the shape); fused == 0: the same block as three
+// launches of the eval path's own kernels (conv_pw.hip, conv_c3.hip, conv_pw.hip with the shortcut), mid tensors in
+// scratch - the reference point of the parity test and of the tuner.  iters > 0: the launches are repeated and *ms_out
+// receives the mean time of one block (events on `stream`).
+extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2, const float* w3, const float* s1,
+                                 const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, void* y,
+                                 int n, int h, int wd, int cm, int fused, int iters, float* ms_out, void* stream) {
+  if (!x || !w1 || !w2 || !w3 || !s1 || !b1 || !s2 || !b2 || !s3 || !b3 || !y || n < 1 || h < 1 || wd < 1 || x == y)
+    return ofail(SPK_ERR_ARG, "op_bottleneck: bad arguments");
+  if (cm % 64) return ofail(SPK_ERR_UNSUPPORTED, "mid channels must be a multiple of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const int c4 = 4 * cm, M = n * h * wd;
+  if ((size_t)M * c4 * 2 >= 0x80000000ull) return ofail(SPK_ERR_UNSUPPORTED, "op_bottleneck: an operand of 2 GiB or more");
+  Scratch sc;
+  bf16_t* p1 = sc.get<bf16_t>((size_t)cm * c4);
+  bf16_t* p2 = sc.get<bf16_t>((size_t)9 * cm * cm);
+  bf16_t* p3 = sc.get<bf16_t>((size_t)cm * c4);
+  bf16_t* y1 = sc.get<bf16_t>((size_t)M * cm);
+  bf16_t* y2 = sc.get<bf16_t>((size_t)M * cm);
+  if (!p1 || !p2 || !p3 || !y1 || !y2) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pack_pw(w1, nullptr, p1, cm, c4, DT_F16, 1, s), "pack_pw");
+  O_TRY(spk_launch_pack_c3(w2, p2, cm, cm, 1, s), "pack_c3");
+  O_TRY(spk_launch_pack_pw(w3, nullptr, p3, c4, cm, DT_F16, 1, s), "pack_pw");
+  BneckArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.w1 = p1; a.w2 = p2; a.w3 = p3;
+  a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
+  a.N = n; a.H = h; a.W = wd; a.C4 = c4; a.CM = cm; a.x_bytes = (unsigned)((size_t)M * c4 * 2);
+  auto pw = [&](const bf16_t* in, const bf16_t* wp, bf16_t* out, const bf16_t* res, const float* sc_, const float* sh_, int cin,
+                int cout) {
+    PwConvArgs q;
+    memset(&q, 0, sizeof q);
+    q.x = in; q.wp = wp; q.y = out; q.res = res; q.scale = sc_; q.shift = sh_;
+    q.N = n; q.H = h; q.W = wd; q.Ho = h; q.Wo = wd; q.stride = 1; q.Cin = cin; q.Cout = cout; q.M = M;
+    q.relu = 1; q.dt = DT_F16; q.nb = 1;
+    q.x_bytes = (unsigned)((size_t)M * cin * 2);
+    q.y_bytes = (unsigned)((size_t)M * cout * 2);
+    for (int cfg : {7, 9, 11, 5, 1, 3, 0, 4})    // (every configuration gives the same bits: tests/test_gpu_pw.py)
+      if (const int r = spk_pw_launch(q, cfg, s); r != -3) return r;
+    return -3;
+  };
+  auto once = [&]() -> int {
+    if (fused) return spk_bneck_launch(a, s);
+    if (const int r = pw((const bf16_t*)x, p1, y1, nullptr, s1, b1, c4, cm)) return r;
+    C3Args q;
+    memset(&q, 0, sizeof q);
+    q.x = y1; q.wp = p2; q.y = y2; q.scale = s2; q.shift = b2;
+    q.N = n; q.H = h; q.W = wd; q.Cin = cm; q.Cout = cm; q.M = M; q.relu = 1; q.dt = DT_F16; q.nb = 1;
+    q.x_bytes = q.y_bytes = (unsigned)((size_t)M * cm * 2);
+    q.wp_bytes = (unsigned)((size_t)9 * cm * cm * 2);
+    int r = -3;
+    for (int cfg : {2, 0, 10, 8, 9, 3, 7})       // (likewise: tests/test_gpu_c3.py)
+      if ((r = spk_c3_launch(q, cfg, s)) != -3) break;
+    if (r) return r;
+    return pw(y2, p3, (bf16_t*)y, (const bf16_t*)x, s3, b3, cm, c4);
+  };
+  int r = once();
+  if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "no kernel for this bottleneck shape");
+  if (r) return ofail(SPK_ERR_HIP, "bottleneck launch failed");
+  if (iters > 0 && ms_out) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return ofail(SPK_ERR_HIP, "hipEventCreate failed");
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters && !r; ++i) r = once();
+    (void)hipEventRecord(e1, s);
+    float ms = 0.f;
+    const bool ok = !r && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (!ok) return ofail(SPK_ERR_HIP, "bottleneck timing failed");
+    *ms_out = ms / iters;
+  }
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "bottleneck kernel failed");
+  return SPK_OK;
+}
+
 // Zero-sum rounding of fp32 weight rows to fp16 values (zero_sum.hip) on caller-provided device buffers: w, out
 // [rows][row_len] fp32, mu [mu_period] fp32 or null.  The kernel spk_commit runs per conv in the calibrated mode.
 extern "C" int spk_op_zero_sum_round(const float* w, const float* mu, float* out, int64_t rows, int row_len, int mu_period,

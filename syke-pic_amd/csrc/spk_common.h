@@ -225,6 +225,22 @@ int spk_launch_pack_c3(const float* w_ohwi, bf16_t* out, int cout, int cin, int 
 int spk_conv3x3_launch(const C3Args& a, hipStream_t s);
 
 // ---------------------------------------------------------------------------
+// A whole identity bottleneck block (1x1 -> 3x3 -> 1x1 + shortcut, ReLU after each BatchNorm) as one kernel: the two mid
+// tensors stay in LDS (conv_bneck.hip).  fp16, single weight images.
+// ---------------------------------------------------------------------------
+struct BneckArgs {
+  const bf16_t* x;      // [N,H,W,C4] fp16: block input = shortcut
+  bf16_t* y;            // [N,H,W,C4] fp16 (may not alias x: a band reads the halo rows of x its neighbours write in y)
+  const bf16_t* w1;     // conv1 [CM][C4]        packed by spk_launch_pack_pw (nb = 1)
+  const bf16_t* w2;     // conv2 [CM][3][3][CM]  packed by spk_launch_pack_c3 (nb = 1)
+  const bf16_t* w3;     // conv3 [C4][CM]        packed by spk_launch_pack_pw (nb = 1)
+  const float *s1, *b1, *s2, *b2, *s3, *b3;   // folded eval-BatchNorm scale / shift of the three convs
+  int N, H, W, C4, CM;
+  unsigned int x_bytes; // N*H*W*C4*2
+};
+int spk_bneck_launch(const BneckArgs& a, hipStream_t s);   // -3: no kernel for this shape
+
+// ---------------------------------------------------------------------------
 // Zero-sum rounding of fp16 weights + activation means (zero_sum.hip)
 // ---------------------------------------------------------------------------
 // w, out: [rows][row_len] fp32; mu: [mu_period] (element k is weighted with mu[k % mu_period]) or null (all ones).

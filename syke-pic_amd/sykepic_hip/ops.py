@@ -255,6 +255,29 @@ def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0, res=Non
     return y.permute(0, 3, 1, 2)
 
 
+def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0):
+    """Eval-path identity bottleneck block (spk_op_bottleneck): x [N,4cm,H,W] float16, w1 [cm,4cm,1,1], w2 [cm,cm,3,3],
+    w3 [4cm,cm,1,1], bn* = (scale, shift) of the folded eval BatchNorms.  fused: the one-kernel form (csrc/conv_bneck.hip),
+    else the eval path's three launches.  Returns y [N,4cm,H,W] (and the mean milliseconds per block when iters > 0)."""
+    import ctypes as C
+    so = lib.load()
+    dev = x.device
+    n, c4, h, w = x.shape
+    cm = w1.shape[0]
+    xh = x.half().permute(0, 2, 3, 1).contiguous()
+    y = torch.full((n, h, w, c4), float("nan"), dtype=torch.float16, device=dev)
+    k1 = w1.float().reshape(cm, c4).contiguous()
+    k2 = w2.float().permute(0, 2, 3, 1).contiguous()
+    k3 = w3.float().reshape(c4, cm).contiguous()
+    vecs = [t.float().contiguous() for pair in (bn1, bn2, bn3) for t in pair]
+    ms = C.c_float(0.0)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_bottleneck(_p(xh), _p(k1), _p(k2), _p(k3), *[_p(v) for v in vecs], _p(y), n, h, w, cm,
+                                       int(bool(fused)), int(iters), C.cast(C.pointer(ms), C.c_void_p), _stream(dev)))
+    out = y.permute(0, 3, 1, 2)
+    return (out, float(ms.value)) if iters > 0 else out
+
+
 def zero_sum_round(w, mu=None, period=None):
     """w [rows, row_len] float32 device tensor, mu [period] or None -> the zero-sum rounded rows (float32 values that are
     fp16 numbers), csrc/zero_sum.hip."""

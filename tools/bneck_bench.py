@@ -1,0 +1,30 @@
+"""Times one identity bottleneck block of the eval path: the one-kernel form (csrc/conv_bneck.hip) against the three
+launches of the eval path's own kernels, through spk_op_bottleneck.  usage: bneck_bench.py [n ...]"""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "syke-pic_amd")]
+import torch
+from sykepic_hip import ops
+
+SHAPES = {"stage3": (14, 256), "stage2": (28, 128), "stage1": (56, 64)}
+ns = [int(v) for v in sys.argv[1:]] or [256, 128]
+for name, (hw, cm) in SHAPES.items():
+    for n in ns:
+        g = torch.Generator().manual_seed(1)
+        c4 = 4 * cm
+        x = torch.relu(torch.randn(n, c4, hw, hw, generator=g)).half().cuda()
+        w1 = ((torch.rand(cm, c4, 1, 1, generator=g) * 2 - 1) * (6.0 / c4) ** 0.5).cuda()
+        w2 = ((torch.rand(cm, cm, 3, 3, generator=g) * 2 - 1) * (6.0 / (9 * cm)) ** 0.5).cuda()
+        w3 = ((torch.rand(c4, cm, 1, 1, generator=g) * 2 - 1) * (6.0 / cm) ** 0.5).cuda()
+        bns = [((0.5 + torch.rand(c, generator=g)).cuda(), (torch.rand(c, generator=g) - 0.5).cuda()) for c in (cm, cm, c4)]
+        gflop = 2.0 * n * hw * hw * (2 * cm * c4 + 9 * cm * cm) / 1e9
+        mbytes = 2.0 * n * hw * hw * c4 * 2 / 1e6
+        line = f"{name} n={n} {hw}x{hw} cm={cm}: {gflop:.1f} GFLOP, {mbytes:.0f} MB in+out;"
+        for fused in (False, True):
+            try:
+                _, ms = ops.bottleneck(x, w1, w2, w3, *bns, fused=fused, iters=20)
+                line += f"  {'fused' if fused else 'three launches'} {ms * 1e3:.1f} us = {gflop / ms:.0f} TFLOP/s, {mbytes / ms:.0f} GB/s;"
+            except RuntimeError as e:
+                line += f"  {'fused' if fused else 'three launches'}: {str(e)[:60]};"
+        print(line, flush=True)
