@@ -334,7 +334,8 @@ int spk_op_conv3x3_num_configs(void);
  * block over `iters` repetitions. */
 int spk_op_bottleneck(const void* x_dev, const float* w1_dev, const float* w2_dev, const float* w3_dev, const float* s1_dev,
                       const float* b1_dev, const float* s2_dev, const float* b2_dev, const float* s3_dev, const float* b3_dev,
-                      void* y_dev, int n, int h, int w, int cm, int fused, int iters, float* ms_out, void* stream);
+                      void* y_dev, int n, int h, int w, int cm, int fused, int iters, float* ms_out, void* stream,
+                      unsigned long long* stamps_dev /* diagnostics: [blocks][8] shader-clock stamps of the fused kernel, or null */);
 /* Two chained 1x1 convs in ONE launch (round 4, csrc/conv_pw.hip): y = act(BN(W . x) + res) with cout = 256, then
  * z = actz(BNz(Wz . y)) computed from the output tile while it is still in registers - what the eval path runs for a
  * bottleneck's block-closing conv and the next block's first conv in the single-weight-image modes (the trunk y is

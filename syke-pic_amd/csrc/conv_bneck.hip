@@ -78,6 +78,19 @@ __device__ __forceinline__ unsigned int pack2h(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2_t));
 }
 
+// A 16-byte buffer load the compiler's s_waitcnt pass does not see (phase 1's weight fragments).  hipcc 7.2 does not count
+// LDS-DMA instructions when it derives the vmcnt of a register load's first use, so with builtin loads next to the DMAs it
+// waits for "all but N" with an N that is too small by the DMAs issued in between - i.e. for the x chunk still in flight.
+// The caller orders these loads with its own s_waitcnt (the same that publishes the DMA pieces).
+__device__ __forceinline__ u32x4_t buffer_load_b128_untracked(u32x4_t rsrc, unsigned voff, unsigned soff, int imm) {
+  u32x4_t d;
+  if (imm == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  else if (imm == 1024) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  else if (imm == 2048) asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  else asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=v"(d) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  return d;
+}
+
 template <int CM, int HW, int R>
 __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   using K = BnCfg<CM, HW, R>;
@@ -102,7 +115,6 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, CM * C4 * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 9 * CM * CM * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, CM * C4 * 2, 0x00020000);
 
@@ -113,6 +125,12 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     tab[2 * CM + c] = a.s2[c]; tab[3 * CM + c] = a.b2[c];
   }
   for (int c = tid; c < C4; c += 512) { tab[4 * CM + c] = a.s3[c]; tab[4 * CM + C4 + c] = a.b3[c]; }
+
+  // diagnostics only: wave 0 leaves the shader clock at each phase boundary (a.stamps null in the product path)
+  auto stamp = [&](int i) {
+    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
 
   // weight fragments of this wave's 64 couts: [K step][pair][tile][lane][8] images, pairs 2 wn and 2 wn + 1
   const unsigned w_lane = (unsigned)(2 * wn) * 2048 + lane * 16;
@@ -142,12 +160,14 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     // (K step 1 of a chunk = chunk 4 + g: slot (4 + g) ^ s = (g ^ s) ^ 4 - the byte offset xor 64)
     const unsigned xlane = (unsigned)((wm * MT1 * 16 + p) * 128 + ((g ^ ((p >> 1) & 7)) << 4));
     u32x4_t wa[2][2][4];   // [chunk parity][ks][tile of the wave's 64 couts]
+    // (the descriptor by hand for the asm form: base, stride 0, bytes, raw-buffer flags - make_buffer_rsrc's words)
+    const unsigned long long w1p = (unsigned long long)a.w1;
+    const u32x4_t rw1s = {(unsigned)w1p, (unsigned)(w1p >> 32) & 0xffffu, (unsigned)(CM * C4 * 2), 0x00020000u};
     auto load_w = [&](u32x4_t (&d)[2][4], int c) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          d[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(rw1, w_lane + t * 1024, (2 * c + ks) * (CM * 64), 0);
+        for (int t = 0; t < 4; ++t) d[ks][t] = buffer_load_b128_untracked(rw1s, w_lane, (unsigned)((2 * c + ks) * (CM * 64)), t * 1024);
     };
     f32x4_t acc[MT1][4];
 #pragma unroll
@@ -163,6 +183,8 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       // publishes everyone's pieces and proves everyone is done with chunk c - 1, whose stage is refilled at once
       if (NXS == 3 && c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (the chunk's weight fragments - requested one chunk ago, BEFORE the DMAs that may still be in flight - are complete
+      // here too: buffer_load_b128_untracked)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       load_w(wnext, c + 1 < NCH ? c + 1 : NCH - 1);
@@ -191,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       chunk(c, wa[0], wa[1]);
       chunk(c + 1, wa[1], wa[0]);
     }
+    stamp(1);
     __syncthreads();   // everyone is done with the x ring: the window takes its place
 
     // zeros wherever the window has no image pixel: the shared padding column, rows outside the image, the tail
@@ -225,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     __syncthreads();
   }
 
+  stamp(2);
   // position tiles of this wave in phases 2 and 3: window-pitch positions 16 (wm MTW + j) + p
   const unsigned plane_lane = (unsigned)(g * PLANE + (wm * MTW * 16 + p) * 16);
 
@@ -272,6 +296,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
         }
       }
     }
+    stamp(3);
     __syncthreads();   // everyone has read its last y1 fragment: y2 takes the window's place (positions at pitch WP)
 #pragma unroll
     for (int j = 0; j < MTW; ++j) {
@@ -295,10 +320,15 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   }
 
   // =====================================================================================================================
-  // phase 3: out = ReLU(BN3(W3 . y2) + x), 4 passes of 64 WN couts; a wave's couts in pass q: 64 (q WN + wn) .. + 63
+  // phase 3: out = ReLU(BN3(W3 . y2) + x) in 8 half passes: in half pass hp a wave computes the 32 couts
+  // (hp / 2) 64 WN + 64 wn + 32 (hp % 2) .. + 31 of its position tiles.  Everything a half pass reads from memory is
+  // requested one half pass earlier, BEFORE the previous epilogue's stores (vmcnt retires in issue order: a load waited for
+  // behind stores sits through their write latency): its weight fragments when the previous K loop has consumed the
+  // register set, its shortcut values into the second of two register sets.
   // =====================================================================================================================
   {
     constexpr int KS3 = CM / 32;
+    stamp(4);
     // output / shortcut row segments: position q = 16 (wm MTW + j) + p -> pixel (r0 + q / WP, q % WP), 8 couts from 8 g
     unsigned yoff[MTW];
 #pragma unroll
@@ -308,76 +338,90 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       yoff[j] = (orow < R && ocol < HW) ? (unsigned)((img * HW + r0 + orow) * HW + ocol) * (unsigned)(C4 * 2) + (unsigned)(64 * wn + 8 * g) * 2
                                         : 0x80000000u;
     }
-    constexpr int RD = MTW < 4 ? MTW : 4;       // position tiles whose shortcut values are in flight
-    for (int pass = 0; pass < 4; ++pass) {
-      const int co = pass * 64 * WN;            // first cout of the pass (this wave: + 64 wn)
-      // shortcut values of the first RD tiles, requested now; the epilogue of tile j requests tile j + RD's into the
-      // registers it has just consumed.  (Loads take the pass's column offset as soffset; stores never do - conv_pw.hip's
-      // store-data hazard note - theirs goes into the vector offset.)
-      u32x4_t rq[RD][2];
+    // The two waves of a SIMD run the same program from the same barrier: left alone they multiply together (sharing the
+    // matrix pipe) and then run their epilogues together (sharing the vector issue).  A static priority for waves 4-7 lets
+    // them take the pipe first; the other half then multiplies while they are in their epilogue, and the halves stay
+    // out of phase (MI355X_MICROARCH.md, "Two waves per SIMD", items 4 and 9).
+    if (wave >= 4 && !(a.flags & 1)) __builtin_amdgcn_s_setprio(1);
+    u32x4_t wq[KS3][2];      // the half pass's weight fragments: K step x tile of the pair
+    u32x4_t rq[2][MTW];      // shortcut values: this half pass's and the next one's
+    auto col = [&](int hp) { return (hp >> 1) * 64 * WN + 32 * (hp & 1); };   // first cout of the half pass (this wave: + 64 wn)
+    auto load_w = [&](int hp) {
 #pragma unroll
-      for (int j = 0; j < RD; ++j)
+      for (int ks = 0; ks < KS3; ++ks)
 #pragma unroll
-        for (int P = 0; P < 2; ++P) rq[j][P] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j] + P * 64, co * 2, 0);
-      u32x4_t wq[2][4];
-      auto load_w = [&](u32x4_t (&d)[4], int s) {
+        for (int t = 0; t < 2; ++t)
+          wq[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(rw3, w_lane + t * 1024, (ks * (C4 / 32) + (hp >> 1) * 2 * WN + (hp & 1)) * 2048, 0);
+    };
+    auto load_r = [&](u32x4_t (&d)[MTW], int hp) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          d[t] = __builtin_amdgcn_raw_buffer_load_b128(rw3, w_lane + t * 1024, (s * (C4 / 32) + pass * 2 * WN) * 2048, 0);
+      for (int j = 0; j < MTW; ++j) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j], col(hp) * 2, 0);
+    };
+    load_w(0);
+    load_r(rq[0], 0);
+    lds_u8_t sb0 = (lds_u8_t)win + plane_lane, sb1 = sb0 + (KS3 > 4 ? 16 * PLANE : 0);
+    asm volatile("" : "+v"(sb0), "+v"(sb1));
+    auto half_pass = [&](int hp, const u32x4_t (&rcur)[MTW], u32x4_t (&rnext)[MTW]) {
+      f32x4_t acc[MTW][2];
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) acc[j][0] = acc[j][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      constexpr int UNITS = KS3 * MTW;
+      // unit u = (K step ks, position tile j): planes 4 ks + g (two bases: the ds_read immediate reaches 64 KB)
+      auto addr = [&](int u) {
+        const int ks = u / MTW, j = u % MTW;
+        return (ks < 4 ? sb0 + ks * 4 * PLANE : sb1 + (ks - 4) * 4 * PLANE) + j * 256;
       };
-      load_w(wq[0], 0);
-      f32x4_t acc[MTW][4];
+      u32x4_t fr[DEPTH];
 #pragma unroll
-      for (int j = 0; j < MTW; ++j)
+      for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)addr(u);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      lds_u8_t sb = (lds_u8_t)win + plane_lane;   // one running base: K step s reads planes 4 s + g
-#pragma unroll
-      for (int s = 0; s < KS3; ++s) {
-        asm volatile("" : "+v"(sb));
-        load_w(wq[(s + 1) & 1], s + 1 < KS3 ? s + 1 : KS3 - 1);
-        u32x4_t fr[DEPTH];
-#pragma unroll
-        for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)(sb + u * 256);
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) {
-          if (j + DEPTH - 1 < MTW) fr[(j + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)(sb + (j + DEPTH - 1) * 256);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(wq[s & 1][t], fr[j % DEPTH], acc[j][t]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        sb += 4 * PLANE;
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + DEPTH - 1 < UNITS) fr[(u + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)addr(u + DEPTH - 1);
+        const int ks = u / MTW, j = u % MTW;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[j][0] = mfma16<DT_F16>(wq[ks][0], fr[u % DEPTH], acc[j][0]);
+        acc[j][1] = mfma16<DT_F16>(wq[ks][1], fr[u % DEPTH], acc[j][1]);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      // the next half pass's operands, in front of this one's stores
+      if (hp + 1 < 8) {
+        load_w(hp + 1);
+        load_r(rnext, hp + 1);
+      }
+      if (hp == 0) stamp(7);
+      __builtin_amdgcn_sched_barrier(0);
+      const int co = col(hp);
+      lds_f32x4_t sp = (lds_f32x4_t)(tab + 4 * CM + co + 64 * wn + 8 * g);
+      asm volatile("" : "+v"(sp));
+      const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[C4 / 4], sh1 = sp[C4 / 4 + 1];
 #pragma unroll
       for (int j = 0; j < MTW; ++j) {
-        const unsigned yo = yoff[j] + (unsigned)(co * 2);
+        float v[8];
 #pragma unroll
-        for (int P = 0; P < 2; ++P) {
-          lds_f32x4_t sp = (lds_f32x4_t)(tab + 4 * CM + co + 64 * wn + 32 * P + 8 * g);
-          asm volatile("" : "+v"(sp));
-          const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[C4 / 4], sh1 = sp[C4 / 4 + 1];
-          float v[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            v[r] = __builtin_fmaf(acc[j][2 * P][r], sc0[r], sh0[r]);
-            v[4 + r] = __builtin_fmaf(acc[j][2 * P + 1][r], sc1[r], sh1[r]);
-          }
-          const u32x4_t q = rq[j % RD][P];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            v[2 * i] += lo_f32<DT_F16>(q[i]);
-            v[2 * i + 1] += hi_f32<DT_F16>(q[i]);
-          }
-          if (j + RD < MTW) rq[j % RD][P] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j + RD] + P * 64, co * 2, 0);
-          u32x4_t ov;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            ov[i] = pack2h(__builtin_amdgcn_fmed3f(v[2 * i], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[2 * i + 1], 0.f, 65504.f));
-          __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yo + P * 64, 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          v[r] = __builtin_fmaf(acc[j][0][r], sc0[r], sh0[r]);
+          v[4 + r] = __builtin_fmaf(acc[j][1][r], sc1[r], sh1[r]);
         }
+        const u32x4_t q = rcur[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[2 * i] += lo_f32<DT_F16>(q[i]);
+          v[2 * i + 1] += hi_f32<DT_F16>(q[i]);
+        }
+        u32x4_t ov;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          ov[i] = pack2h(__builtin_amdgcn_fmed3f(v[2 * i], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[2 * i + 1], 0.f, 65504.f));
+        // (the column offset in the VECTOR operand, never an SGPR soffset on a store: conv_pw.hip's store-data hazard note)
+        __builtin_amdgcn_raw_buffer_store_b128(ov, ry, yoff[j] + (unsigned)(co * 2), 0, 0);
       }
+      if (hp == 0) stamp(6);
+    };
+    for (int hp = 0; hp < 8; hp += 2) {
+      half_pass(hp, rq[0], rq[1]);
+      half_pass(hp + 1, rq[1], rq[0]);
     }
+    stamp(5);
   }
 }
 
@@ -393,9 +437,13 @@ int launch_bneck(const BneckArgs& a, hipStream_t s) {
 }  // namespace
 
 // 0 ok, -1 HIP error, -3 no kernel for this shape (the caller runs the three convs one by one)
-int spk_bneck_launch(const BneckArgs& a, hipStream_t s) {
+int spk_bneck_launch(const BneckArgs& a0, hipStream_t s) {
+  static const int env_flags = getenv("SPK_BNECK_FLAGS") ? atoi(getenv("SPK_BNECK_FLAGS")) : 0;
+  BneckArgs a = a0;
+  a.flags |= env_flags;
   if (a.N <= 0 || a.H != a.W || a.C4 != 4 * a.CM) return -3;
   if ((size_t)a.N * a.H * a.W * a.C4 * 2 >= 0x80000000ull) return -3;
-  if (a.CM == 256 && a.H == 14) return launch_bneck<256, 14, 14>(a, s);
+  if (a.CM == 256 && a.H == 14) return launch_bneck<256, 14, 14>(a, s);   // ResNet-50 stage 3: a block owns an image
+  if (a.CM == 128 && a.H == 28) return launch_bneck<128, 28, 14>(a, s);   // stage 2: two bands of 14 rows per image
   return -3;
 }

@@ -53,6 +53,11 @@ struct Layer {
   int chained_by = -1;            // that conv: index of the block-closing conv
   bool chained_now_h[2] = {false, false};   // set by the block-closing conv's launch of the current forward, per half-batch
                                   // chain (index = spk_model::half): chain_next is done for THAT half
+  // eval, single-weight modes: a whole identity bottleneck block - conv1 1x1 -> conv2 3x3 -> conv3 1x1 + shortcut, ReLU behind
+  // each BatchNorm - as ONE kernel (conv_bneck.hip): the two mid tensors are never written
+  int bn_c2 = -1, bn_c3 = -1;     // the block's conv1: indices of its conv2 / conv3, or -1
+  int bn_head = -1;               // conv2 / conv3 of such a block: index of its conv1
+  bool bneck_now_h[2] = {false, false};   // conv1: the one-kernel form ran for this half-batch chain of the current forward
   size_t mu_off = 0;              // generic convs: offset of this layer's cin input-channel means in spk_model::act_mean
   // fp16 eval of an MBConv block: the squeeze-excitation layer computes its gates only and the project 1x1 conv that is
   // the sole reader of its output multiplies them into its activation operand (conv_igemm.hip, spk_set_gate)
@@ -97,6 +102,8 @@ struct spk_model {
   bool fuse_se = true;         // fp16 eval: squeeze-excitation scaling inside the project conv (SPK_SE_FUSE=0: its own pass)
   int chain = 1;               // conv3 -> next conv1 chaining: 1 where it is faster (timed once per problem), SPK_CHAIN=0 never, 2 always
   bool no_chain_now = false;   // the chain tuner is timing the two-kernel alternative
+  int bneck = 1;               // whole-bottleneck kernel: 1 where it is faster (timed once per problem), SPK_BNECK=0 never, 2 always
+  bool no_bneck_now = false;   // its tuner is timing the three-launch alternative
   std::vector<char> stale;     // per tensor: the last eval forward did not write it (a fused-away shortcut tensor)
   bool effnet = false;         // EfficientNet graph (widths that are not multiples of 64, depthwise / SE / SiLU ops): its
                                // TRAINING plan pads every activation tensor to a multiple of 64 channels (train_effnet.hip)

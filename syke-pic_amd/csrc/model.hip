@@ -228,6 +228,36 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       hipMemcpy(m->pbuf + p.off, ones.data(), ones.size() * 4, hipMemcpyHostToDevice);
     }
   }
+  // identity bottleneck blocks: conv3 (1x1, + shortcut, ReLU) <- conv2 (3x3 stride 1 pad 1, ReLU) <- conv1 (1x1, ReLU) whose
+  // input IS conv3's shortcut operand, mid tensors read by nothing else, 4 cm trunk channels (conv_bneck.hip)
+  for (size_t i3 = 0; i3 < m->layers.size(); ++i3) {
+    Layer& L3 = m->layers[i3];
+    if (L3.d.kind != SPK_OP_CONV || L3.d.k != 1 || L3.d.stride != 1 || L3.d.pad != 0 || L3.d.res < 0 || L3.d.relu != 1) continue;
+    auto producer = [&](int t) {
+      int idx = -1, readers = 0;
+      for (size_t j = 0; j < m->layers.size(); ++j) {
+        const Layer& Q = m->layers[j];
+        if (Q.d.dst == t) idx = (int)j;
+        readers += (Q.d.src == t) + (Q.d.kind == SPK_OP_CONV && Q.d.res == t);
+      }
+      return readers == 1 && t != m->layers.back().d.dst ? idx : -1;
+    };
+    const int i2 = producer(L3.d.src);
+    if (i2 < 0) continue;
+    Layer& L2 = m->layers[i2];
+    if (L2.d.kind != SPK_OP_CONV || L2.d.k != 3 || L2.d.stride != 1 || L2.d.pad != 1 || L2.d.res >= 0 || L2.d.relu != 1) continue;
+    const int i1 = producer(L2.d.src);
+    if (i1 < 0) continue;
+    Layer& L1 = m->layers[i1];
+    if (L1.d.kind != SPK_OP_CONV || L1.d.k != 1 || L1.d.stride != 1 || L1.d.pad != 0 || L1.d.res >= 0 || L1.d.relu != 1) continue;
+    const int cm = L1.d.cout;
+    if (L1.d.src != L3.d.res || L2.d.cin != cm || L2.d.cout != cm || L3.d.cin != cm || L3.d.cout != 4 * cm || L1.d.cin != 4 * cm ||
+        cm % 64 || L1.mode != CONV_MODE_GENERIC || L2.mode != CONV_MODE_GENERIC || L3.mode != CONV_MODE_GENERIC)
+      continue;
+    L1.bn_c2 = i2; L1.bn_c3 = (int)i3;
+    L2.bn_head = L3.bn_head = i1;
+  }
+  if (const char* e = getenv("SPK_BNECK")) m->bneck = atoi(e);
   // packed bf16 weights + folded BN scale/bias
   size_t wpack = 0, sb = 0, dwp = 0;
   for (Layer& L : m->layers) {
@@ -249,7 +279,9 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
       }
       L.c3_ok = L.mode == CONV_MODE_GENERIC && L.d.k == 3 && L.d.stride == 1 && L.d.pad == 1 && L.cin_p == L.d.cin &&
                 L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 256 == 0;
-      if (L.c3_ok) {
+      // (the fragment-ordered 3x3 image also feeds the whole-bottleneck kernel: conv2 of such a block keeps one even where
+      // conv_c3.hip itself has no configuration for its width)
+      if (L.c3_ok || (L.bn_head >= 0 && L.d.k == 3)) {
         L.wpw_off = wpack;
         wpack += (size_t)2 * L.d.cout * 9 * L.d.cin;
       }
@@ -610,7 +642,7 @@ int spk_commit(spk_model* m) {
         spk_launch_pack_pw(wsrc, nullptr, m->wpack + L.wpw_off, L.d.cout, L.d.cin, DT_F16, layer_split(m, L) ? 2 : 1,
                            m->stream))
       return fail(SPK_ERR_HIP, "pack_pw launch failed");
-    if (L.c3_ok && m->infer_dt == DT_F16 &&
+    if ((L.c3_ok || (L.bn_head >= 0 && L.d.k == 3)) && m->infer_dt == DT_F16 &&
         spk_launch_pack_c3(wsrc, m->wpack + L.wpw_off, L.d.cout, L.d.cin, layer_split(m, L) ? 2 : 1, m->stream))
       return fail(SPK_ERR_HIP, "pack_c3 launch failed");
   }
@@ -934,12 +966,25 @@ static bool dual_active(const spk_model* m, const Layer& L) {
   return m->fuse_ds && L.dual_src >= 0 && L.dual_ok && m->infer_dt == DT_F16 && !m->precise_res && !m->force_unfused;
 }
 
+// eval: may the block whose first conv is L run as the whole-bottleneck kernel (single fp16 weight images, a shape the kernel
+// has an instantiation for)?
+static bool bneck_shape_ok(int hw_h, int hw_w, int cm) {
+  return hw_h == hw_w && ((cm == 256 && hw_h == 14) || (cm == 128 && hw_h == 28));
+}
+static bool bneck_possible(const spk_model* m, const Layer& L) {
+  if (!m->bneck || m->no_bneck_now || L.bn_c2 < 0 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused) return false;
+  if (layer_split(m, L) || layer_split(m, m->layers[L.bn_c2]) || layer_split(m, m->layers[L.bn_c3])) return false;
+  const TDim& in = m->tdims[L.d.src];
+  return bneck_shape_ok(in.h, in.w, L.d.cout) && in.c == L.d.cin;
+}
+
 // eval: may the block-closing conv L also compute the conv that reads its output (single fp16 weight images only)?
 static bool chain_possible(const spk_model* m, const Layer& L) {
   if (!m->chain || m->no_chain_now || L.chain_next < 0 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused)
     return false;
   const Layer& Q = m->layers[L.chain_next];
   if (layer_split(m, L) || layer_split(m, Q)) return false;
+  if (bneck_possible(m, Q)) return false;   // (that conv is the head of a block the whole-bottleneck kernel computes)
   if (L.dual_src >= 0 && !dual_active(m, L)) return false;   // (a shortcut conv that runs on its own: plain res operand)
   return true;
 }
@@ -1042,9 +1087,125 @@ static bool chain_args(spk_model* m, const Layer& L, PwConvArgs& q, int nb) {
   return true;
 }
 
+// whole-bottleneck kernel or three launches?  Timed once per problem (the same bits either way), "bneck ..." lines of
+// SPK_TUNE_CACHE
+typedef std::tuple<int, int, int> BneckKey;   // H CM N
+static std::map<BneckKey, int> g_bneck_choice;
+static std::mutex g_bneck_mu;
+static bool g_bneck_loaded = false;
+
+static void bneck_args(spk_model* m, const Layer& L, BneckArgs& a, int nb) {
+  const Layer& L2 = m->layers[L.bn_c2];
+  const Layer& L3 = m->layers[L.bn_c3];
+  const TDim& in = m->tdims[L.d.src];
+  memset(&a, 0, sizeof a);
+  a.x = (const bf16_t*)m->TI(L.d.src);
+  a.y = (bf16_t*)m->TI(L3.d.dst);
+  a.w1 = m->wpack + L.wpw_off; a.w2 = m->wpack + L2.wpw_off; a.w3 = m->wpack + L3.wpw_off;
+  a.s1 = m->scale_bias + L.sb_off; a.b1 = a.s1 + L.cout_p;
+  a.s2 = m->scale_bias + L2.sb_off; a.b2 = a.s2 + L2.cout_p;
+  a.s3 = m->scale_bias + L3.sb_off; a.b3 = a.s3 + L3.cout_p;
+  a.N = nb; a.H = in.h; a.W = in.w; a.C4 = L.d.cin; a.CM = L.d.cout;
+  a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
+}
+
+static int bneck_choice(spk_model* m, Layer& L, const BneckArgs& a, int nb) {
+  if (m->bneck >= 2) return 1;
+  // A grid that gives at least every other CU a block (one block per image at 14 x 14, two at 28 x 28): the one-kernel form
+  // without timing.  Inside a forward it wins from there on (ResNet-50, batch 256 as two halves of 128: 3.70 -> 3.34 ms with
+  // all eight blocks of stages 2-3 fused), while the isolated timing below - one launch sequence alone on the chip - sees
+  // a half batch's 128 blocks leave half the CUs idle and would keep the three launches (98 vs 112 us at 14 x 14).
+  if (a.N * (a.H / 14) >= 128) return 1;
+  const BneckKey key(a.H, a.CM, a.N);
+  const char* path = getenv("SPK_TUNE_CACHE");
+  if (path && (!*path || !strcmp(path, "off"))) path = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_bneck_mu);
+    if (!g_bneck_loaded) {
+      g_bneck_loaded = true;
+      if (path)
+        if (FILE* f = fopen(path, "r")) {
+          char line[256];
+          int v[4];
+          while (fgets(line, sizeof line, f))
+            if (sscanf(line, "bneck %d %d %d %d", &v[0], &v[1], &v[2], &v[3]) == 4 && (v[3] == 0 || v[3] == 1))
+              g_bneck_choice[BneckKey(v[0], v[1], v[2])] = v[3];
+          fclose(f);
+        }
+    }
+    auto it = g_bneck_choice.find(key);
+    if (it != g_bneck_choice.end()) return it->second;
+    for (const auto& kv : g_bneck_choice) {   // a ragged tail batch: the choice of a tuned batch within a factor of two
+      const int n2 = std::get<2>(kv.first);
+      if (std::get<0>(kv.first) == a.H && std::get<1>(kv.first) == a.CM && n2 <= 2 * a.N && a.N <= 2 * n2) return kv.second;
+    }
+  }
+  const bool tune = !getenv("SPK_AUTOTUNE") || atoi(getenv("SPK_AUTOTUNE")) != 0;
+  int choice = 1;
+  float t_three = 0.f, t_one = 0.f;
+  hipEvent_t e0, e1;
+  if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    auto three = [&]() {
+      m->no_bneck_now = true;
+      int r = run_conv_eval(m, L, nb);
+      if (r == SPK_OK) r = run_conv_eval(m, m->layers[L.bn_c2], nb);
+      if (r == SPK_OK) r = run_conv_eval(m, m->layers[L.bn_c3], nb);
+      m->no_bneck_now = false;
+      return r;
+    };
+    bool ok = three() == SPK_OK && spk_bneck_launch(a, m->stream) == 0;   // warm-up (and the other kernels' own tuning)
+    if (ok) {
+      (void)hipEventRecord(e0, m->stream);
+      for (int r = 0; r < 3; ++r) (void)three();
+      (void)hipEventRecord(e1, m->stream);
+      ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t_three, e0, e1) == hipSuccess;
+    }
+    if (ok) {
+      (void)hipEventRecord(e0, m->stream);
+      for (int r = 0; r < 3; ++r) (void)spk_bneck_launch(a, m->stream);
+      (void)hipEventRecord(e1, m->stream);
+      ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t_one, e0, e1) == hipSuccess;
+    }
+    choice = ok && t_one < t_three ? 1 : 0;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (getenv("SPK_TUNE_LOG"))
+      fprintf(stderr, "[spk tune bottleneck] N%d %dx%d %d->%d->%d: three kernels %.1f us, one %.1f us\n", a.N, a.H, a.W, a.C4, a.CM,
+              a.C4, t_three * 1000.f / 3.f, t_one * 1000.f / 3.f);
+    std::lock_guard<std::mutex> lk(g_bneck_mu);
+    g_bneck_choice[key] = choice;
+    if (path)
+      if (FILE* f = fopen(path, "a")) {
+        fprintf(f, "bneck %d %d %d %d\n", a.H, a.CM, a.N, choice);
+        fclose(f);
+      }
+  }
+  return choice;
+}
+
 static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   const TDim& in = m->tdims[L.d.src];
   const TDim& o = m->tdims[L.d.dst];
+  // conv2 / conv3 of a bottleneck whose first conv launched the whole-block kernel for this half: done
+  if (L.bn_head >= 0 && !m->no_bneck_now && m->layers[L.bn_head].bneck_now_h[m->half]) {
+    if (L.d.k == 3) m->stale[L.d.dst] = 3;   // y2 was not written (read_activation recomputes it); conv3's output was
+    else m->stale[L.d.dst] = 0;
+    return SPK_OK;
+  }
+  if (L.bn_c2 >= 0 && !m->no_bneck_now) L.bneck_now_h[m->half] = false;
+  if (bneck_possible(m, L) && !(L.chained_by >= 0 && m->layers[L.chained_by].chained_now_h[m->half])) {
+    BneckArgs ba;
+    bneck_args(m, L, ba, nb);
+    if (bneck_choice(m, L, ba, nb) == 1) {
+      const int r = spk_bneck_launch(ba, m->stream);
+      if (r == 0) {
+        L.bneck_now_h[m->half] = true;
+        m->stale[L.d.dst] = 3;               // y1 was not written
+        return SPK_OK;
+      }
+      (void)hipGetLastError();               // (no instantiation after all, or the launch was refused: three launches)
+    }
+  }
   if (L.chained_by >= 0 && !m->no_chain_now && m->layers[L.chained_by].chained_now_h[m->half]) return SPK_OK;   // done by that launch
   if (L.chain_next >= 0 && !m->no_chain_now) L.chained_now_h[m->half] = false;
   if (L.fused_into >= 0 && dual_active(m, m->layers[L.fused_into])) {
@@ -1701,6 +1862,19 @@ extern "C" int spk_model_read_activation(spk_model* m, int t, int n, float* host
             if (r != SPK_OK) return r;
           }
   }
+  if (t < (int)m->stale.size() && m->stale[t] == 3 && m->last_eval_nb > 0) {
+    // a mid tensor of a bottleneck block the last forward ran as one kernel: conv1 (and conv2) on their own - the block's
+    // input is still there
+    for (Layer& L : m->layers)
+      if (L.d.kind == SPK_OP_CONV && L.d.dst == t) {
+        m->force_unfused = true;
+        int r = SPK_OK;
+        if (L.bn_head >= 0) r = run_conv_eval(m, m->layers[L.bn_head], m->last_eval_nb);
+        if (r == SPK_OK) r = run_conv_eval(m, L, m->last_eval_nb);
+        m->force_unfused = false;
+        if (r != SPK_OK) return r;
+      }
+  }
   if (t == m->stale_stem_t && m->last_eval_nb > 0) {
     // the last forward computed stem + max-pool in one kernel and never wrote this tensor: run the stem layer alone
     // (its input is still in the arena)
@@ -1819,6 +1993,15 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
         fl += 2.0 * nb * o.h * o.w * (double)D.d.cout * D.d.cin;
         by = in_b + (double)nb * o.h * o.w * din.c * 2 + out_b + (double)L.d.cout * (L.d.cin + D.d.cin) * 2;
         snprintf(nm, sizeof nm, "%s+%s", L.d.name, D.d.name);
+      }
+      if (L.bn_head >= 0 && m->layers[L.bn_head].bneck_now_h[0]) by = fl = 0;   // computed by the whole-bottleneck kernel
+      if (L.bn_c2 >= 0 && L.bneck_now_h[0]) {   // ... launched in this conv's place: x in (+ once more as the shortcut), out
+        const Layer& L2 = m->layers[L.bn_c2];
+        const Layer& L3 = m->layers[L.bn_c3];
+        const double px = (double)nb * in.h * in.w;
+        fl = 2.0 * px * ((double)L.d.cin * L.d.cout + 9.0 * L2.d.cin * L2.d.cout + (double)L3.d.cin * L3.d.cout);
+        by = 3.0 * in_b + ((double)L.d.cin * L.d.cout + 9.0 * L2.d.cin * L2.d.cout + (double)L3.d.cin * L3.d.cout) * 2;
+        snprintf(nm, sizeof nm, "%.40s+conv2+conv3 (one kernel)", L.d.name);
       }
       if (L.chained_by >= 0 && m->layers[L.chained_by].chained_now_h[0]) by = fl = 0;   // computed by the block-closing conv's launch
       if (L.chain_next >= 0 && L.chained_now_h[0]) {   // ... which also read that conv's weights and wrote its output

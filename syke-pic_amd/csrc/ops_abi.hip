@@ -374,7 +374,8 @@ extern "C" int spk_op_conv3x3_num_configs(void) { return spk_c3_num_configs(); }
 // receives the mean time of one block (events on `stream`).
 extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2, const float* w3, const float* s1,
                                  const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, void* y,
-                                 int n, int h, int wd, int cm, int fused, int iters, float* ms_out, void* stream) {
+                                 int n, int h, int wd, int cm, int fused, int iters, float* ms_out, void* stream,
+                                 unsigned long long* stamps_dev) {
   if (!x || !w1 || !w2 || !w3 || !s1 || !b1 || !s2 || !b2 || !s3 || !b3 || !y || n < 1 || h < 1 || wd < 1 || x == y)
     return ofail(SPK_ERR_ARG, "op_bottleneck: bad arguments");
   if (cm % 64) return ofail(SPK_ERR_UNSUPPORTED, "mid channels must be a multiple of 64");
@@ -396,6 +397,7 @@ extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2
   a.x = (const bf16_t*)x; a.y = (bf16_t*)y; a.w1 = p1; a.w2 = p2; a.w3 = p3;
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
   a.N = n; a.H = h; a.W = wd; a.C4 = c4; a.CM = cm; a.x_bytes = (unsigned)((size_t)M * c4 * 2);
+  a.stamps = stamps_dev;
   auto pw = [&](const bf16_t* in, const bf16_t* wp, bf16_t* out, const bf16_t* res, const float* sc_, const float* sh_, int cin,
                 int cout) {
     PwConvArgs q;

@@ -237,6 +237,8 @@ struct BneckArgs {
   const float *s1, *b1, *s2, *b2, *s3, *b3;   // folded eval-BatchNorm scale / shift of the three convs
   int N, H, W, C4, CM;
   unsigned int x_bytes; // N*H*W*C4*2
+  int flags;            // experiments (SPK_BNECK_FLAGS): 1 no static wave priority in phase 3
+  unsigned long long* stamps;   // diagnostics (tools/bneck_bench.py): [block][8] s_memtime values at the phase boundaries, or null
 };
 int spk_bneck_launch(const BneckArgs& a, hipStream_t s);   // -3: no kernel for this shape
 

@@ -255,7 +255,7 @@ def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0, res=Non
     return y.permute(0, 3, 1, 2)
 
 
-def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0):
+def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0, stamps=None):
     """Eval-path identity bottleneck block (spk_op_bottleneck): x [N,4cm,H,W] float16, w1 [cm,4cm,1,1], w2 [cm,cm,3,3],
     w3 [4cm,cm,1,1], bn* = (scale, shift) of the folded eval BatchNorms.  fused: the one-kernel form (csrc/conv_bneck.hip),
     else the eval path's three launches.  Returns y [N,4cm,H,W] (and the mean milliseconds per block when iters > 0)."""
@@ -273,7 +273,8 @@ def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0):
     ms = C.c_float(0.0)
     with torch.cuda.device(dev):
         lib.check(so.spk_op_bottleneck(_p(xh), _p(k1), _p(k2), _p(k3), *[_p(v) for v in vecs], _p(y), n, h, w, cm,
-                                       int(bool(fused)), int(iters), C.cast(C.pointer(ms), C.c_void_p), _stream(dev)))
+                                       int(bool(fused)), int(iters), C.cast(C.pointer(ms), C.c_void_p), _stream(dev),
+                                       _p(stamps) if stamps is not None else None))
     out = y.permute(0, 3, 1, 2)
     return (out, float(ms.value)) if iters > 0 else out
 

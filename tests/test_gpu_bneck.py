@@ -17,6 +17,8 @@ SHAPES = [
     (3, 14, 256),      # ResNet-50 stage 3 (a block owns a whole image)
     (1, 14, 256),
     (9, 14, 256),      # more blocks than one XCD's share of a small grid
+    (3, 28, 128),      # stage 2: two bands per image, one halo row each side (top band: none above, bottom band: none below)
+    (1, 28, 128),
 ]
 
 
