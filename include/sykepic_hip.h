@@ -335,7 +335,11 @@ int spk_op_conv3x3_num_configs(void);
 int spk_op_bottleneck(const void* x_dev, const float* w1_dev, const float* w2_dev, const float* w3_dev, const float* s1_dev,
                       const float* b1_dev, const float* s2_dev, const float* b2_dev, const float* s3_dev, const float* b3_dev,
                       void* y_dev, int n, int h, int w, int cm, int fused, int iters, float* ms_out, void* stream,
-                      unsigned long long* stamps_dev /* diagnostics: [blocks][8] shader-clock stamps of the fused kernel, or null */);
+                      unsigned long long* stamps_dev /* diagnostics: [blocks][8] shader-clock stamps of the fused kernel, or null */,
+                      /* optional: the 1x1 conv + BatchNorm + ReLU that reads the block's output (the next block's conv1):
+                       * wz [coutz][4 cm] fp32, z [n,h,w,coutz] fp16.  fused == 2: conv1 on its own, then conv2 + conv3 + shortcut
+                       * (+ that conv) as one kernel (conv_btail_kernel) */
+                      const float* wz_dev, const float* sz_dev, const float* bz_dev, void* z_dev, int coutz);
 /* Two chained 1x1 convs in ONE launch (round 4, csrc/conv_pw.hip): y = act(BN(W . x) + res) with cout = 256, then
  * z = actz(BNz(Wz . y)) computed from the output tile while it is still in registers - what the eval path runs for a
  * bottleneck's block-closing conv and the next block's first conv in the single-weight-image modes (the trunk y is

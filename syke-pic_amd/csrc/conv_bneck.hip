@@ -130,6 +130,10 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   auto stamp = [&](int i) {
     if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
   };
+  if ((a.flags & 2) && (lin & 1)) {   // experiment: every other block starts ~40 us late (are the phases HBM-bound in lockstep?)
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < 80000ull) __builtin_amdgcn_s_sleep(32);
+  }
   stamp(0);
 
   // weight fragments of this wave's 64 couts: [K step][pair][tile][lane][8] images, pairs 2 wn and 2 wn + 1
@@ -425,6 +429,312 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The TAIL of an identity bottleneck block as one kernel, for the stage whose trunk is too wide to fuse the whole block
+// (ResNet-50 stage 1, 56 x 56 x 256: a whole-block kernel would read x twice - conv1's operand and, a phase later, the
+// shortcut - and move MORE bytes than the launches it replaces):
+//     out = ReLU(BN3(W3 . ReLU(BN2(W2 * y1))) + x)            y1 = the block's conv1 output, already in memory
+//     z   = ReLU(BNz(Wz . out))   (NPZ > 0)                   the NEXT block's conv1, from the output tile in registers
+// i.e. conv2 3x3 + conv3 1x1 + shortcut (+ the chained conv of conv_pw.hip's NPZ flavour).  The 3x3 conv's output and its
+// re-read never exist; per block the kernel moves y1 (with one halo row each side), x, out and z.  Phases 2 and 3 of the
+// kernel above on a band of R rows: the band's y1 rows go straight into the LDS window, W2 / W3 / Wz stream from L2 in
+// fragment order.  With CM = 64 every wave owns ALL 64 mid couts and, over the 8 half passes of phase 3, all 256 trunk
+// couts of its position tiles: the packed output registers of half pass hp are the MFMA B fragments of K step hp of
+// the chained conv (conv_pw.hip), accumulated across the half passes.  Same K orders and epilogues as conv_c3.hip /
+// conv_pw.hip: out and z are bit-identical to the launches they replace.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CM_, int HW_, int R_, int NPZ_>
+struct BtCfg {
+  static constexpr int CM = CM_, HW = HW_, R = R_, NPZ = NPZ_;
+  static constexpr int C4 = 4 * CM, COZ = 32 * NPZ;
+  static constexpr int WN = CM / 64, WM = 8 / WN;
+  static constexpr int WP = HW + 1, NROW = R + 2;
+  static constexpr int P2 = R * WP;
+  static constexpr int NT2 = (P2 + 15) / 16;
+  static constexpr int MTW = (NT2 + WM - 1) / WM;
+  static constexpr int NVA = cmax(NROW * WP + 1, WM * MTW * 16 + 2 * WP + 2);
+  static constexpr int PLANE = (NVA * 16 + 255) & ~255;
+  static constexpr int WIN = (CM / 8) * PLANE;
+  static constexpr int TAB = (2 * CM + 2 * C4 + 2 * COZ) * 4;   // [s2 | b2 | s3 | b3 | sz | bz]
+  static constexpr int LDS = WIN + TAB;
+  static constexpr int UL = (NROW * HW * (CM / 8) + 511) / 512;  // 16-byte units of the y1 band per thread
+  static constexpr int DEPTH = 4;
+  static_assert(NPZ == 0 || WN == 1, "the chained conv needs every trunk cout of a position in one wave");
+  static_assert(HW % R == 0, "bands tile the image");
+  static_assert(LDS <= 160 * 1024, "LDS");
+};
+
+// (<= 128 registers where the chained conv is narrow: two blocks per CU - 52 KB of LDS each - whose phases overlap; these
+// layers wait for HBM, and one block alone runs load -> conv2 -> conv3 strictly one after the other)
+template <int CM, int HW, int R, int NPZ>
+__global__ __launch_bounds__(512, NPZ <= 2 ? 4 : 2) void conv_btail_kernel(BneckArgs a) {
+  using K = BtCfg<CM, HW, R, NPZ>;
+  constexpr int C4 = K::C4, COZ = K::COZ, WN = K::WN, WP = K::WP, MTW = K::MTW, PLANE = K::PLANE, DEPTH = K::DEPTH;
+  constexpr int UL = K::UL, NPL = CM / 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, p = lane & 15;
+  const int wn = wave % WN, wm = wave / WN;
+
+  constexpr int BPI = HW / R;
+  const int nblk = a.N * BPI;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
+  const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + ((int)blockIdx.x >> 3);
+  const int img = lin / BPI, band = lin - img * BPI;
+  const int r0 = band * R;
+  const int rlo = r0 > 0 ? r0 - 1 : 0, rhi = r0 + R + 1 < HW ? r0 + R + 1 : HW;
+  const int P1 = (rhi - rlo) * HW;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.y1, 0, a.x_bytes / 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(NPZ ? a.z : a.y), 0, NPZ ? a.z_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 9 * CM * CM * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, CM * C4 * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rwz = __builtin_amdgcn_make_buffer_rsrc((void*)(NPZ ? a.wz : a.w3), 0, NPZ ? COZ * C4 * 2 : 0, 0x00020000);
+
+  unsigned char* const win = smem;                  // the y1 window, then y2
+  float* const tab = (float*)(smem + K::WIN);       // [s2 | b2 | s3 | b3 | sz | bz]
+  for (int c = tid; c < CM; c += 512) { tab[c] = a.s2[c]; tab[CM + c] = a.b2[c]; }
+  for (int c = tid; c < C4; c += 512) { tab[2 * CM + c] = a.s3[c]; tab[2 * CM + C4 + c] = a.b3[c]; }
+  if (NPZ)
+    for (int c = tid; c < COZ; c += 512) { tab[2 * CM + 2 * C4 + c] = a.sz[c]; tab[2 * CM + 2 * C4 + COZ + c] = a.bz[c]; }
+
+  // ---- the band's y1 rows -> window planes (a position's CM channels are 16 CM / 8 contiguous bytes: NPL neighbouring
+  // threads read them as one run), zeros wherever the window has no image pixel ----
+  {
+    u32x4_t st[UL];
+    unsigned dst[UL];
+#pragma unroll
+    for (int i = 0; i < UL; ++i) {
+      const int u = tid + 512 * i;
+      const int pos = u / NPL, pl = u - pos * NPL;
+      const int pr = pos / HW, pc = pos - pr * HW;
+      const bool ok = pos < P1;
+      st[i] = __builtin_amdgcn_raw_buffer_load_b128(
+          ry1, ok ? (unsigned)((img * HW + rlo + pr) * HW + pc) * (unsigned)(CM * 2) + (unsigned)pl * 16 : 0x80000000u, 0, 0);
+      dst[i] = ok ? (unsigned)(pl * PLANE + ((rlo + pr - (r0 - 1)) * WP + pc + 1) * 16) : 0xffffffffu;
+    }
+    for (int u = tid; u < NPL * K::NVA; u += 512) {
+      const int pl = u / K::NVA, v = u - pl * K::NVA;
+      const int wr = v / WP, wc = v - wr * WP;
+      const int ir = r0 - 1 + wr;
+      if (!(wc >= 1 && ir >= 0 && ir < HW && wr < K::NROW)) *(u32x4_t*)(win + pl * PLANE + v * 16) = u32x4_t{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < UL; ++i)
+      if (dst[i] != 0xffffffffu) *(u32x4_t*)(win + dst[i]) = st[i];
+    __syncthreads();
+  }
+
+  const unsigned w_lane = (unsigned)(2 * wn) * 2048 + lane * 16;
+  const unsigned plane_lane = (unsigned)(g * PLANE + (wm * MTW * 16 + p) * 16);
+
+  // ---- phase 2: y2 = ReLU(BN2(W2 * y1)), K order chunk -> tap -> half (conv_c3.hip's) ----
+  {
+    constexpr int PW = 3;
+    constexpr int KSTEPS = (CM / 64) * 18;
+    u32x4_t wq[PW][4];
+    auto load_w = [&](u32x4_t (&d)[4], int step) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) d[t] = __builtin_amdgcn_raw_buffer_load_b128(rw2, w_lane + t * 1024, step * (CM * 64), 0);
+    };
+    f32x4_t acc[MTW][4];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < PW; ++s) load_w(wq[s], s);
+    for (int c = 0; c < CM / 64; ++c) {
+      lds_u8_t cb = (lds_u8_t)win + plane_lane + c * 8 * PLANE;
+      asm volatile("" : "+v"(cb));
+      constexpr int UNITS = 18 * MTW;
+      auto addr = [&](int u) {
+        const int q = u / MTW, j = u % MTW, tap = q >> 1, kk = q & 1;
+        return cb + kk * 4 * PLANE + (j * 16 + (tap / 3) * WP + (tap % 3)) * 16;
+      };
+      u32x4_t fr[DEPTH];
+#pragma unroll
+      for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)addr(u);
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + DEPTH - 1 < UNITS) fr[(u + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)addr(u + DEPTH - 1);
+        const int q = u / MTW, j = u % MTW;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(wq[q % PW][t], fr[u % DEPTH], acc[j][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == MTW - 1) {
+          const int step = c * 18 + q + PW;
+          load_w(wq[q % PW], step < KSTEPS ? step : KSTEPS - 1);
+        }
+      }
+    }
+    __syncthreads();   // everyone has read its last y1 fragment: y2 takes the window's place
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+#pragma unroll
+      for (int P = 0; P < 2; ++P) {
+        lds_f32x4_t sp = (lds_f32x4_t)(tab + 64 * wn + 32 * P + 8 * g);
+        asm volatile("" : "+v"(sp));
+        const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[CM / 4], sh1 = sp[CM / 4 + 1];
+        u32x4_t ov;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ov[i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P][2 * i], sc0[2 * i], sh0[2 * i]), 0.f, 65504.f),
+                         __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P][2 * i + 1], sc0[2 * i + 1], sh0[2 * i + 1]), 0.f, 65504.f));
+          ov[2 + i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P + 1][2 * i], sc1[2 * i], sh1[2 * i]), 0.f, 65504.f),
+                             __builtin_amdgcn_fmed3f(__builtin_fmaf(acc[j][2 * P + 1][2 * i + 1], sc1[2 * i + 1], sh1[2 * i + 1]), 0.f, 65504.f));
+        }
+        *(u32x4_t*)(win + plane_lane + (8 * wn + 4 * P) * PLANE + j * 256) = ov;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- phase 3: out = ReLU(BN3(W3 . y2) + x) in 8 half passes of 32 couts (+ the chained conv's K step per half pass) ----
+  {
+    constexpr int KS3 = CM / 32;
+    constexpr int NTZ = NPZ ? 2 * NPZ : 1;      // 16-cout tiles of the chained conv
+    unsigned yoff[MTW], zoff[NPZ ? MTW : 1];
+#pragma unroll
+    for (int j = 0; j < MTW; ++j) {
+      const int q = 16 * (wm * MTW + j) + p;
+      const int orow = q / WP, ocol = q - orow * WP;
+      const bool ok = orow < R && ocol < HW;
+      const unsigned pix = (unsigned)((img * HW + r0 + orow) * HW + ocol);
+      yoff[j] = ok ? pix * (unsigned)(C4 * 2) + (unsigned)(64 * wn + 8 * g) * 2 : 0x80000000u;
+      if (NPZ) zoff[j] = ok ? pix * (unsigned)(COZ * 2) + (unsigned)(8 * g) * 2 : 0x80000000u;
+    }
+    if (wave >= 4 && !(a.flags & 1)) __builtin_amdgcn_s_setprio(1);
+    u32x4_t wq[KS3][2];
+    u32x4_t rq[2][MTW];
+    u32x4_t wz[NTZ];
+    f32x4_t az[NPZ ? MTW : 1][NTZ];
+#pragma unroll
+    for (int j = 0; j < (NPZ ? MTW : 1); ++j)
+#pragma unroll
+      for (int t = 0; t < NTZ; ++t) az[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto col = [&](int hp) { return (hp >> 1) * 64 * WN + 32 * (hp & 1); };
+    auto load_w = [&](int hp) {
+#pragma unroll
+      for (int ks = 0; ks < KS3; ++ks)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          wq[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(rw3, w_lane + t * 1024, (ks * (C4 / 32) + (hp >> 1) * 2 * WN + (hp & 1)) * 2048, 0);
+    };
+    auto load_z = [&](int hp) {   // K step hp of the chained conv: every cout tile
+      if (NPZ) {
+#pragma unroll
+        for (int t = 0; t < NTZ; ++t) wz[t] = __builtin_amdgcn_raw_buffer_load_b128(rwz, lane * 16 + t * 1024, hp * (NPZ * 2048), 0);
+      }
+    };
+    auto load_r = [&](u32x4_t (&d)[MTW], int hp) {
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j], col(hp) * 2, 0);
+    };
+    load_w(0);
+    load_z(0);
+    load_r(rq[0], 0);
+    lds_u8_t sb0 = (lds_u8_t)win + plane_lane, sb1 = sb0 + (KS3 > 4 ? 16 * PLANE : 0);
+    asm volatile("" : "+v"(sb0), "+v"(sb1));
+    auto half_pass = [&](int hp, const u32x4_t (&rcur)[MTW], u32x4_t (&rnext)[MTW]) {
+      f32x4_t acc[MTW][2];
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) acc[j][0] = acc[j][1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      constexpr int UNITS = KS3 * MTW;
+      auto addr = [&](int u) {
+        const int ks = u / MTW, j = u % MTW;
+        return (ks < 4 ? sb0 + ks * 4 * PLANE : sb1 + (ks - 4) * 4 * PLANE) + j * 256;
+      };
+      u32x4_t fr[DEPTH];
+#pragma unroll
+      for (int u = 0; u < DEPTH - 1 && u < UNITS; ++u) fr[u] = *(lds_u32x4_t)addr(u);
+#pragma unroll
+      for (int u = 0; u < UNITS; ++u) {
+        if (u + DEPTH - 1 < UNITS) fr[(u + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)addr(u + DEPTH - 1);
+        const int ks = u / MTW, j = u % MTW;
+        __builtin_amdgcn_sched_barrier(0);
+        acc[j][0] = mfma16<DT_F16>(wq[ks][0], fr[u % DEPTH], acc[j][0]);
+        acc[j][1] = mfma16<DT_F16>(wq[ks][1], fr[u % DEPTH], acc[j][1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (hp + 1 < 8) {
+        load_w(hp + 1);
+        load_r(rnext, hp + 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const int co = col(hp);
+      lds_f32x4_t sp = (lds_f32x4_t)(tab + 2 * CM + co + 64 * wn + 8 * g);
+      asm volatile("" : "+v"(sp));
+      const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[C4 / 4], sh1 = sp[C4 / 4 + 1];
+      u32x4_t ovs[MTW];
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = __builtin_fmaf(acc[j][0][r], sc0[r], sh0[r]);
+          v[4 + r] = __builtin_fmaf(acc[j][1][r], sc1[r], sh1[r]);
+        }
+        const u32x4_t q = rcur[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[2 * i] += lo_f32<DT_F16>(q[i]);
+          v[2 * i + 1] += hi_f32<DT_F16>(q[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          ovs[j][i] = pack2h(__builtin_amdgcn_fmed3f(v[2 * i], 0.f, 65504.f), __builtin_amdgcn_fmed3f(v[2 * i + 1], 0.f, 65504.f));
+        if (NPZ) {   // the values about to be stored ARE K step hp of the chained conv for this position tile
+#pragma unroll
+          for (int t = 0; t < NTZ; ++t) az[j][t] = mfma16<DT_F16>(wz[t], ovs[j], az[j][t]);
+        }
+      }
+      if (hp + 1 < 8) load_z(hp + 1);   // (into the registers the MFMAs above have read: lands under the next K loop)
+      // The stores LAST: vmcnt retires in issue order, so every load this wave waits for in the next half pass (weights,
+      // shortcut values, the chained conv's fragments) must be older than them - a load behind a store sits through the
+      // store's HBM write latency, once per half pass.
+#pragma unroll
+      for (int j = 0; j < MTW; ++j) __builtin_amdgcn_raw_buffer_store_b128(ovs[j], ry, yoff[j] + (unsigned)(co * 2), 0, 0);
+    };
+    for (int hp = 0; hp < 8; hp += 2) {
+      half_pass(hp, rq[0], rq[1]);
+      half_pass(hp + 1, rq[1], rq[0]);
+    }
+    if (NPZ) {
+#pragma unroll
+      for (int j = 0; j < MTW; ++j)
+#pragma unroll
+        for (int Pz = 0; Pz < NPZ; ++Pz) {
+          lds_f32x4_t sp = (lds_f32x4_t)(tab + 2 * CM + 2 * C4 + 32 * Pz + 8 * g);
+          asm volatile("" : "+v"(sp));
+          const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[COZ / 4], sh1 = sp[COZ / 4 + 1];
+          u32x4_t ov;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            ov[i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(az[j][2 * Pz][2 * i], sc0[2 * i], sh0[2 * i]), 0.f, 65504.f),
+                           __builtin_amdgcn_fmed3f(__builtin_fmaf(az[j][2 * Pz][2 * i + 1], sc0[2 * i + 1], sh0[2 * i + 1]), 0.f, 65504.f));
+            ov[2 + i] = pack2h(__builtin_amdgcn_fmed3f(__builtin_fmaf(az[j][2 * Pz + 1][2 * i], sc1[2 * i], sh1[2 * i]), 0.f, 65504.f),
+                               __builtin_amdgcn_fmed3f(__builtin_fmaf(az[j][2 * Pz + 1][2 * i + 1], sc1[2 * i + 1], sh1[2 * i + 1]), 0.f, 65504.f));
+          }
+          __builtin_amdgcn_raw_buffer_store_b128(ov, rz, zoff[NPZ ? j : 0] + Pz * 64, 0, 0);
+        }
+    }
+  }
+}
+
+template <int CM, int HW, int R, int NPZ>
+int launch_btail(const BneckArgs& a, hipStream_t s) {
+  using K = BtCfg<CM, HW, R, NPZ>;
+  static std::atomic<unsigned long long> attr;
+  if (!spk_lds_limit_once(attr, (const void*)&conv_btail_kernel<CM, HW, R, NPZ>, 160 * 1024)) return -1;
+  hipLaunchKernelGGL((conv_btail_kernel<CM, HW, R, NPZ>), dim3(a.N * (HW / R)), dim3(512), K::LDS, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 template <int CM, int HW, int R>
 int launch_bneck(const BneckArgs& a, hipStream_t s) {
   using K = BnCfg<CM, HW, R>;
@@ -435,6 +745,21 @@ int launch_bneck(const BneckArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+// conv2 + conv3 + shortcut (+ the chained conv a.wz) from the block's conv1 output a.y1; -3: no kernel for this shape
+int spk_btail_launch(const BneckArgs& a0, hipStream_t s) {
+  static const int env_flags = getenv("SPK_BNECK_FLAGS") ? atoi(getenv("SPK_BNECK_FLAGS")) : 0;
+  BneckArgs a = a0;
+  a.flags |= env_flags;
+  if (a.N <= 0 || a.H != a.W || a.C4 != 4 * a.CM || !a.y1) return -3;
+  if ((size_t)a.N * a.H * a.W * a.C4 * 2 >= 0x80000000ull) return -3;
+  if (a.CM == 64 && a.H == 56) {
+    if (!a.wz) return launch_btail<64, 56, 4, 0>(a, s);
+    if (a.Coutz == 64) return launch_btail<64, 56, 4, 2>(a, s);
+    if (a.Coutz == 128) return launch_btail<64, 56, 4, 4>(a, s);
+  }
+  return -3;
+}
 
 // 0 ok, -1 HIP error, -3 no kernel for this shape (the caller runs the three convs one by one)
 int spk_bneck_launch(const BneckArgs& a0, hipStream_t s) {

@@ -58,6 +58,7 @@ struct Layer {
   int bn_c2 = -1, bn_c3 = -1;     // the block's conv1: indices of its conv2 / conv3, or -1
   int bn_head = -1;               // conv2 / conv3 of such a block: index of its conv1
   bool bneck_now_h[2] = {false, false};   // conv1: the one-kernel form ran for this half-batch chain of the current forward
+  bool btail_now_h[2] = {false, false};   // conv2: its launch also computed conv3 + shortcut (+ the chained conv): conv_btail_kernel
   size_t mu_off = 0;              // generic convs: offset of this layer's cin input-channel means in spk_model::act_mean
   // fp16 eval of an MBConv block: the squeeze-excitation layer computes its gates only and the project 1x1 conv that is
   // the sole reader of its output multiplies them into its activation operand (conv_igemm.hip, spk_set_gate)
@@ -104,6 +105,8 @@ struct spk_model {
   bool no_chain_now = false;   // the chain tuner is timing the two-kernel alternative
   int bneck = 1;               // whole-bottleneck kernel: 1 where it is faster (timed once per problem), SPK_BNECK=0 never, 2 always
   bool no_bneck_now = false;   // its tuner is timing the three-launch alternative
+  int btail = 0;               // conv2 + conv3 (+ chained conv) kernel on the stage the whole-block kernel does not take: off - it is
+                               // bit-identical but no faster than the launches it replaces; SPK_BTAIL=1
   std::vector<char> stale;     // per tensor: the last eval forward did not write it (a fused-away shortcut tensor)
   bool effnet = false;         // EfficientNet graph (widths that are not multiples of 64, depthwise / SE / SiLU ops): its
                                // TRAINING plan pads every activation tensor to a multiple of 64 channels (train_effnet.hip)

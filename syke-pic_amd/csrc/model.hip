@@ -258,6 +258,7 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
     L2.bn_head = L3.bn_head = i1;
   }
   if (const char* e = getenv("SPK_BNECK")) m->bneck = atoi(e);
+  if (const char* e = getenv("SPK_BTAIL")) m->btail = atoi(e);
   // packed bf16 weights + folded BN scale/bias
   size_t wpack = 0, sb = 0, dwp = 0;
   for (Layer& L : m->layers) {
@@ -978,6 +979,20 @@ static bool bneck_possible(const spk_model* m, const Layer& L) {
   return bneck_shape_ok(in.h, in.w, L.d.cout) && in.c == L.d.cin;
 }
 
+static bool chain_possible(const spk_model* m, const Layer& L);
+// eval: may conv2 (L) of an identity bottleneck also compute the block's conv3 + shortcut (conv_btail_kernel: the stage whose
+// trunk is too wide for the whole-block kernel)?
+static bool btail_possible(const spk_model* m, const Layer& L) {
+  if (!m->btail || m->no_bneck_now || L.bn_head < 0 || L.d.k != 3 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused)
+    return false;
+  const Layer& H = m->layers[L.bn_head];
+  const Layer& L3 = m->layers[H.bn_c3];
+  if (layer_split(m, L) || layer_split(m, L3) || L3.dual_src >= 0) return false;
+  if (H.bneck_now_h[m->half]) return false;
+  const TDim& in = m->tdims[L.d.src];
+  return in.h == in.w && in.h == 56 && L.d.cout == 64 && in.c == 64;
+}
+
 // eval: may the block-closing conv L also compute the conv that reads its output (single fp16 weight images only)?
 static bool chain_possible(const spk_model* m, const Layer& L) {
   if (!m->chain || m->no_chain_now || L.chain_next < 0 || m->infer_dt != DT_F16 || m->precise_res || m->force_unfused)
@@ -1191,6 +1206,49 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
     if (L.d.k == 3) m->stale[L.d.dst] = 3;   // y2 was not written (read_activation recomputes it); conv3's output was
     else m->stale[L.d.dst] = 0;
     return SPK_OK;
+  }
+  // conv3 of a bottleneck whose conv2 launch computed it too (conv_btail_kernel)
+  if (L.bn_head >= 0 && L.d.k == 1 && !m->no_bneck_now && m->layers[m->layers[L.bn_head].bn_c2].btail_now_h[m->half]) {
+    m->stale[L.d.dst] = 0;
+    return SPK_OK;
+  }
+  if (L.bn_head >= 0 && L.d.k == 3 && !m->no_bneck_now) L.btail_now_h[m->half] = false;
+  if (L.bn_head >= 0 && L.d.k == 3 && btail_possible(m, L)) {
+    Layer& H = m->layers[L.bn_head];
+    Layer& L3 = m->layers[H.bn_c3];
+    BneckArgs ba;
+    memset(&ba, 0, sizeof ba);
+    ba.x = (const bf16_t*)m->TI(L3.d.res);
+    ba.y1 = (const bf16_t*)m->TI(L.d.src);
+    ba.y = (bf16_t*)m->TI(L3.d.dst);
+    ba.w2 = m->wpack + L.wpw_off; ba.w3 = m->wpack + L3.wpw_off;
+    ba.s2 = m->scale_bias + L.sb_off; ba.b2 = ba.s2 + L.cout_p;
+    ba.s3 = m->scale_bias + L3.sb_off; ba.b3 = ba.s3 + L3.cout_p;
+    ba.N = nb; ba.H = in.h; ba.W = in.w; ba.C4 = L3.d.cout; ba.CM = L.d.cout;
+    ba.x_bytes = (unsigned)((size_t)nb * in.h * in.w * L3.d.cout * 2);
+    bool chained = false;
+    if (chain_possible(m, L3)) {   // the next block's first conv from the output tile in registers, as conv_pw.hip's chained flavour
+      PwConvArgs qc;
+      memset(&qc, 0, sizeof qc);
+      if (chain_args(m, L3, qc, nb)) {
+        ba.wz = qc.wpz; ba.z = qc.z; ba.sz = qc.scalez; ba.bz = qc.shiftz; ba.Coutz = qc.Coutz; ba.z_bytes = qc.z_bytes;
+        chained = qc.reluz == 1;
+        if (!chained) ba.wz = nullptr;
+      }
+    }
+    int r = spk_btail_launch(ba, m->stream);
+    if (r == -3 && chained) {      // (no instantiation with this chained width: without it)
+      ba.wz = nullptr;
+      chained = false;
+      r = spk_btail_launch(ba, m->stream);
+    }
+    if (r == 0) {
+      L.btail_now_h[m->half] = true;
+      L3.chained_now_h[m->half] = chained;
+      m->stale[L.d.dst] = 3;       // y2 was not written
+      return SPK_OK;
+    }
+    (void)hipGetLastError();
   }
   if (L.bn_c2 >= 0 && !m->no_bneck_now) L.bneck_now_h[m->half] = false;
   if (bneck_possible(m, L) && !(L.chained_by >= 0 && m->layers[L.chained_by].chained_now_h[m->half])) {
@@ -1995,6 +2053,22 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
         snprintf(nm, sizeof nm, "%s+%s", L.d.name, D.d.name);
       }
       if (L.bn_head >= 0 && m->layers[L.bn_head].bneck_now_h[0]) by = fl = 0;   // computed by the whole-bottleneck kernel
+      if (L.bn_head >= 0 && L.d.k == 1 && m->layers[m->layers[L.bn_head].bn_c2].btail_now_h[0]) by = fl = 0;   // by conv2's launch
+      if (L.bn_head >= 0 && L.d.k == 3 && L.btail_now_h[0]) {   // conv2 + conv3 + shortcut (+ chained conv): y1 in, x in, out (+ z)
+        const Layer& L3 = m->layers[m->layers[L.bn_head].bn_c3];
+        const double px = (double)nb * in.h * in.w;
+        fl += 2.0 * px * L3.d.cin * L3.d.cout;
+        by = in_b + 2.0 * px * L3.d.cout * 2 + (9.0 * L.d.cin * L.d.cout + (double)L3.d.cin * L3.d.cout) * 2;
+        snprintf(nm, sizeof nm, "%.40s+conv3 (one kernel)", L.d.name);
+        if (L3.chain_next >= 0 && L3.chained_now_h[0]) {
+          const Layer& Q = m->layers[L3.chain_next];
+          fl += 2.0 * px * Q.d.cin * Q.d.cout;
+          by += px * Q.d.cout * 2 + (double)Q.d.cin * Q.d.cout * 2;
+          char both[96];
+          snprintf(both, sizeof both, "%.60s>%.30s", nm, Q.d.name);
+          snprintf(nm, sizeof nm, "%s", both);
+        }
+      }
       if (L.bn_c2 >= 0 && L.bneck_now_h[0]) {   // ... launched in this conv's place: x in (+ once more as the shortcut), out
         const Layer& L2 = m->layers[L.bn_c2];
         const Layer& L3 = m->layers[L.bn_c3];
@@ -2004,7 +2078,8 @@ extern "C" int spk_model_profile_infer(spk_model* m, const void* x, int n, int h
         snprintf(nm, sizeof nm, "%.40s+conv2+conv3 (one kernel)", L.d.name);
       }
       if (L.chained_by >= 0 && m->layers[L.chained_by].chained_now_h[0]) by = fl = 0;   // computed by the block-closing conv's launch
-      if (L.chain_next >= 0 && L.chained_now_h[0]) {   // ... which also read that conv's weights and wrote its output
+      const bool by_tail = L.bn_head >= 0 && L.d.k == 1 && m->layers[m->layers[L.bn_head].bn_c2].btail_now_h[0];
+      if (L.chain_next >= 0 && L.chained_now_h[0] && !by_tail) {   // ... which also read that conv's weights and wrote its output
         const Layer& Q = m->layers[L.chain_next];
         const TDim& zo = m->tdims[Q.d.dst];
         fl += 2.0 * nb * zo.h * zo.w * (double)Q.d.cout * Q.d.cin;

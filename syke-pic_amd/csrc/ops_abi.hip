@@ -375,7 +375,8 @@ extern "C" int spk_op_conv3x3_num_configs(void) { return spk_c3_num_configs(); }
 extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2, const float* w3, const float* s1,
                                  const float* b1, const float* s2, const float* b2, const float* s3, const float* b3, void* y,
                                  int n, int h, int wd, int cm, int fused, int iters, float* ms_out, void* stream,
-                                 unsigned long long* stamps_dev) {
+                                 unsigned long long* stamps_dev, const float* wz, const float* sz, const float* bz, void* z,
+                                 int coutz) {
   if (!x || !w1 || !w2 || !w3 || !s1 || !b1 || !s2 || !b2 || !s3 || !b3 || !y || n < 1 || h < 1 || wd < 1 || x == y)
     return ofail(SPK_ERR_ARG, "op_bottleneck: bad arguments");
   if (cm % 64) return ofail(SPK_ERR_UNSUPPORTED, "mid channels must be a multiple of 64");
@@ -388,7 +389,10 @@ extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2
   bf16_t* p3 = sc.get<bf16_t>((size_t)cm * c4);
   bf16_t* y1 = sc.get<bf16_t>((size_t)M * cm);
   bf16_t* y2 = sc.get<bf16_t>((size_t)M * cm);
-  if (!p1 || !p2 || !p3 || !y1 || !y2) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  bf16_t* pz = sc.get<bf16_t>((size_t)(wz ? coutz : 1) * c4);
+  if (!p1 || !p2 || !p3 || !y1 || !y2 || !pz) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  if (wz && (!sz || !bz || !z || coutz % 32)) return ofail(SPK_ERR_ARG, "op_bottleneck: bad chained-conv arguments");
+  if (wz) O_TRY(spk_launch_pack_pw(wz, nullptr, pz, coutz, c4, DT_F16, 1, s), "pack_pw");
   O_TRY(spk_launch_pack_pw(w1, nullptr, p1, cm, c4, DT_F16, 1, s), "pack_pw");
   O_TRY(spk_launch_pack_c3(w2, p2, cm, cm, 1, s), "pack_c3");
   O_TRY(spk_launch_pack_pw(w3, nullptr, p3, c4, cm, DT_F16, 1, s), "pack_pw");
@@ -398,6 +402,8 @@ extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2
   a.s1 = s1; a.b1 = b1; a.s2 = s2; a.b2 = b2; a.s3 = s3; a.b3 = b3;
   a.N = n; a.H = h; a.W = wd; a.C4 = c4; a.CM = cm; a.x_bytes = (unsigned)((size_t)M * c4 * 2);
   a.stamps = stamps_dev;
+  a.y1 = y1;
+  if (wz) { a.wz = pz; a.z = (bf16_t*)z; a.sz = sz; a.bz = bz; a.Coutz = coutz; a.z_bytes = (unsigned)((size_t)M * coutz * 2); }
   auto pw = [&](const bf16_t* in, const bf16_t* wp, bf16_t* out, const bf16_t* res, const float* sc_, const float* sh_, int cin,
                 int cout) {
     PwConvArgs q;
@@ -412,8 +418,9 @@ extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2
     return -3;
   };
   auto once = [&]() -> int {
-    if (fused) return spk_bneck_launch(a, s);
+    if (fused == 1) return wz ? -3 : spk_bneck_launch(a, s);
     if (const int r = pw((const bf16_t*)x, p1, y1, nullptr, s1, b1, c4, cm)) return r;
+    if (fused == 2) return spk_btail_launch(a, s);     // conv2 + conv3 + shortcut (+ the chained conv) in one kernel
     C3Args q;
     memset(&q, 0, sizeof q);
     q.x = y1; q.wp = p2; q.y = y2; q.scale = s2; q.shift = b2;
@@ -424,7 +431,8 @@ extern "C" int spk_op_bottleneck(const void* x, const float* w1, const float* w2
     for (int cfg : {2, 0, 10, 8, 9, 3, 7})       // (likewise: tests/test_gpu_c3.py)
       if ((r = spk_c3_launch(q, cfg, s)) != -3) break;
     if (r) return r;
-    return pw(y2, p3, (bf16_t*)y, (const bf16_t*)x, s3, b3, cm, c4);
+    if ((r = pw(y2, p3, (bf16_t*)y, (const bf16_t*)x, s3, b3, cm, c4)) != 0 || !wz) return r;
+    return pw((const bf16_t*)y, pz, (bf16_t*)z, nullptr, sz, bz, c4, coutz);
   };
   int r = once();
   if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "no kernel for this bottleneck shape");

@@ -237,10 +237,18 @@ struct BneckArgs {
   const float *s1, *b1, *s2, *b2, *s3, *b3;   // folded eval-BatchNorm scale / shift of the three convs
   int N, H, W, C4, CM;
   unsigned int x_bytes; // N*H*W*C4*2
+  // spk_btail_launch only (conv2 + conv3 + shortcut of a block whose conv1 already ran, + optionally the next block's conv1):
+  const bf16_t* y1;     // [N,H,W,CM] fp16: the block's conv1 output
+  const bf16_t* wz;     // chained conv [Coutz][C4] packed by spk_launch_pack_pw (nb = 1), or null
+  bf16_t* z;            // [N,H,W,Coutz]
+  const float *sz, *bz; // its folded BatchNorm (ReLU behind it)
+  int Coutz;
+  unsigned int z_bytes;
   int flags;            // experiments (SPK_BNECK_FLAGS): 1 no static wave priority in phase 3
   unsigned long long* stamps;   // diagnostics (tools/bneck_bench.py): [block][8] s_memtime values at the phase boundaries, or null
 };
 int spk_bneck_launch(const BneckArgs& a, hipStream_t s);   // -3: no kernel for this shape
+int spk_btail_launch(const BneckArgs& a, hipStream_t s);   // conv2 + conv3 (+ chained conv) from y1; -3: no kernel for this shape
 
 // ---------------------------------------------------------------------------
 // Zero-sum rounding of fp16 weights + activation means (zero_sum.hip)

@@ -106,7 +106,7 @@ SYMBOLS = {
     "spk_op_conv1x1_num_configs": (C.c_int, []),
     "spk_op_conv3x3": (C.c_int, [_P, _P, _P, _P, _P, _P] + [C.c_int] * 8 + [_P]),
     "spk_op_conv3x3_num_configs": (C.c_int, []),
-    "spk_op_bottleneck": (C.c_int, [_P] * 11 + [C.c_int] * 6 + [_P, _P, _P]),
+    "spk_op_bottleneck": (C.c_int, [_P] * 11 + [C.c_int] * 6 + [_P, _P, _P] + [_P] * 4 + [C.c_int]),
     "spk_preprocess_rois": (C.c_int, [_P, C.c_int64, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "spk_predict_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_float, _P, _P, _P]),
     "spk_augment_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P]),

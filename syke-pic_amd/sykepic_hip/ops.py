@@ -255,7 +255,7 @@ def conv3x3(x, weight, bn_scale, bn_bias, relu=True, split=False, cfg=0, res=Non
     return y.permute(0, 3, 1, 2)
 
 
-def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0, stamps=None):
+def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0, stamps=None, wz=None, bnz=None):
     """Eval-path identity bottleneck block (spk_op_bottleneck): x [N,4cm,H,W] float16, w1 [cm,4cm,1,1], w2 [cm,cm,3,3],
     w3 [4cm,cm,1,1], bn* = (scale, shift) of the folded eval BatchNorms.  fused: the one-kernel form (csrc/conv_bneck.hip),
     else the eval path's three launches.  Returns y [N,4cm,H,W] (and the mean milliseconds per block when iters > 0)."""
@@ -271,11 +271,23 @@ def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, fused=True, iters=0, stamps=None):
     k3 = w3.float().reshape(c4, cm).contiguous()
     vecs = [t.float().contiguous() for pair in (bn1, bn2, bn3) for t in pair]
     ms = C.c_float(0.0)
+    # fused: False / 0 three launches, True / 1 the whole block as one kernel, 2 conv1 + (conv2 + conv3 + shortcut [+ wz]) kernel
+    kz = z = sz = bz = None
+    coutz = 0
+    if wz is not None:      # the conv + BN + ReLU that reads the block's output (the next block's conv1): z comes back too
+        coutz = wz.shape[0]
+        kz = wz.float().reshape(coutz, c4).contiguous()
+        sz, bz = (t.float().contiguous() for t in bnz)
+        z = torch.full((n, h, w, coutz), float("nan"), dtype=torch.float16, device=dev)
     with torch.cuda.device(dev):
         lib.check(so.spk_op_bottleneck(_p(xh), _p(k1), _p(k2), _p(k3), *[_p(v) for v in vecs], _p(y), n, h, w, cm,
-                                       int(bool(fused)), int(iters), C.cast(C.pointer(ms), C.c_void_p), _stream(dev),
-                                       _p(stamps) if stamps is not None else None))
+                                       int(fused), int(iters), C.cast(C.pointer(ms), C.c_void_p), _stream(dev),
+                                       _p(stamps) if stamps is not None else None,
+                                       _p(kz) if kz is not None else None, _p(sz) if sz is not None else None,
+                                       _p(bz) if bz is not None else None, _p(z) if z is not None else None, coutz))
     out = y.permute(0, 3, 1, 2)
+    if z is not None:
+        out = (out, z.permute(0, 3, 1, 2))
     return (out, float(ms.value)) if iters > 0 else out
 
 

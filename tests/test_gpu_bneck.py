@@ -60,3 +60,39 @@ def test_fused_bottleneck_equals_the_three_launches(shape):
     bound = 2e-2 + 1e-2 * ref.abs()       # (a flipped fp16 rounding of a mid value moves an output by ~ its weight)
     assert (err <= bound).all(), float(err.max())
     assert torch.equal(fused, three), (float((fused - three).abs().max()), int((fused != three).sum()))
+
+
+TAIL_SHAPES = [
+    # n, hw, cm, coutz (0: no chained conv)
+    (2, 56, 64, 0),       # ResNet-50 stage 1: bands of 4 rows, 14 per image
+    (3, 56, 64, 64),      # + the next block's conv1 (256 -> 64) from the output tile in registers
+    (1, 56, 64, 128),     # + the next STAGE's conv1 (256 -> 128)
+]
+
+
+@pytest.mark.parametrize("shape", TAIL_SHAPES, ids=lambda s: "n%d_%dx%d_cm%d_z%d" % (s[0], s[1], s[1], s[2], s[3]))
+def test_block_tail_kernel_equals_the_launches_it_replaces(shape):
+    """conv2 + conv3 + shortcut (+ the conv that reads the block's output) as ONE kernel (conv_btail_kernel) on the stage whose
+    trunk is too wide for the whole-block kernel: bit-identical to conv_c3 -> conv_pw (-> conv_pw) on the same conv1 output."""
+    from sykepic_hip import ops
+    n, hw, cm, coutz = shape
+    x, w1, w2, w3, bns = _block(n, hw, cm, seed=hw + cm + n + coutz)
+    g = torch.Generator().manual_seed(7 + coutz)
+    c4 = 4 * cm
+    wz = ((torch.rand(coutz, c4, 1, 1, generator=g) * 2 - 1) * (6.0 / c4) ** 0.5) if coutz else None
+    bnz = (0.5 + torch.rand(coutz, generator=g), torch.rand(coutz, generator=g) - 0.5) if coutz else None
+    dev = "cuda:0"
+    d = lambda t: t.to(dev)  # noqa: E731
+    dbns = [(d(a), d(b)) for a, b in bns]
+    kw = dict(wz=d(wz), bnz=(d(bnz[0]), d(bnz[1]))) if coutz else {}
+    ref = ops.bottleneck(d(x), d(w1), d(w2), d(w3), *dbns, fused=0, **kw)
+    got = ops.bottleneck(d(x), d(w1), d(w2), d(w3), *dbns, fused=2, **kw)
+    if not coutz:
+        ref, got = (ref,), (got,)
+    for name, r, t in zip(("out", "z"), ref, got):
+        r, t = r.float().cpu(), t.float().cpu()
+        assert torch.isfinite(t).all(), f"{name}: an element was never written"
+        assert torch.equal(t, r), (name, float((t - r).abs().max()), int((t != r).sum()))
+    want = _ref(x, w1, w2, w3, bns)
+    err = (got[0].float().cpu() - want).abs()
+    assert (err <= 2e-2 + 1e-2 * want.abs()).all(), float(err.max())

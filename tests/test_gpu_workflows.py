@@ -114,7 +114,8 @@ def test_prob_calibrates_a_reference_trained_directory_on_its_first_sample(tmp_p
         prob.call(Args(str(raw), None, None, None, str(model), out, 64, 2, False))
     assert any("calibrated single-pass mode from here on" in r.message for r in caplog.records)
     side = torch.load(model / prob.ACT_MEANS_FILE)
-    assert side["images"] == 256 and side["state_sha256"] == prob.state_digest(model)
+    # (whichever sample `list_sample_paths` hands over first: its first <= 256 ROIs)
+    assert side["images"] in (256, 90) and side["state_sha256"] == prob.state_digest(model)
     cfg = ConfigParser()
     cfg.read(model / "config.ini")
     _, ev = get_transforms(cfg, get_img_shape(cfg))

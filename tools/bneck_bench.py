@@ -21,12 +21,18 @@ for name, (hw, cm) in SHAPES.items():
         gflop = 2.0 * n * hw * hw * (2 * cm * c4 + 9 * cm * cm) / 1e9
         mbytes = 2.0 * n * hw * hw * c4 * 2 / 1e6
         line = f"{name} n={n} {hw}x{hw} cm={cm}: {gflop:.1f} GFLOP, {mbytes:.0f} MB in+out;"
-        for fused in (False, True):
+        for fused, what in ((0, "three launches"), (1, "one kernel"), (2, "conv1 + tail kernel")):
             try:
                 _, ms = ops.bottleneck(x, w1, w2, w3, *bns, fused=fused, iters=20)
-                line += f"  {'fused' if fused else 'three launches'} {ms * 1e3:.1f} us = {gflop / ms:.0f} TFLOP/s, {mbytes / ms:.0f} GB/s;"
+                line += f"  {what} {ms * 1e3:.1f} us = {gflop / ms:.0f} TFLOP/s, {mbytes / ms:.0f} GB/s;"
             except RuntimeError as e:
-                line += f"  {'fused' if fused else 'three launches'}: {str(e)[:60]};"
+                line += f"  {what}: {str(e)[-40:]};"
+        if hw == 56:   # with the next block's conv1 chained (256 -> 64): four launches against conv1 + one kernel
+            wz = ((torch.rand(64, c4, 1, 1, generator=g) * 2 - 1) * (6.0 / c4) ** 0.5).cuda()
+            bnz = ((0.5 + torch.rand(64, generator=g)).cuda(), (torch.rand(64, generator=g) - 0.5).cuda())
+            for fused, what in ((0, "four launches (+ next conv1)"), (2, "conv1 + tail kernel with the chained conv")):
+                _, ms = ops.bottleneck(x, w1, w2, w3, *bns, fused=fused, iters=20, wz=wz, bnz=bnz)
+                line += f"  {what} {ms * 1e3:.1f} us;"
         print(line, flush=True)
         if "STAMPS" in __import__("os").environ:
             # phase breakdown of the fused kernel from shader-clock stamps (one launch, median over the blocks)
