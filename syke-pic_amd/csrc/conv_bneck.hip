@@ -41,11 +41,11 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
-template <int CM_, int HW_, int R_>
+template <int CM_, int HW_, int R_, int NW_>
 struct BnCfg {
-  static constexpr int CM = CM_, HW = HW_, R = R_;
+  static constexpr int CM = CM_, HW = HW_, R = R_, NW = NW_;   // NW: waves per block (8: two per SIMD; 4: one, two blocks per CU)
   static constexpr int C4 = 4 * CM;
-  static constexpr int WN = CM / 64, WM = 8 / WN;       // the 8 waves: along the couts x along the positions
+  static constexpr int WN = CM / 64, WM = NW / WN;      // the waves: along the couts x along the positions
   static constexpr int WP = HW + 1;                     // window pitch
   static constexpr int NROW = R + 2;                    // window rows: one halo row above, one below
   static constexpr int P2 = R * WP;                     // output positions of a band at pitch WP (column HW is no output)
@@ -59,17 +59,25 @@ struct BnCfg {
   static constexpr int NVA = cmax(NROW * WP + 1, WM * MTW * 16 + 2 * WP + 2);
   static constexpr int PLANE = (NVA * 16 + 255) & ~255;
   static constexpr int WIN = (CM / 8) * PLANE;
-  static constexpr int DI = (WM * MT1 * 2 + 7) / 8;     // LDS-DMA instructions (8 rows x 128 B) per wave and x chunk
-  static constexpr int XSTAGE = DI * 8 * 1024;
-  static constexpr int NXS = 3 * XSTAGE <= cmax(WIN, 96 * 1024) ? 3 : 2;
-  static constexpr int TAB = 12 * CM * 4;               // BN tables: [s1 b1 | s2 b2 | s3 b3] = (2 + 2 + 8) CM floats
+  static constexpr int DI = (WM * MT1 * 2 + NW - 1) / NW;   // LDS-DMA instructions (8 rows x 128 B) per wave and x chunk
+  static constexpr int XSTAGE = DI * NW * 1024;
+  // x ring stages (the ring lives in the window's space).  Three only in the 8-wave form: with three stages the weight
+  // fragments of phase 1 are loaded by instructions the compiler does not track (buffer_load_b128_untracked), which must
+  // never be spilled - the 4-wave instantiations sit at the 256-register limit and do spill a few values
+  static constexpr int NXS = (NW == 8 && 3 * XSTAGE <= cmax(WIN, 96 * 1024)) ? 3 : 2;
   static constexpr int REGION = cmax(WIN, NXS * XSTAGE);
+  // BN tables in LDS: [s1 b1 | s2 b2 | s3 b3] = (2 + 2 + 8) CM floats - or, where a 4-wave block would then pass the 80 KB
+  // that let two blocks share a CU, conv3's only (phases 1 and 2 read theirs from memory, once per wave)
+  static constexpr bool SMALLTAB = NW == 4 && REGION + 12 * CM * 4 > 80 * 1024;
+  static constexpr int TAB = (SMALLTAB ? 8 : 12) * CM * 4;
+  static constexpr int T3 = SMALLTAB ? 0 : 4 * CM;      // float offset of s3 in the table
   static constexpr int LDS = REGION + TAB;
   static constexpr int NCH = C4 / 64;                   // x chunks
   static constexpr int DEPTH = 4;                       // activation fragments in flight (ring of registers)
   static_assert(CM == 64 || CM == 128 || CM == 256, "mid channels");
   static_assert(HW % R == 0, "bands tile the image");
-  static_assert(LDS <= 160 * 1024, "LDS");
+  static_assert(NW % WN == 0 && (NW == 4 || NW == 8), "waves");
+  static_assert(LDS <= 160 * 1024 && (NW == 8 || LDS <= 80 * 1024), "LDS");
 };
 
 // two clamped floats -> one dword of two fp16 values
@@ -91,9 +99,10 @@ __device__ __forceinline__ u32x4_t buffer_load_b128_untracked(u32x4_t rsrc, unsi
   return d;
 }
 
-template <int CM, int HW, int R>
-__global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
-  using K = BnCfg<CM, HW, R>;
+template <int CM, int HW, int R, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
+  using K = BnCfg<CM, HW, R, NW>;
+  constexpr int NT = NW * 64;
   constexpr int C4 = K::C4, WN = K::WN, WP = K::WP, MTW = K::MTW, MT1 = K::MT1, PLANE = K::PLANE, DI = K::DI;
   constexpr int NXS = K::NXS, XSTAGE = K::XSTAGE, NCH = K::NCH, DEPTH = K::DEPTH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -119,12 +128,13 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, CM * C4 * 2, 0x00020000);
 
   unsigned char* const win = smem;                       // x ring (phase 1), then the y1 window, then y2
-  float* const tab = (float*)(smem + K::REGION);         // [s1 | b1 | s2 | b2 | s3 | b3]
-  for (int c = tid; c < CM; c += 512) {
-    tab[c] = a.s1[c]; tab[CM + c] = a.b1[c];
-    tab[2 * CM + c] = a.s2[c]; tab[3 * CM + c] = a.b2[c];
-  }
-  for (int c = tid; c < C4; c += 512) { tab[4 * CM + c] = a.s3[c]; tab[4 * CM + C4 + c] = a.b3[c]; }
+  float* const tab = (float*)(smem + K::REGION);         // [s1 | b1 | s2 | b2 |] s3 | b3
+  if (!K::SMALLTAB)
+    for (int c = tid; c < CM; c += NT) {
+      tab[c] = a.s1[c]; tab[CM + c] = a.b1[c];
+      tab[2 * CM + c] = a.s2[c]; tab[3 * CM + c] = a.b2[c];
+    }
+  for (int c = tid; c < C4; c += NT) { tab[K::T3 + c] = a.s3[c]; tab[K::T3 + C4 + c] = a.b3[c]; }
 
   // diagnostics only: wave 0 leaves the shader clock at each phase boundary (a.stamps null in the product path)
   auto stamp = [&](int i) {
@@ -136,6 +146,19 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   }
   stamp(0);
 
+  // folded BatchNorm scale / shift of 8 consecutive couts from `c0` on (conv1 / conv2): from the LDS table, or - where the
+  // block keeps conv3's table only - from memory (two 16-byte loads each, once per wave and cout pair)
+  auto bn_pair = [&](const float* gs, const float* gb, int toff, int c0, f32x4_t& sc0, f32x4_t& sc1, f32x4_t& sh0, f32x4_t& sh1) {
+    if (K::SMALLTAB) {
+      sc0 = *(const f32x4_t*)(gs + c0); sc1 = *(const f32x4_t*)(gs + c0 + 4);
+      sh0 = *(const f32x4_t*)(gb + c0); sh1 = *(const f32x4_t*)(gb + c0 + 4);
+    } else {
+      lds_f32x4_t sp = (lds_f32x4_t)(tab + toff + c0);
+      asm volatile("" : "+v"(sp));
+      sc0 = sp[0]; sc1 = sp[1]; sh0 = sp[CM / 4]; sh1 = sp[CM / 4 + 1];
+    }
+  };
+
   // weight fragments of this wave's 64 couts: [K step][pair][tile][lane][8] images, pairs 2 wn and 2 wn + 1
   const unsigned w_lane = (unsigned)(2 * wn) * 2048 + lane * 16;
 
@@ -143,12 +166,12 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
   // phase 1: y1 = ReLU(BN1(W1 . x)) on the window's real positions (compact index: row-major over image rows [rlo, rhi))
   // =====================================================================================================================
   {
-    // LDS-DMA of one 64-channel chunk: instruction ii = wave + 8 i covers rows 8 ii .. 8 ii + 7; lane l lands in row
+    // LDS-DMA of one 64-channel chunk: instruction ii = wave + NW i covers rows 8 ii .. 8 ii + 7; lane l lands in row
     // l / 8, slot l % 8 and therefore fetches the chunk whose swizzled slot that is
     unsigned voff[DI];
 #pragma unroll
     for (int i = 0; i < DI; ++i) {
-      const int row = 8 * (wave + 8 * i) + (lane >> 3);
+      const int row = 8 * (wave + NW * i) + (lane >> 3);
       const int pr = row / HW, pc = row - pr * HW;
       const unsigned pix = (unsigned)((img * HW + rlo + pr) * HW + pc);
       voff[i] = row < P1 ? pix * (unsigned)(C4 * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
@@ -156,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     auto dma = [&](int c, int stage) {
 #pragma unroll
       for (int i = 0; i < DI; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(win + stage * XSTAGE + (wave + 8 * i) * 1024), 16, (unsigned)voff[i],   // (the cast: hipcc 7.2 host pass silently drops the kernel when an lvalue array element is passed here)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(win + stage * XSTAGE + (wave + NW * i) * 1024), 16, (unsigned)voff[i],   // (the cast: hipcc 7.2 host pass silently drops the kernel when an lvalue array element is passed here)
                                                  c * 128, 0, 0);
     };
     // activation fragment of position tile j, K step ks of a chunk: row 16 (wm MT1 + j) + p, chunk 4 ks + g, swizzled
@@ -165,13 +188,20 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     const unsigned xlane = (unsigned)((wm * MT1 * 16 + p) * 128 + ((g ^ ((p >> 1) & 7)) << 4));
     u32x4_t wa[2][2][4];   // [chunk parity][ks][tile of the wave's 64 couts]
     // (the descriptor by hand for the asm form: base, stride 0, bytes, raw-buffer flags - make_buffer_rsrc's words)
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, CM * C4 * 2, 0x00020000);
     const unsigned long long w1p = (unsigned long long)a.w1;
     const u32x4_t rw1s = {(unsigned)w1p, (unsigned)(w1p >> 32) & 0xffffu, (unsigned)(CM * C4 * 2), 0x00020000u};
     auto load_w = [&](u32x4_t (&d)[2][4], int c) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) d[ks][t] = buffer_load_b128_untracked(rw1s, w_lane, (unsigned)((2 * c + ks) * (CM * 64)), t * 1024);
+        for (int t = 0; t < 4; ++t) {
+          // (two ring stages: every wait is vmcnt(0) anyway - plain loads, which the compiler may also spill or copy; the
+          // untracked form must never be: its registers are not valid until the manual wait.  Check the instantiations
+          // with three stages for "VGPRs Spill: 0" when this file changes.)
+          if (NXS == 2) d[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(rw1, w_lane + t * 1024, (2 * c + ks) * (CM * 64), 0);
+          else d[ks][t] = buffer_load_b128_untracked(rw1s, w_lane, (unsigned)((2 * c + ks) * (CM * 64)), t * 1024);
+        }
     };
     f32x4_t acc[MT1][4];
 #pragma unroll
@@ -191,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       // here too: buffer_load_b128_untracked)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      load_w(wnext, c + 1 < NCH ? c + 1 : NCH - 1);
+      if (c + 1 < NCH) load_w(wnext, c + 1);   // (no dead load past the last chunk: nothing would ever wait for it - below)
       if (c + NXS - 1 < NCH) dma(c + NXS - 1, (c + NXS - 1) % NXS);
       lds_u8_t xb0 = (lds_u8_t)win + (c % NXS) * XSTAGE + xlane;
       lds_u8_t xb1 = (lds_u8_t)win + (c % NXS) * XSTAGE + (xlane ^ 64u);
@@ -217,11 +247,15 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       chunk(c, wa[0], wa[1]);
       chunk(c + 1, wa[1], wa[0]);
     }
+    // Every untracked load has been waited for by the last chunk's s_waitcnt vmcnt(0).  This matters: the compiler believes
+    // their destination registers dead from here on and re-uses them - a load still in flight would land in whatever lives
+    // there by then (seen as one wrong image in a few hundred blocks while the last chunk still issued a dead load).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp(1);
     __syncthreads();   // everyone is done with the x ring: the window takes its place
 
     // zeros wherever the window has no image pixel: the shared padding column, rows outside the image, the tail
-    for (int u = tid; u < (CM / 8) * K::NVA; u += 512) {
+    for (int u = tid; u < (CM / 8) * K::NVA; u += NT) {
       const int pl = u / K::NVA, v = u - pl * K::NVA;
       const int wr = v / WP, wc = v - wr * WP;
       const int ir = r0 - 1 + wr;
@@ -235,9 +269,8 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       const int v = (rlo + pr - (r0 - 1)) * WP + pc + 1;
 #pragma unroll
       for (int P = 0; P < 2; ++P) {
-        lds_f32x4_t sp = (lds_f32x4_t)(tab + 64 * wn + 32 * P + 8 * g);
-        asm volatile("" : "+v"(sp));
-        const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[CM / 4], sh1 = sp[CM / 4 + 1];
+        f32x4_t sc0, sc1, sh0, sh1;
+        bn_pair(a.s1, a.b1, 0, 64 * wn + 32 * P + 8 * g, sc0, sc1, sh0, sh1);
         u32x4_t ov;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -306,9 +339,8 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     for (int j = 0; j < MTW; ++j) {
 #pragma unroll
       for (int P = 0; P < 2; ++P) {
-        lds_f32x4_t sp = (lds_f32x4_t)(tab + 2 * CM + 64 * wn + 32 * P + 8 * g);
-        asm volatile("" : "+v"(sp));
-        const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[CM / 4], sh1 = sp[CM / 4 + 1];
+        f32x4_t sc0, sc1, sh0, sh1;
+        bn_pair(a.s2, a.b2, 2 * CM, 64 * wn + 32 * P + 8 * g, sc0, sc1, sh0, sh1);
         u32x4_t ov;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -346,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
     // matrix pipe) and then run their epilogues together (sharing the vector issue).  A static priority for waves 4-7 lets
     // them take the pipe first; the other half then multiplies while they are in their epilogue, and the halves stay
     // out of phase (MI355X_MICROARCH.md, "Two waves per SIMD", items 4 and 9).
-    if (wave >= 4 && !(a.flags & 1)) __builtin_amdgcn_s_setprio(1);
+    if (NW == 8 && wave >= 4 && !(a.flags & 1)) __builtin_amdgcn_s_setprio(1);
     u32x4_t wq[KS3][2];      // the half pass's weight fragments: K step x tile of the pair
     u32x4_t rq[2][MTW];      // shortcut values: this half pass's and the next one's
     auto col = [&](int hp) { return (hp >> 1) * 64 * WN + 32 * (hp & 1); };   // first cout of the half pass (this wave: + 64 wn)
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv_bneck_kernel(BneckArgs a) {
       if (hp == 0) stamp(7);
       __builtin_amdgcn_sched_barrier(0);
       const int co = col(hp);
-      lds_f32x4_t sp = (lds_f32x4_t)(tab + 4 * CM + co + 64 * wn + 8 * g);
+      lds_f32x4_t sp = (lds_f32x4_t)(tab + K::T3 + co + 64 * wn + 8 * g);
       asm volatile("" : "+v"(sp));
       const f32x4_t sc0 = sp[0], sc1 = sp[1], sh0 = sp[C4 / 4], sh1 = sp[C4 / 4 + 1];
 #pragma unroll
@@ -735,12 +767,12 @@ int launch_btail(const BneckArgs& a, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-template <int CM, int HW, int R>
+template <int CM, int HW, int R, int NW>
 int launch_bneck(const BneckArgs& a, hipStream_t s) {
-  using K = BnCfg<CM, HW, R>;
+  using K = BnCfg<CM, HW, R, NW>;
   static std::atomic<unsigned long long> attr;
-  if (!spk_lds_limit_once(attr, (const void*)&conv_bneck_kernel<CM, HW, R>, 160 * 1024)) return -1;
-  hipLaunchKernelGGL((conv_bneck_kernel<CM, HW, R>), dim3(a.N * (HW / R)), dim3(512), K::LDS, s, a);
+  if (!spk_lds_limit_once(attr, (const void*)&conv_bneck_kernel<CM, HW, R, NW>, 160 * 1024)) return -1;
+  hipLaunchKernelGGL((conv_bneck_kernel<CM, HW, R, NW>), dim3(a.N * (HW / R)), dim3(NW * 64), K::LDS, s, a);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -768,7 +800,11 @@ int spk_bneck_launch(const BneckArgs& a0, hipStream_t s) {
   a.flags |= env_flags;
   if (a.N <= 0 || a.H != a.W || a.C4 != 4 * a.CM) return -3;
   if ((size_t)a.N * a.H * a.W * a.C4 * 2 >= 0x80000000ull) return -3;
-  if (a.CM == 256 && a.H == 14) return launch_bneck<256, 14, 14>(a, s);   // ResNet-50 stage 3: a block owns an image
-  if (a.CM == 128 && a.H == 28) return launch_bneck<128, 28, 14>(a, s);   // stage 2: two bands of 14 rows per image
+  // flags & 4: the small-block form - bands of 7 rows, 4 waves, <= 80 KB of LDS: two blocks per CU, whose HBM-bound phases
+  // (1: x in, 3: shortcut in + out) then run beside each other's MFMA-bound phase 2 instead of all at once on every CU
+  if (a.CM == 256 && a.H == 14)   // ResNet-50 stage 3: a block owns an image / half an image
+    return (a.flags & 4) ? launch_bneck<256, 14, 7, 4>(a, s) : launch_bneck<256, 14, 14, 8>(a, s);
+  if (a.CM == 128 && a.H == 28)   // stage 2: two bands of 14 rows / four of 7 per image
+    return (a.flags & 4) ? launch_bneck<128, 28, 7, 4>(a, s) : launch_bneck<128, 28, 14, 8>(a, s);
   return -3;
 }

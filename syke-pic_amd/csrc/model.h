@@ -103,7 +103,9 @@ struct spk_model {
   bool fuse_se = true;         // fp16 eval: squeeze-excitation scaling inside the project conv (SPK_SE_FUSE=0: its own pass)
   int chain = 1;               // conv3 -> next conv1 chaining: 1 where it is faster (timed once per problem), SPK_CHAIN=0 never, 2 always
   bool no_chain_now = false;   // the chain tuner is timing the two-kernel alternative
-  int bneck = 1;               // whole-bottleneck kernel: 1 where it is faster (timed once per problem), SPK_BNECK=0 never, 2 always
+  int bneck = 1;               // whole-bottleneck kernel: 1 where it is faster (rule + timing: bneck_choice), SPK_BNECK=0 never, 2 always
+                               // (14-row blocks), 3 always (7-row blocks)
+  bool two_streams_now = false;   // the executor is enqueueing the two halves of a batch on two streams
   bool no_bneck_now = false;   // its tuner is timing the three-launch alternative
   int btail = 0;               // conv2 + conv3 (+ chained conv) kernel on the stage the whole-block kernel does not take: off - it is
                                // bit-identical but no faster than the launches it replaces; SPK_BTAIL=1

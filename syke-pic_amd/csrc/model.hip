@@ -278,8 +278,13 @@ extern "C" int spk_model_create(const spk_layer_desc* layers, int n_layers, int 
         L.wpw_off = wpack;
         wpack += (size_t)2 * L.d.cout * L.d.cin;
       }
+      // (128 couts: the 3x3 conv of a bottleneck block the whole-block kernel may take (conv_bneck.hip sums in this kernel's K
+      // order).  Run on its own - small batches, SPK_BNECK=0 - it must give the same bits, so it takes this kernel too and
+      // never the implicit GEMM, whose tap-major sums differ in the last place: a row of probabilities does not depend on
+      // the batch it was computed in.)
       L.c3_ok = L.mode == CONV_MODE_GENERIC && L.d.k == 3 && L.d.stride == 1 && L.d.pad == 1 && L.cin_p == L.d.cin &&
-                L.cout_p == L.d.cout && L.d.cin % 64 == 0 && L.d.cout % 256 == 0;
+                L.cout_p == L.d.cout && L.d.cin % 64 == 0 &&
+                (L.d.cout % 256 == 0 || (L.bn_head >= 0 && L.d.cout % 128 == 0));
       // (the fragment-ordered 3x3 image also feeds the whole-bottleneck kernel: conv2 of such a block keeps one even where
       // conv_c3.hip itself has no configuration for its width)
       if (L.c3_ok || (L.bn_head >= 0 && L.d.k == 3)) {
@@ -1124,13 +1129,18 @@ static void bneck_args(spk_model* m, const Layer& L, BneckArgs& a, int nb) {
   a.x_bytes = (unsigned)((size_t)nb * in.h * in.w * in.c * 2);
 }
 
+// 0: three launches, 1: blocks of 14 rows x 8 waves (one per CU), 2: blocks of 7 rows x 4 waves (two per CU)
 static int bneck_choice(spk_model* m, Layer& L, const BneckArgs& a, int nb) {
-  if (m->bneck >= 2) return 1;
-  // A grid that gives at least every other CU a block (one block per image at 14 x 14, two at 28 x 28): the one-kernel form
-  // without timing.  Inside a forward it wins from there on (ResNet-50, batch 256 as two halves of 128: 3.70 -> 3.34 ms with
-  // all eight blocks of stages 2-3 fused), while the isolated timing below - one launch sequence alone on the chip - sees
-  // a half batch's 128 blocks leave half the CUs idle and would keep the three launches (98 vs 112 us at 14 x 14).
-  if (a.N * (a.H / 14) >= 128) return 1;
+  if (m->bneck >= 2) return m->bneck == 3 ? 2 : 1;
+  const int big_blocks = a.N * (a.H / 14);
+  // Two half batches on two streams: each half's large blocks take every other CU (140 KB of LDS: one block per CU), the two
+  // launches start a few microseconds apart and their HBM-bound phases do not coincide (ResNet-50, batch 256: 3.33 ms; with
+  // the small blocks, which share CUs across the halves and run in step, 3.41).
+  if (m->two_streams_now && big_blocks >= 96) return 1;
+  // One launch alone on the chip: the small blocks when the large ones would leave CUs idle or run every CU in step
+  // (isolated, 14 x 14: 256 images 123 -> 114 us, 128 images 96 -> 67 us, 64 images 89 -> 57 us; 28 x 28: 197 -> 189, 87 -> 79,
+  // 65 -> 51 us); below a quarter of the chip the three launches are timed against them.
+  if (2 * big_blocks >= 64) return 2;
   const BneckKey key(a.H, a.CM, a.N);
   const char* path = getenv("SPK_TUNE_CACHE");
   if (path && (!*path || !strcmp(path, "off"))) path = nullptr;
@@ -1143,7 +1153,7 @@ static int bneck_choice(spk_model* m, Layer& L, const BneckArgs& a, int nb) {
           char line[256];
           int v[4];
           while (fgets(line, sizeof line, f))
-            if (sscanf(line, "bneck %d %d %d %d", &v[0], &v[1], &v[2], &v[3]) == 4 && (v[3] == 0 || v[3] == 1))
+            if (sscanf(line, "bneck %d %d %d %d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[3] >= 0 && v[3] <= 2)
               g_bneck_choice[BneckKey(v[0], v[1], v[2])] = v[3];
           fclose(f);
         }
@@ -1156,10 +1166,12 @@ static int bneck_choice(spk_model* m, Layer& L, const BneckArgs& a, int nb) {
     }
   }
   const bool tune = !getenv("SPK_AUTOTUNE") || atoi(getenv("SPK_AUTOTUNE")) != 0;
-  int choice = 1;
+  int choice = 2;
   float t_three = 0.f, t_one = 0.f;
   hipEvent_t e0, e1;
   if (tune && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    BneckArgs as = a;
+    as.flags |= 4;
     auto three = [&]() {
       m->no_bneck_now = true;
       int r = run_conv_eval(m, L, nb);
@@ -1168,7 +1180,7 @@ static int bneck_choice(spk_model* m, Layer& L, const BneckArgs& a, int nb) {
       m->no_bneck_now = false;
       return r;
     };
-    bool ok = three() == SPK_OK && spk_bneck_launch(a, m->stream) == 0;   // warm-up (and the other kernels' own tuning)
+    bool ok = three() == SPK_OK && spk_bneck_launch(as, m->stream) == 0;   // warm-up (and the other kernels' own tuning)
     if (ok) {
       (void)hipEventRecord(e0, m->stream);
       for (int r = 0; r < 3; ++r) (void)three();
@@ -1177,16 +1189,16 @@ static int bneck_choice(spk_model* m, Layer& L, const BneckArgs& a, int nb) {
     }
     if (ok) {
       (void)hipEventRecord(e0, m->stream);
-      for (int r = 0; r < 3; ++r) (void)spk_bneck_launch(a, m->stream);
+      for (int r = 0; r < 3; ++r) (void)spk_bneck_launch(as, m->stream);
       (void)hipEventRecord(e1, m->stream);
       ok = hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t_one, e0, e1) == hipSuccess;
     }
-    choice = ok && t_one < t_three ? 1 : 0;
+    choice = ok && t_one < t_three ? 2 : 0;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (getenv("SPK_TUNE_LOG"))
-      fprintf(stderr, "[spk tune bottleneck] N%d %dx%d %d->%d->%d: three kernels %.1f us, one %.1f us\n", a.N, a.H, a.W, a.C4, a.CM,
-              a.C4, t_three * 1000.f / 3.f, t_one * 1000.f / 3.f);
+      fprintf(stderr, "[spk tune bottleneck] N%d %dx%d %d->%d->%d: three kernels %.1f us, one (7-row blocks) %.1f us\n", a.N, a.H, a.W,
+              a.C4, a.CM, a.C4, t_three * 1000.f / 3.f, t_one * 1000.f / 3.f);
     std::lock_guard<std::mutex> lk(g_bneck_mu);
     g_bneck_choice[key] = choice;
     if (path)
@@ -1254,7 +1266,8 @@ static int run_conv_eval(spk_model* m, Layer& L, int nb) {
   if (bneck_possible(m, L) && !(L.chained_by >= 0 && m->layers[L.chained_by].chained_now_h[m->half])) {
     BneckArgs ba;
     bneck_args(m, L, ba, nb);
-    if (bneck_choice(m, L, ba, nb) == 1) {
+    if (const int form = bneck_choice(m, L, ba, nb)) {
+      if (form == 2) ba.flags |= 4;
       const int r = spk_bneck_launch(ba, m->stream);
       if (r == 0) {
         L.bneck_now_h[m->half] = true;
@@ -1676,6 +1689,7 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
       const bool warm = std::find(m->half_warm.begin(), m->half_warm.end(), key) != m->half_warm.end();
       if (!warm) m->half_warm.push_back(key);
       const hipStream_t str[2] = {main_s, warm ? m->half_stream : main_s};
+      m->two_streams_now = warm;
       const int cnt[2] = {n / 2, n - n / 2}, off[2] = {0, n / 2};
       HIP_TRY(hipEventRecord(m->half_fork, main_s));
       HIP_TRY(hipStreamWaitEvent(m->half_stream, m->half_fork, 0));
@@ -1706,6 +1720,7 @@ int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, in
       }
       m->img0 = 0;
       m->stream = main_s;
+      m->two_streams_now = false;
       // (join even after an error: nothing may be left running on the second stream behind the caller's back)
       (void)hipEventRecord(m->half_join, m->half_stream);
       (void)hipStreamWaitEvent(main_s, m->half_join, 0);
