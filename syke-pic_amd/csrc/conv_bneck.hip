@@ -122,8 +122,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
   const int rlo = r0 > 0 ? r0 - 1 : 0, rhi = r0 + R + 1 < HW ? r0 + R + 1 : HW;   // image rows [rlo, rhi) of the window
   const int P1 = (rhi - rlo) * HW;                                                  // its real positions
 
+  // (timing experiments, a.flags: 8 every block reads image 0 in phase 1 - x from L2; 16 no shortcut loads; 32 no stores)
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rxr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (a.flags & 16) ? 0 : a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (a.flags & 32) ? 0 : a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 9 * CM * CM * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw3 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w3, 0, CM * C4 * 2, 0x00020000);
 
@@ -138,12 +140,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
 
   // diagnostics only: wave 0 leaves the shader clock at each phase boundary (a.stamps null in the product path)
   auto stamp = [&](int i) {
-    if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memtime();
+    if (a.stamps && (tid == 0 || tid == NT / 2)) a.stamps[(size_t)blockIdx.x * 16 + (tid ? 8 : 0) + i] = __builtin_amdgcn_s_memtime();
   };
-  if ((a.flags & 2) && (lin & 1)) {   // experiment: every other block starts ~40 us late (are the phases HBM-bound in lockstep?)
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    while (__builtin_amdgcn_s_memtime() - t0 < 80000ull) __builtin_amdgcn_s_sleep(32);
-  }
   stamp(0);
 
   // folded BatchNorm scale / shift of 8 consecutive couts from `c0` on (conv1 / conv2): from the LDS table, or - where the
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
     for (int i = 0; i < DI; ++i) {
       const int row = 8 * (wave + NW * i) + (lane >> 3);
       const int pr = row / HW, pc = row - pr * HW;
-      const unsigned pix = (unsigned)((img * HW + rlo + pr) * HW + pc);
+      const unsigned pix = (unsigned)((((a.flags & 8) ? 0 : img) * HW + rlo + pr) * HW + pc);
       voff[i] = row < P1 ? pix * (unsigned)(C4 * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
     }
     auto dma = [&](int c, int stage) {
@@ -203,6 +201,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
           else d[ks][t] = buffer_load_b128_untracked(rw1s, w_lane, (unsigned)((2 * c + ks) * (CM * 64)), t * 1024);
         }
     };
+    auto load_w_ks = [&](u32x4_t (&d)[2][4], int c, int ks) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (NXS == 2) d[ks][t] = __builtin_amdgcn_raw_buffer_load_b128(rw1, w_lane + t * 1024, (2 * c + ks) * (CM * 64), 0);
+        else d[ks][t] = buffer_load_b128_untracked(rw1s, w_lane, (unsigned)((2 * c + ks) * (CM * 64)), t * 1024);
+      }
+    };
+    auto dma_piece = [&](int c, int stage, int i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(win + stage * XSTAGE + (wave + NW * i) * 1024), 16, (unsigned)voff[i],
+                                               c * 128, 0, 0);
+    };
     f32x4_t acc[MT1][4];
 #pragma unroll
     for (int j = 0; j < MT1; ++j)
@@ -221,8 +230,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
       // here too: buffer_load_b128_untracked)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < NCH) load_w(wnext, c + 1);   // (no dead load past the last chunk: nothing would ever wait for it - below)
-      if (c + NXS - 1 < NCH) dma(c + NXS - 1, (c + NXS - 1) % NXS);
+      // The next chunk's weight fragments and the DMA pieces of chunk c + NXS - 1 are issued BETWEEN the MFMA groups below, a
+      // few per group (an MFMA holds the issue port for half of its 16 cycles): issued here in one go they cost every wave
+      // ~0.5 k cycles per chunk in front of its first MFMA, in step on all waves of the CU.  Order as before - weights, then
+      // DMA pieces - which is what the s_waitcnt at the top counts on.  (No dead load past the last chunk: nothing would
+      // ever wait for it - see below the loop.)
+      const bool more_w = c + 1 < NCH, more_x = c + NXS - 1 < NCH;
       lds_u8_t xb0 = (lds_u8_t)win + (c % NXS) * XSTAGE + xlane;
       lds_u8_t xb1 = (lds_u8_t)win + (c % NXS) * XSTAGE + (xlane ^ 64u);
       asm volatile("" : "+v"(xb0), "+v"(xb1));
@@ -241,7 +254,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(w[ks][t], fr[u % DEPTH], acc[j][t]);
         __builtin_amdgcn_sched_barrier(0);
+        if (u < 2) {
+          if (more_w) load_w_ks(wnext, c + 1, u);
+        } else if (u < 2 + DI) {
+          if (more_x) dma_piece(c + NXS - 1, (c + NXS - 1) % NXS, u - 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+      static_assert(2 * MT1 >= 2 + DI, "a chunk has fewer MFMA groups than memory instructions to place between them");
     };
     for (int c = 0; c < NCH; c += 2) {
       chunk(c, wa[0], wa[1]);
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
     };
     auto load_r = [&](u32x4_t (&d)[MTW], int hp) {
 #pragma unroll
-      for (int j = 0; j < MTW; ++j) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rx, yoff[j], col(hp) * 2, 0);
+      for (int j = 0; j < MTW; ++j) d[j] = __builtin_amdgcn_raw_buffer_load_b128(rxr, yoff[j], col(hp) * 2, 0);
     };
     load_w(0);
     load_r(rq[0], 0);
@@ -407,16 +427,19 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
         const int ks = u / MTW, j = u % MTW;
         return (ks < 4 ? sb0 + ks * 4 * PLANE : sb1 + (ks - 4) * 4 * PLANE) + j * 256;
       };
-      u32x4_t fr[DEPTH];
+      // (eight fragments in flight instead of four - a unit is two MFMAs here, half of phase 2's - measured the same: the phase
+      // is bound by instruction issue, 2 MFMAs + ~5 VALU per unit and wave, not by the LDS latency)
+      constexpr int D3 = DEPTH;
+      u32x4_t fr[D3];
 #pragma unroll
-      for (int u = 0; u < DEPTH - 1; ++u) fr[u] = *(lds_u32x4_t)addr(u);
+      for (int u = 0; u < D3 - 1; ++u) fr[u] = *(lds_u32x4_t)addr(u);
 #pragma unroll
       for (int u = 0; u < UNITS; ++u) {
-        if (u + DEPTH - 1 < UNITS) fr[(u + DEPTH - 1) % DEPTH] = *(lds_u32x4_t)addr(u + DEPTH - 1);
+        if (u + D3 - 1 < UNITS) fr[(u + D3 - 1) % D3] = *(lds_u32x4_t)addr(u + D3 - 1);
         const int ks = u / MTW, j = u % MTW;
         __builtin_amdgcn_sched_barrier(0);
-        acc[j][0] = mfma16<DT_F16>(wq[ks][0], fr[u % DEPTH], acc[j][0]);
-        acc[j][1] = mfma16<DT_F16>(wq[ks][1], fr[u % DEPTH], acc[j][1]);
+        acc[j][0] = mfma16<DT_F16>(wq[ks][0], fr[u % D3], acc[j][0]);
+        acc[j][1] = mfma16<DT_F16>(wq[ks][1], fr[u % D3], acc[j][1]);
         __builtin_amdgcn_sched_barrier(0);
       }
       // the next half pass's operands, in front of this one's stores

@@ -244,8 +244,9 @@ struct BneckArgs {
   const float *sz, *bz; // its folded BatchNorm (ReLU behind it)
   int Coutz;
   unsigned int z_bytes;
-  int flags;            // experiments (SPK_BNECK_FLAGS): 1 no static wave priority in phase 3
-  unsigned long long* stamps;   // diagnostics (tools/bneck_bench.py): [block][8] s_memtime values at the phase boundaries, or null
+  int flags;            // 4: the 7-row / 4-wave block form.  Timing experiments (SPK_BNECK_FLAGS, results then wrong): 1 no static wave
+                        // priority in phase 3, 8 phase 1 reads image 0 for every block (x from L2), 16 no shortcut loads, 32 no stores
+  unsigned long long* stamps;   // diagnostics (tools/bneck_bench.py): [block][2][8] s_memtime values at the phase boundaries (first wave, first wave of the second half), or null
 };
 int spk_bneck_launch(const BneckArgs& a, hipStream_t s);   // -3: no kernel for this shape
 int spk_btail_launch(const BneckArgs& a, hipStream_t s);   // conv2 + conv3 (+ chained conv) from y1; -3: no kernel for this shape

@@ -96,3 +96,42 @@ def test_block_tail_kernel_equals_the_launches_it_replaces(shape):
     want = _ref(x, w1, w2, w3, bns)
     err = (got[0].float().cpu() - want).abs()
     assert (err <= 2e-2 + 1e-2 * want.abs()).all(), float(err.max())
+
+
+def test_network_output_does_not_depend_on_the_form_the_blocks_run_in():
+    """ResNet-50 at 224 x 224 (stage 2: 28 x 28 x 512, stage 3: 14 x 14 x 1024): the identity bottlenecks of stages 2-3 as
+    three launches (SPK_BNECK=0), as 14-row blocks (2) and as 7-row blocks (3), on one stream and on two, for a batch that
+    takes the two-stream path (64) and a ragged single-stream one (33): the same logits bit for bit, call after call - a
+    row of probabilities does not depend on the batch it was computed in or on what the tuner picked."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path[:0] = [{str(root)!r}, {str(root / 'syke-pic_amd')!r}]\n"
+        "from sykepic_hip import arch, synth\n"
+        "from sykepic_hip.net import HipNet\n"
+        "g = arch.build_graph('resnet50', 50)\n"
+        "sd = synth.synth_state_dict(arch.param_specs(g), seed=2)\n"
+        "net = HipNet('resnet50', 50, weights=None)\n"
+        "net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}); net.eval()\n"
+        "net.calibrate(torch.from_numpy(synth.synth_images(16, 3, 224, 224, seed=9000)).cuda())\n"
+        "net.set_precision('calibrated')\n"
+        "for n in (64, 33):\n"
+        "    x = torch.from_numpy(synth.synth_images(n, 3, 224, 224, seed=5)).cuda()\n"
+        "    for it in range(3):\n"
+        "        z = net.forward(x).cpu().numpy()\n"
+        "        print('SHA', n, hashlib.sha256(z.tobytes()).hexdigest())\n")
+    seen = {}
+    for env in ({"SPK_BNECK": "0"}, {"SPK_BNECK": "2"}, {"SPK_BNECK": "3"}, {"SPK_BNECK": "3", "SPK_EVAL_STREAMS": "1"},
+                {"SPK_BNECK": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPK_TUNE_CACHE="off", **env), capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        for ln in out.stdout.splitlines():
+            if ln.startswith("SHA"):
+                _, n, h = ln.split()
+                seen.setdefault(n, set()).add(h)
+    assert set(seen) == {"64", "33"} and all(len(v) == 1 for v in seen.values()), seen

@@ -1,5 +1,6 @@
 """Times one identity bottleneck block of the eval path: the one-kernel form (csrc/conv_bneck.hip) against the three
 launches of the eval path's own kernels, through spk_op_bottleneck.  usage: bneck_bench.py [n ...]"""
+import os
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -37,13 +38,15 @@ for name, (hw, cm) in SHAPES.items():
         if "STAMPS" in __import__("os").environ:
             # phase breakdown of the fused kernel from shader-clock stamps (one launch, median over the blocks)
             blocks = n * (hw // {14: 14, 28: 14, 56: 8}[hw])
-            st = torch.zeros(blocks, 8, dtype=torch.int64, device="cuda")
+            blocks *= 2 if os.environ.get("SPK_BNECK_FLAGS", "0") in ("4", "5") else 1
+            st = torch.zeros(blocks, 16, dtype=torch.int64, device="cuda")
             try:
                 ops.bottleneck(x, w1, w2, w3, *bns, fused=True, stamps=st)
             except RuntimeError:
                 continue
-            t = st.cpu().double()
-            d = lambda a, b: float((t[:, b] - t[:, a]).median())  # noqa: E731
-            print(f"   clocks (median over {blocks} blocks): setup->phase1 K loop {d(0, 1):.0f}, y1 epilogue {d(1, 2):.0f}, phase 2 K loop "
-                  f"{d(2, 3):.0f}, y2 epilogue {d(3, 4):.0f}, phase 3 {d(4, 5):.0f} (pass 0: K loop {d(4, 7):.0f}, epilogue {d(7, 6):.0f}); "
-                  f"whole {d(0, 5):.0f}; first block start -> last block end {float(t[:, 5].max() - t[:, 0].min()):.0f}", flush=True)
+            for half, o in (("first wave", 0), ("first wave of the second half", 8)):
+                t = st.cpu().double()[:, o:o + 8]
+                d = lambda a, b: float((t[:, b] - t[:, a]).median())  # noqa: E731
+                print(f"   {half}, clocks (median over {blocks} blocks): setup->phase1 K loop {d(0, 1):.0f}, y1 epilogue {d(1, 2):.0f}, phase 2 K loop "
+                      f"{d(2, 3):.0f}, y2 epilogue {d(3, 4):.0f}, phase 3 {d(4, 5):.0f} (pass 0: K loop {d(4, 7):.0f}, epilogue {d(7, 6):.0f}); "
+                      f"whole {d(0, 5):.0f}", flush=True)
