@@ -51,7 +51,7 @@ def parse():
                          "per-channel activation means measured on 32 calibration images that are not in the timed batch "
                          "(csrc/zero_sum.hip; as accurate as `precise`: tests/test_gpu_calibrated.py); "
                          "mixed (what a model directory without act_means.pth runs): fp16 + hi/lo split weights on every conv except the 3x3 convs "
-                         "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tests/diagnostics/split_rules.py: "
+                         "inside a residual block (max |dp| 6.8e-4 over 3 nets x 512 images, tests/archive/diagnostics/split_rules.py: "
                          "passes the 1e-3 parity tolerance); precise: split on every conv (5.9e-4); balanced: split "
                          "only the layers that write the residual trunk (1.3e-3 worst case); fast: plain fp16 "
                          "(1.5e-3); bf16 (5e-3); fp8: e4m3 inside the EfficientNet MBConv blocks (BASELINE config 5; "
@@ -66,7 +66,7 @@ def parse():
     if args.precision is None:
         # the fastest mode that holds the parity tolerance: ResNets - calibrated single pass (tests/test_gpu_calibrated.py);
         # EfficientNets - `mixed`, which splits none of their convs (the weight rounding does not show beside the fp16
-        # rounding of their activations: tests/diagnostics/effnet_calibrated.py)
+        # rounding of their activations: tests/archive/diagnostics/effnet_calibrated.py)
         args.precision = "mixed" if args.network.startswith("efficientnet") else "calibrated"
     return args
 

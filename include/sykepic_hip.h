@@ -149,7 +149,7 @@ int spk_model_set_infer_dtype(spk_model* m, int bf16);
  * block (the lo-products that buy the least accuracy per MFMA cycle) - and, on
  * the EfficientNet graphs, no conv at all: their error is the fp16 rounding of
  * the stored activations, the weight rounding does not show beside it
- * (tests/diagnostics/effnet_calibrated.py; 1 still splits every conv).
+ * (tests/archive/diagnostics/effnet_calibrated.py; 1 still splits every conv).
  * split_weights = 1: every conv weight is carried as
  * hi + lo fp16 halves and both products are accumulated (2x MFMA work, weight
  * rounding error ~2^-22) — weight rounding is the dominant logit error at
@@ -159,7 +159,7 @@ int spk_model_set_precision(spk_model* m, int split_weights, int precise_residua
 /* Per-op choice of split weights: flags[i] != 0 carries conv op i (index into the
  * spk_layer_desc array of spk_model_create) as hi+lo halves; flags of non-conv ops
  * are ignored.  Replaces the split_weights mode until spk_model_set_precision is
- * called again.  `tests/diagnostics/split_search.py` derives the cheapest mask that keeps
+ * called again.  `tests/archive/diagnostics/split_search.py` derives the cheapest mask that keeps
  * the reference's 1e-3 probability tolerance. */
 int spk_model_set_split_ops(spk_model* m, const unsigned char* flags, int n_ops);
 /* Calibrated single-pass mode (round 4): split_weights = 5 in spk_model_set_precision.

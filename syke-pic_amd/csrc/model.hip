@@ -553,15 +553,15 @@ static int layer_split(const spk_model* m, const Layer& L) {
   // image's channel means: raw pixels on a near-constant background are almost all mean)
   if (m->splitw == 5) return 0;
   // 3: every conv except the 3x3 conv in the middle of a BOTTLENECK block, i.e. a 3x3 conv that neither writes the
-  // trunk nor reads it (tests/diagnostics/split_rules.py: its weight rounding adds the least logit error per MFMA
+  // trunk nor reads it (tests/archive/diagnostics/split_rules.py: its weight rounding adds the least logit error per MFMA
   // cycle a lo-product costs).  The first 3x3 conv of a basic block (ResNet-18/34) reads the trunk and stays split:
-  // un-split it costs 1.1e-3 of probability on the class-standardised golden fixture (tests/diagnostics/diverse_prec.py)
-  // (Round 3 tried splitting the last stage's inner 3x3 convs as well, tests/diagnostics/split_rules.py "all-but-
+  // un-split it costs 1.1e-3 of probability on the class-standardised golden fixture (tests/archive/diagnostics/diverse_prec.py)
+  // (Round 3 tried splitting the last stage's inner 3x3 convs as well, tests/archive/diagnostics/split_rules.py "all-but-
   // inner3x3(stages1-3)": +0.29 ms per forward and no gain on the class-standardised golden fixture.)
   // EfficientNets: none.  Their error is the fp16 rounding of every stored activation, amplified layer by layer through 16-32
-  // SiLU blocks (tests/diagnostics/effnet_prec.py); the weight rounding does not show beside it - goldens 1.2e-4 with
+  // SiLU blocks (tests/archive/diagnostics/effnet_prec.py); the weight rounding does not show beside it - goldens 1.2e-4 with
   // hi + lo on every 1x1 conv, 2.4e-4 without, fresh images the same medians and maxima either way
-  // (tests/diagnostics/effnet_calibrated.py) - while the lo products cost 7 % of the B4 forward (26.2 -> 28.2 k img/s).
+  // (tests/archive/diagnostics/effnet_calibrated.py) - while the lo products cost 7 % of the B4 forward (26.2 -> 28.2 k img/s).
   if (m->splitw == 3 && m->effnet) return 0;
   if (m->splitw == 3) return L.trunk_writer || L.d.k != 3 || !L.inner3x3 ? 1 : 0;
   return m->splitw == 1 || L.trunk_writer ? 1 : 0;
@@ -746,7 +746,7 @@ static int assign_fp8_roles(spk_model* m, bool count_only = false) {
     if (count_only) continue;
     // Default (no explicit flags): only blocks that ADD their branch to the trunk.  A block without a shortcut (the first
     // of every stage) replaces the trunk by its e4m3-computed output, ~10 % relative error on the trunk itself, and alone
-    // flips more arg-maxes than all residual blocks together (tests/diagnostics/fp8_block_sweep.py).
+    // flips more arg-maxes than all residual blocks together (tests/archive/diagnostics/fp8_block_sweep.py).
     if (m->fp8_blocks.empty() ? P.d.res < 0 : (idx >= (int)m->fp8_blocks.size() || !m->fp8_blocks[idx])) continue;
     E.fp8_role = 1; m->layers[di].fp8_role = 2; m->layers[si].fp8_role = 3; P.fp8_role = 4;
   }

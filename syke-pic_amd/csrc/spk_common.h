@@ -269,7 +269,7 @@ int spk_launch_chan_mean(const bf16_t* x, float* part, float* mean, size_t rows,
 // The model executors pass SPK_INPUT_SCALE = 255: the reference's inputs are k / 255 (ToTensor), which no 16-bit float
 // holds exactly, while the integers 0..255 are exact in fp16 AND bf16 - the stem kernels take the factor back in fp32
 // (eval: folded BatchNorm scale / 255; training: stem weights / 255 at packing, weight gradient / 255).  Measured on
-// trained nets (tests/diagnostics/input_rounding.py): against the fp32 oracle the eval path was 1.2e-3 off on the worst of
+// trained nets (tests/archive/diagnostics/input_rounding.py): against the fp32 oracle the eval path was 1.2e-3 off on the worst of
 // 256 images, 7.6e-5 against the oracle fed the fp16-rounded pixels - the input rounding WAS the error.
 #define SPK_INPUT_SCALE 255.0f
 int spk_launch_to_nhwc4(const void* x, int layout, int dtype, int n, int c, int h, int w,

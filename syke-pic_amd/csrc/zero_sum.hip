@@ -9,7 +9,7 @@
 // midpoint are rounded the other way - one at a time, cheapest first - until sum_k mu_k dw_k has gone to (within the
 // smallest available step of) zero, mu_k = E[x_k] from a calibration batch.  A flipped weight was ~0.5 ulp off either
 // way, so the row's squared rounding error hardly moves (measured +0.02..1 %), while its mu-weighted sum drops by 2-4
-// orders of magnitude.  Measured on the synthetic ResNet-50s (tests/diagnostics/zero_sum_round.py): plain fp16 1.64e-3
+// orders of magnitude.  Measured on the synthetic ResNet-50s (tests/archive/diagnostics/zero_sum_round.py): plain fp16 1.64e-3
 // worst |dp|, zero-sum with calibrated means 3.9e-4 - below the 37-conv hi + lo default (8.8e-4) with no second product.
 // Groups: a k x k conv is balanced per filter TAP (each cin slice on its own), so a border pixel, which sees a subset
 // of the taps, keeps the cancellation.

@@ -160,7 +160,7 @@ def decode_context():
     life ("Unexpected segmentation fault encountered in worker", one run in ~20), a fork()ed child of a process whose
     other threads were inside the HIP runtime (the batch thread forked the workers while the main thread was uploading
     the network's parameters).  The cause could NOT be established from that one record: no traceback was captured,
-    and two probes of the plausible mechanisms came back clean on the GPU box (tests/diagnostics/
+    and two probes of the plausible mechanisms came back clean on the GPU box (tests/archive/diagnostics/
     fork_dontfork_probe.py: 50 children forked while another thread copies pageable memory to the GPU read every page
     of the buffer; children that finalize an inherited CUDA tensor / event / stream / pinned tensor / HipNet handle
     exit 0).  What is certain is the exposure: a forked child carries the parent's HIP / RCCL state (mapped queues,

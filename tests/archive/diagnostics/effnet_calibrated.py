@@ -1,6 +1,6 @@
 """Diagnostic (not a test): the calibrated single-pass mode (zero-sum rounded fp16 weights, csrc/zero_sum.hip) on the
 EfficientNets - golden vectors of the reference's net_pass and fresh images against the oracle, beside `mixed` (hi + lo
-weights on every 1x1 conv).  Run on the GPU box from the repo root:  python tests/diagnostics/effnet_calibrated.py"""
+weights on every 1x1 conv).  Run on the GPU box from the repo root:  python tests/archive/diagnostics/effnet_calibrated.py"""
 import sys
 from pathlib import Path
 

@@ -3,7 +3,7 @@ while another thread of the parent is inside a host->device copy from PAGEABLE m
 
 Parent: one thread copies a large pageable buffer to the GPU in a loop.  Main thread: fork() repeatedly; each child
 reads one byte of every page of that buffer (and of a bystander array allocated next to it) and exits 0; a child that
-dies on a signal is counted.  Run on the GPU box:  python tests/diagnostics/fork_dontfork_probe.py
+dies on a signal is counted.  Run on the GPU box:  python tests/archive/diagnostics/fork_dontfork_probe.py
 Not a test (no asserts): prints the counts."""
 import os
 import signal

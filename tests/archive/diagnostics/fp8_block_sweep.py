@@ -1,7 +1,7 @@
 """Which MBConv blocks can run on the e4m3 path?  (VERDICT r2 item 4 / DESIGN.md section 5.)
 EfficientNet-B4 at 224x224 with the calibrated synthetic weights of the goldens: for several sets of fp8 blocks,
 agreement of the fp8 mode with the fp16 parity mode on 64 fresh images (top-1, |dp| median / p90 / max at the reference's
-softmax base 1.3) and the forward time at batch 128.  Usage (GPU box, repo root): python tests/diagnostics/fp8_block_sweep.py
+softmax base 1.3) and the forward time at batch 128.  Usage (GPU box, repo root): python tests/archive/diagnostics/fp8_block_sweep.py
 """
 import sys
 import time

@@ -1,7 +1,7 @@
 """fp8 mode of EfficientNet-B4 / B0 on DECIDED images: top-1 agreement with the fp16 parity mode as a function of the fp16
 top-1 margin (p1 - p2 at the reference's softmax base 1.3), 256 fresh images.  Sets: every block on the e4m3 path; every
 block but the first of each stage (the stride-2 / widening blocks, the sensitive ones in fp8_block_sweep.py).
-Usage (GPU box, repo root): python tests/diagnostics/fp8_decided.py [network]"""
+Usage (GPU box, repo root): python tests/archive/diagnostics/fp8_decided.py [network]"""
 import sys
 from pathlib import Path
 

@@ -1,6 +1,6 @@
 """Diagnostic: does running the 1x1 convs on conv_pw.hip (SPK_PW=2) change the probability error of the default
 `mixed` mode?  ResNet-50 @224, 3 synthetic nets x 128 images vs the fp32 oracle.  Run once per SPK_PW value:
-  SPK_PW=0 python tests/diagnostics/pw_prec.py ; SPK_PW=2 python tests/diagnostics/pw_prec.py"""
+  SPK_PW=0 python tests/archive/diagnostics/pw_prec.py ; SPK_PW=2 python tests/archive/diagnostics/pw_prec.py"""
 import os
 import sys
 from pathlib import Path

@@ -48,7 +48,7 @@ def test_efficientnet_probabilities_match_reference_golden(golden_dir, network):
     decided = (top2[:, 1] - top2[:, 0]) > 2 * PROB_TOL
     assert (p.argmax(1)[decided] == want.argmax(1)[decided]).all()
     # Fresh images against the oracle.  A 32-block (B0: 16) random-weight SiLU network amplifies the fp16
-    # rounding of every stored tensor layer by layer (tests/diagnostics/effnet_prec.py: the relative error grows smoothly
+    # rounding of every stored tensor layer by layer (tests/archive/diagnostics/effnet_prec.py: the relative error grows smoothly
     # from 6e-4 after the stem to ~2e-2 at the last feature map of the worst image; split weights or fp16
     # remainders of the trunk do not change it), so individual images land above 1e-3 although the golden
     # vectors pass: the check on fresh images is statistical, and the probabilities are compared at a

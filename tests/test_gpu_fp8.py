@@ -102,7 +102,7 @@ def test_pw_fp8_kernel_matches_e4m3_reference(case):
         assert err < 2e-3
 
 
-# fp8 default mode vs the fp16 parity mode, 256 fresh images (measured, tests/diagnostics/fp8_decided.py: B0 top-1 0.953 /
+# fp8 default mode vs the fp16 parity mode, 256 fresh images (measured, tests/archive/diagnostics/fp8_decided.py: B0 top-1 0.953 /
 # 0.987 at margin >= 0.05, |dp| median 2.3e-3; B4 0.844 / 1.000 at margin >= 0.2 (0.87 at >= 0.05), median 4.2e-3)
 DECIDED = {"efficientnet_b0": 0.05, "efficientnet_b4": 0.2}
 # (B4: ~24 of the 256 random-weight images have a margin >= 0.2; one image is 4 points.  Measured over the rounds 0.917-1.00
@@ -186,7 +186,7 @@ def test_efficientnet_fp8_mode(golden_dir, network):
     # SiLU network, whose fp16 top-1 MARGIN is 0.011 in the median (p1 - p2 at the reference's base 1.3) and which
     # amplifies even fp16 rounding 40-fold (test_gpu_effnet.py).  Round 3: the mode's default covers the blocks WITH a
     # shortcut only - a block without one (the first of each stage) replaces the trunk by its e4m3-computed output and
-    # alone flips more arg-maxes than all the others together (tests/diagnostics/fp8_block_sweep.py, fp8_decided.py).
+    # alone flips more arg-maxes than all the others together (tests/archive/diagnostics/fp8_block_sweep.py, fp8_decided.py).
     assert torch.isfinite(p8_fresh).all() and torch.allclose(p8_fresh.sum(1), torch.ones(32), atol=1e-4)
     # agreement with the fp16 parity mode on 256 fresh images, overall and on the DECIDED ones
     more = [torch.from_numpy(synth.synth_images(32, 3, 224, 224, seed=300 + i)).cuda() for i in range(8)]

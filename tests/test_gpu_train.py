@@ -63,7 +63,7 @@ def test_backward_matches_the_bf16_emulating_oracle(network, hw, n):
       exact  (round_grads=False): float32 gradients = exact backpropagation through that forward;
       bf16   (round_grads=True):  gradients rounded where the GPU stores them.
     |bf16 - exact| is what bf16 gradient STORAGE costs by construction: a random walk that grows from 2e-3 behind
-    the loss to ~1e-2 at the stem of ResNet-50 (measured, tests/diagnostics/grad_err_depth.py).  Two
+    the loss to ~1e-2 at the stem of ResNet-50 (measured, tests/archive/diagnostics/grad_err_depth.py).  Two
     implementations of the same rounding points decorrelate within ~4 layers (one flipped ulp perturbs every sum
     it enters), so beyond the tail of the net the GPU cannot equal the emulation bit for bit; what must hold is
       (1) near the loss (last block + head) the GPU equals the bf16 emulation: <= 3e-3 (measured 3e-5 ... 1.9e-3);

@@ -109,7 +109,7 @@ def test_trained_resnet18_every_mode_within_tolerance():
     # Since the input is stored as exact pixel values (x 255, csrc/spk_common.h SPK_INPUT_SCALE) a trained net sits far
     # inside the tolerance: measured mixed / precise 5.7e-5, calibrated 9.2e-5, plain fp16 1.4e-4 (worst of 256 images).
     # Before that change every mode read 1.2e-3 here - the fp16 rounding of k / 255, one systematic error per grey level
-    # (tests/diagnostics/input_rounding.py), which hid the differences between the weight modes altogether.
+    # (tests/archive/diagnostics/input_rounding.py), which hid the differences between the weight modes altogether.
     for mode in ("mixed", "precise", "calibrated"):
         assert res[mode]["max"] <= 3e-4 and res[mode]["p90"] <= 1e-4, (mode, res[mode])
         assert res[mode]["top1_decided"] == 1.0, (mode, res[mode])

@@ -1,6 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4ec
-timeout -k 10 600 python tests/diagnostics/effnet_calibrated.py > gpurun_out/r4ec/diag.txt 2> gpurun_out/r4ec/diag.err
+timeout -k 10 600 python tests/archive/diagnostics/effnet_calibrated.py > gpurun_out/r4ec/diag.txt 2> gpurun_out/r4ec/diag.err
 cat gpurun_out/r4ec/diag.txt; tail -3 gpurun_out/r4ec/diag.err
 export SPK_TUNE_CACHE=$PWD/gpurun_out/r4ec/tune.txt
 for pr in mixed calibrated fast; do
