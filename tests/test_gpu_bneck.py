@@ -135,3 +135,34 @@ def test_network_output_does_not_depend_on_the_form_the_blocks_run_in():
                 _, n, h = ln.split()
                 seen.setdefault(n, set()).add(h)
     assert set(seen) == {"64", "33"} and all(len(v) == 1 for v in seen.values()), seen
+
+
+@pytest.mark.parametrize("flags", ["0", "4"], ids=["14-row blocks", "7-row blocks"])
+def test_blocks_that_share_and_inherit_cus(flags):
+    """More blocks than the chip holds at once (7-row form: two per CU, later blocks start beside running ones): still the
+    three launches' bits, run after run.  (Round 5 found one wrong image in a few hundred blocks here: phase 1 issued a last,
+    dead weight load through the instruction form the compiler does not track - buffer_load_b128_untracked - and it landed
+    in registers that were live again.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, torch\n"
+        f"sys.path[:0] = [{str(root)!r}, {str(root / 'syke-pic_amd')!r}, {str(root / 'tests')!r}]\n"
+        "from sykepic_hip import ops\n"
+        "from test_gpu_bneck import _block\n"
+        "for (n, hw, cm) in ((300, 14, 256), (160, 28, 128)):\n"
+        "    x, w1, w2, w3, bns = _block(n, hw, cm, seed=3)\n"
+        "    d = lambda t: t.cuda()\n"
+        "    dbns = [(d(a), d(b)) for a, b in bns]\n"
+        "    three = ops.bottleneck(d(x), d(w1), d(w2), d(w3), *dbns, fused=0).cpu()\n"
+        "    for it in range(3):\n"
+        "        one = ops.bottleneck(d(x), d(w1), d(w2), d(w3), *dbns, fused=1).cpu()\n"
+        "        print('CHECK', n, hw, it, int((one != three).sum()))\n")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPK_BNECK_FLAGS=flags), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("CHECK")]
+    assert len(lines) == 6 and all(ln[-1] == "0" for ln in lines), lines
