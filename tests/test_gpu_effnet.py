@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 PROB_TOL = 1e-3
 # fresh images at the reference's base 1.3 (measured r2: median 2.0-2.6e-4, p90 1.6-2.1e-3, max 2.0-3.1e-3, top-1 32/32)
 # round 4 (exact pixel input): measured B0 1.3e-4 / 1.4e-3 / 4.6e-3, B4 1.1e-4 / 8.1e-4 / 2.8e-3 on these RANDOM-weight nets
-# (a trained EfficientNet-B0: median 1.5e-5, p90 5.8e-5, max 2.0e-4 - tests/test_gpu_trained.py)
+# (TRAINED nets, tests/test_gpu_trained.py: EfficientNet-B0 median 1.5e-5, p90 5.8e-5, max 2.0e-4; round 5: EfficientNet-B4 - the
+# config-5 model - median 2.4e-5, p90 9.0e-5, max 6.0e-4, top-1 256 / 256: inside the reference's 1e-3.  The wide bounds below
+# describe what untrained 16-32-block SiLU nets do to fp16 activation storage, not the path on a classifier.)
 BASE13_MEDIAN, BASE13_P90, BASE13_MAX = 3e-4, 3e-3, 9e-3
 
 
