@@ -303,7 +303,7 @@ def run_mode(mode, args, net, x, y, dist, dev, rank, world):
     if mode == "infer" and world == 1 and not args.no_cpu_baseline:
         parity_gpu = step()[:PARITY_N].float().cpu()     # one more forward of the timed configuration (two streams)
     uncal_ms = None
-    if mode == "infer" and args.precision == "calibrated" and world == 1 and rank == 0:
+    if mode == "infer" and args.precision == "calibrated" and world == 1 and rank == 0 and not args.no_kernel_profile:
         # what a model directory runs until it has activation means (`prob` measures them on its first batch): the default
         # hi + lo split mode, timed like the headline.  (Here, not at the end: the LAST forward of the process stays one of the
         # timed configuration - the PMC tools take their per-step figures from it.)
