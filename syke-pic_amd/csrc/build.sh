@@ -9,7 +9,7 @@ mkdir -p build
 pids=()
 for f in $SRCS; do
   o=build/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ spk_common.h -nt "$o" ] || [ model.h -nt "$o" ] || [ ../../include/sykepic_hip.h -nt "$o" ] || [ resize_u8.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ spk_common.h -nt "$o" ] || [ model.h -nt "$o" ] || [ ../../include/sykepic_hip.h -nt "$o" ] || [ resize_u8.h -nt "$o" ] || [ ordered_reduce.h -nt "$o" ] || [ train_effnet.h -nt "$o" ] || [ dw_util.h -nt "$o" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "$f" -o "$o" &
     pids+=($!)
   fi

@@ -200,6 +200,7 @@ struct spk_model {
 
 void spk_set_error(const std::string& s);
 int spk_commit(spk_model* m);
+int spk_train_join(spk_model* m);   // train.hip: the model's stream waits for the last step's deferred side-stream work
 int spk_plan(spk_model* m, int n, int h, int w, bool pad = false);
 int spk_run_layer_eval(spk_model* m, Layer& L, int nb);
 int spk_forward_eval_logits(spk_model* m, const void* x, int n, int h, int w, int layout, int dtype,

@@ -402,7 +402,10 @@ extern "C" void spk_model_destroy(spk_model* m) {
 
 extern "C" int spk_model_set_stream(spk_model* m, void* s) {
   if (!m) return fail(SPK_ERR_ARG, "null model");
+  if (m->stream == (hipStream_t)s) return SPK_OK;   // (the host side sets the stream in front of every call)
   m->stream = (hipStream_t)s;
+  // a training step may have left a weight gradient running on the side stream: what comes next runs on the NEW stream
+  if (spk_train_join(m) != SPK_OK) return fail(SPK_ERR_HIP, "set_stream: joining the side stream failed");
   return SPK_OK;
 }
 
@@ -857,6 +860,7 @@ static int fp8_pack(spk_model* m) {
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int spk_plan(spk_model* m, int n, int h, int w, bool pad) {
+  SPK_TRY(spk_train_join(m));   // a deferred weight gradient of the last training step still reads the input tensor
   // pad: the training layout of the EfficientNet graphs (channels of every conv output rounded up to 64, zeros in the
   // pad); the eval kernels work on the tensors' own widths.  Switching between the two only re-addresses the arena
   // (tensor dims and offsets) as long as the new layout fits the allocation - the per-epoch train -> validate -> train

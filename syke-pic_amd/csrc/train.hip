@@ -87,6 +87,15 @@ struct TrainState {
   // has its own dy tensor (ConvTrain::dy_off, round 4); with SPK_DY_PER_LAYER=0 dy is double buffered as before: bn_bwd of
   // layer i-2 may then overwrite a buffer only after the wgrad that read it has finished (ev_dy_free).
   size_t dy2_off = 0;
+  // The step's LAST weight gradient (the first layer's: its dy is the last tensor the backward makes) runs on the side
+  // stream while the main stream has nothing left to do.  Unless somebody reads the gradients in between, the step
+  // returns WITHOUT waiting for it: spk_optim_step updates every other parameter first and joins the side stream in
+  // front of that one tensor (ResNet-50, batch 256: 0.36 ms of idle main queue in front of the optimizer otherwise).
+  // Every other consumer of side-stream results goes through spk_train_join.
+  bool tail_pending = false;     // ev_side_done is recorded, the main stream has not waited for it
+  int tail_param = -1;           // the parameter whose gradient is still being made
+  bool grads_exported = false;   // spk_model_grad_buffer handed the flat buffer out: always join at the end of the step
+  hipEvent_t ev_side_pre = nullptr;   // side stream, in front of the tail weight gradient
   hipStream_t side = nullptr;
   hipEvent_t ev_dy_ready[2] = {nullptr, nullptr};   // main: dy buffer written
   hipEvent_t ev_dy_free[2] = {nullptr, nullptr};    // side: wgrad has read the dy buffer
@@ -118,6 +127,7 @@ void spk_train_free(spk_model* m) {
     if (t->ev_dy_free[i]) hipEventDestroy(t->ev_dy_free[i]);
   }
   if (t->ev_side_done) hipEventDestroy(t->ev_side_done);
+  if (t->ev_side_pre) hipEventDestroy(t->ev_side_pre);
   if (t->ev_se) hipEventDestroy(t->ev_se);
   delete t;
   m->train = nullptr;
@@ -194,12 +204,16 @@ static int ensure_state(spk_model* m) {
       const int prio = pe ? (atoi(pe) > 0 ? hi : (atoi(pe) < 0 ? lo : 0)) : lo;
       HIP_TRY(hipStreamCreateWithPriority(&t->side, hipStreamNonBlocking, prio));
     }
+    // the events order two streams of ONE device: no system-scope fence (SPK_EVENT_SYSFENCE=1 keeps it, for A/B runs)
+    static const bool sysfence = getenv("SPK_EVENT_SYSFENCE") && atoi(getenv("SPK_EVENT_SYSFENCE")) != 0;
+    const unsigned evf = hipEventDisableTiming | (sysfence ? 0u : (unsigned)hipEventDisableSystemFence);
     for (int i = 0; i < 2; ++i) {
-      HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_ready[i], hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_free[i], hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_ready[i], evf));
+      HIP_TRY(hipEventCreateWithFlags(&t->ev_dy_free[i], evf));
     }
-    HIP_TRY(hipEventCreateWithFlags(&t->ev_side_done, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&t->ev_se, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_side_done, evf));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_side_pre, evf));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_se, evf));
   }
   return SPK_OK;
 }
@@ -714,6 +728,12 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
     return Q.d.kind == SPK_OP_CONV && Q.mode == CONV_MODE_GENERIC && Q.d.src == tr && Q.d.k == 1 && Q.d.stride == 1 &&
            P.d.kind == SPK_OP_CONV && P.d.relu <= 1;
   };
+  // deferred join of the side stream (TrainState::tail_pending): single-process steps whose gradients nobody reads in place
+  static const bool tail_env = !getenv("SPK_TAIL_DEFER") || atoi(getenv("SPK_TAIL_DEFER")) != 0;
+  const bool tail_ok = tail_env && side_on && !m->grad_cb && !t->grads_exported;
+  int first_conv = -1, tail_layer = -1;
+  for (int q = 0; q < nl && first_conv < 0; ++q)
+    if (m->layers[q].d.kind == SPK_OP_CONV || m->layers[q].d.kind == SPK_OP_DWCONV) first_conv = q;
   int cur_bucket = 0;
   for (int i = nl - 1; i >= 0; --i) {
     Layer& L = m->layers[i];
@@ -803,6 +823,8 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
                                          g_res ? has_grad[L.d.res] : 0, M, C, o.h * o.w, L.d.relu, s), "bn bwd apply");
         }
         mark(m, PH_BN_BWD);
+        // (6-9 us of idle main queue behind every one of these records; attaching the event to the apply kernel's own
+        // completion - hipExtLaunchKernelGGL's stopEvent - leaves the same gap: measured in round 5, not kept)
         if (side_on) HIP_TRY(hipEventRecord(t->ev_dy_ready[slot], s));
         if (g_res) has_grad[L.d.res] = 1;
         const Param& pw = m->params[L.p_w];
@@ -895,6 +917,10 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
           const int cin_t = stem ? L.d.cin : in.c;   // channels of the stored input tensor (the 7x7 stem reads NHWC4 itself)
           // ResNets: on the second stream, beside this layer's dgrad and the next layer's BatchNorm backward
           const hipStream_t ws = side_on ? t->side : s;
+          if (side_on && tail_ok && L.d.src == 0 && i == first_conv) {   // the step's last weight gradient: see tail_pending
+            HIP_TRY(hipEventRecord(t->ev_side_pre, ws));
+            tail_layer = i;
+          }
           if (side_on) HIP_TRY(hipStreamWaitEvent(ws, t->ev_dy_ready[slot], 0));
           SPK_TRY(spk_conv_wgrad_slabs((const bf16_t*)m->T(L.d.src), dy, slabs, n, in.h, in.w, cin_t, o.h, o.w, C, L.d.k,
                                        L.d.stride, L.d.pad, stem, ws));
@@ -955,8 +981,25 @@ extern "C" int spk_train_forward_backward(spk_model* m, const void* x, int n, in
     while (cur_bucket < m->grad_buckets) SPK_TRY(grad_bucket_done(m, cur_bucket++));
   if (side_on) {   // the step is complete on the caller's stream only when the side-stream weight gradients are
     HIP_TRY(hipEventRecord(t->ev_side_done, t->side));
-    HIP_TRY(hipStreamWaitEvent(s, t->ev_side_done, 0));
+    if (tail_layer >= 0) {   // ... all but the last one: whoever needs it joins (spk_train_join, spk_optim_step)
+      HIP_TRY(hipStreamWaitEvent(s, t->ev_side_pre, 0));
+      t->tail_pending = true;
+      t->tail_param = m->layers[tail_layer].p_w;
+    } else {
+      HIP_TRY(hipStreamWaitEvent(s, t->ev_side_done, 0));
+    }
   }
+  return SPK_OK;
+}
+
+// Makes the model's stream wait for whatever the last training step left running on the side stream (the deferred tail
+// weight gradient).  Called by everything that reads gradients or overwrites what that kernel reads: the next forward
+// of any kind (spk_plan), the gradient readers, a stream change.
+int spk_train_join(spk_model* m) {
+  TrainState* t = m ? m->train : nullptr;
+  if (!t || !t->tail_pending) return SPK_OK;
+  HIP_TRY(hipStreamWaitEvent(m->stream, t->ev_side_done, 0));
+  t->tail_pending = false;
   return SPK_OK;
 }
 
@@ -1027,7 +1070,16 @@ extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
     tab.count = 0;
     return r;
   };
-  for (Param& p : m->params) {
+  // parameters whose gradients are complete first; the one the side stream may still be writing last, behind the join
+  const int tail_param = t->tail_pending ? t->tail_param : -1;
+  for (int pass = 0; pass < 2; ++pass)
+  for (size_t pidx = 0; pidx < m->params.size(); ++pidx) {
+    Param& p = m->params[pidx];
+    if (((int)pidx == tail_param) != (pass == 1)) continue;
+    if (pass == 1) {
+      K_TRY(flush(), "optimizer");
+      SPK_TRY(spk_train_join(m));
+    }
     if (!p.trainable || !p.requires_grad || p.group < 0) continue;
     p.step += 1;
     OptEntry& e = tab.e[tab.count++];
@@ -1067,6 +1119,7 @@ extern "C" int spk_optim_step(spk_model* m, const spk_optim_desc* opt) {
     if (tab.count == 64) K_TRY(flush(), "optimizer");
   }
   K_TRY(flush(), "optimizer");
+  SPK_TRY(spk_train_join(m));
   t->weights_dirty = true;
   m->dirty = true;
   return SPK_OK;
@@ -1076,6 +1129,8 @@ extern "C" int spk_model_grad_buffer(spk_model* m, void** dev_ptr, int64_t* nume
   if (!m || !dev_ptr || !numel) return tfail(SPK_ERR_ARG, "grad_buffer: bad arguments");
   HIP_TRY(hipSetDevice(m->device));
   SPK_TRY(ensure_state(m));
+  SPK_TRY(spk_train_join(m));
+  m->train->grads_exported = true;   // the caller reads the buffer on its own stream from now on: steps end joined
   *dev_ptr = m->train->gbuf;
   *numel = (int64_t)m->n_train;
   return SPK_OK;
@@ -1089,6 +1144,7 @@ extern "C" int spk_model_read_grad(spk_model* m, const char* key, void* host, in
   if (!p.trainable || p.numel != numel) return tfail(SPK_ERR_ARG, std::string("no gradient / size mismatch for ") + key);
   if (!m->train) return tfail(SPK_ERR_STATE, "read_grad before any training step");
   HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_train_join(m));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return spk_read_flat(m, m->train->gbuf, p, (float*)host);
 }
@@ -1103,6 +1159,7 @@ extern "C" int spk_model_read_activation_grad(spk_model* m, int t, int n, float*
   const size_t cnt = (size_t)n * d.h * d.w * d.c;
   if ((int64_t)((size_t)n * d.h * d.w * cl) != numel) return tfail(SPK_ERR_ARG, "read_activation_grad: size mismatch");
   HIP_TRY(hipSetDevice(m->device));
+  SPK_TRY(spk_train_join(m));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (!d.bf16) {
     HIP_TRY(hipMemcpy(host, m->train->G(t), cnt * 4, hipMemcpyDeviceToHost));

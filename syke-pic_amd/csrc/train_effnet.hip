@@ -9,6 +9,7 @@
 // scale and shift), so the 1x1 convs run on the implicit-GEMM / wgrad kernels unchanged; fp32 statistics and
 // parameters; per-channel reductions are two-stage and ordered (no atomics): a step is bitwise reproducible.
 #include "train_effnet.h"
+#include "ordered_reduce.h"
 
 #include <algorithm>
 
@@ -241,85 +242,49 @@ __global__ __launch_bounds__(256) void bna_bwd_apply_kernel(
 
 // ---- ordered finalize steps for a channel-padded tensor: parameters and running statistics exist for c < c_log only;
 // pad channels get mean 0, invstd 0, scale 0, shift 0 (their raw values are zeros) ----
-__device__ __forceinline__ double colsum16(const float* __restrict__ partials, int count, int C, int which, int c, int r,
-                                           bool valid, double* sm) {
-  double acc = 0.0;
-  if (valid)
-    for (int t = r; t < count; t += 16) acc += (double)partials[((size_t)t * 2 + which) * C + c];
-  sm[r * 64 + (threadIdx.x & 63)] = acc;
-  __syncthreads();
-  double tot = 0.0;
-  if (r == 0)
-    for (int k = 0; k < 16; ++k) tot += sm[k * 64 + (threadIdx.x & 63)];
-  __syncthreads();
-  return tot;
-}
-
-// stage 1 of the ordered reduction when there are many partial rows (one per M tile of the conv kernels): blockIdx.y takes
-// a contiguous slice of the rows and writes one row of out[slices][2][C]
-__global__ __launch_bounds__(1024) void bna_presum_kernel(const float* __restrict__ partials, int count, int C,
-                                                          int rows_per_slice, float* __restrict__ out) {
-  __shared__ double sm[16 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const bool valid = c < C;
-  const int t0 = blockIdx.y * rows_per_slice;
-  const int cnt = max(0, min(count - t0, rows_per_slice));
-  const float* base = partials + (size_t)t0 * 2 * C;
-  const double s1 = colsum16(base, cnt, C, 0, c, r, valid, sm);
-  const double s2 = colsum16(base, cnt, C, 1, c, r, valid, sm);
-  if (r == 0 && valid) {
-    out[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)s1;
-    out[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)s2;
+struct BnaFwdFin {
+  int C, c_log;
+  double M;
+  const float *gamma, *beta;
+  float *rmean, *rvar, *st;
+  float eps, momentum;
+  __device__ __forceinline__ void operator()(int c, double s1, double s2) const {
+    if (c >= c_log) {
+      st[c] = 0.f; st[C + c] = 0.f; st[2 * C + c] = 0.f; st[3 * C + c] = 0.f;
+      return;
+    }
+    const double mean = s1 / M;
+    double var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    st[c] = (float)mean;
+    st[C + c] = invstd;
+    const float sc = gamma[c] * invstd;
+    st[2 * C + c] = sc;
+    st[3 * C + c] = beta[c] - (float)mean * sc;
+    const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
   }
-}
+};
 
-__global__ __launch_bounds__(1024) void bna_finalize_kernel(
-    const float* __restrict__ partials, int count, int C, int c_log, double M, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ st, float eps,
-    float momentum) {
-  __shared__ double sm[16 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const bool valid = c < C;
-  const double s1 = colsum16(partials, count, C, 0, c, r, valid, sm);
-  const double s2 = colsum16(partials, count, C, 1, c, r, valid, sm);
-  if (r != 0 || !valid) return;
-  if (c >= c_log) {
-    st[c] = 0.f; st[C + c] = 0.f; st[2 * C + c] = 0.f; st[3 * C + c] = 0.f;
-    return;
+struct BnaBwdFin {
+  int C, c_log;
+  double M;
+  const float *gamma, *invstd;
+  float *dgamma, *dbeta, *coef;
+  __device__ __forceinline__ void operator()(int c, double s1, double s2) const {
+    if (c >= c_log) {
+      coef[c] = 0.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f;
+      return;
+    }
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / M);
+    coef[C + c] = (float)(s2 / M);
+    coef[2 * C + c] = gamma[c] * invstd[c];
   }
-  const double mean = s1 / M;
-  double var = s2 / M - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  st[c] = (float)mean;
-  st[C + c] = invstd;
-  const float sc = gamma[c] * invstd;
-  st[2 * C + c] = sc;
-  st[3 * C + c] = beta[c] - (float)mean * sc;
-  const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-  rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-  rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-}
-
-__global__ __launch_bounds__(1024) void bna_bwd_finalize_kernel(
-    const float* __restrict__ partials, int count, int C, int c_log, double M, const float* __restrict__ gamma,
-    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
-  __shared__ double sm[16 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const bool valid = c < C;
-  const double s1 = colsum16(partials, count, C, 0, c, r, valid, sm);
-  const double s2 = colsum16(partials, count, C, 1, c, r, valid, sm);
-  if (r != 0 || !valid) return;
-  if (c >= c_log) {
-    coef[c] = 0.f; coef[C + c] = 0.f; coef[2 * C + c] = 0.f;
-    return;
-  }
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  coef[c] = (float)(s1 / M);
-  coef[C + c] = (float)(s2 / M);
-  coef[2 * C + c] = gamma[c] * invstd[c];
-}
+};
 
 // One launch for up to 48 weight images of the step (blockIdx.y = table entry).  kind 0 / 1: master [cout][taps][cin] fp32 ->
 // bf16 image of the channel-padded GEMM, forward [cout_p][taps][cin_p] / data gradient [cin_p][taps][cout_p], zeros outside
@@ -1437,30 +1402,18 @@ int spk_launch_slab_reduce_sub(const float* slabs, float* out, int cout, int tap
   return LAUNCH_OK();
 }
 
-static const float* bna_presum(const float* partials, int* count, int C, float* tmp, hipStream_t s) {
-  if (*count <= 128 || !tmp) return partials;
-  const int slices = 64;
-  const int rps = (*count + slices - 1) / slices;
-  hipLaunchKernelGGL(bna_presum_kernel, dim3((C + 63) / 64, slices), dim3(1024), 0, s, partials, *count, C, rps, tmp);
-  *count = slices;
-  return tmp;
-}
-
+// the ordered reductions themselves (one launch each: ordered_reduce.h)
 int spk_launch_bna_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
                             const float* beta, float* rmean, float* rvar, float* st, float eps, float momentum,
                             float* tmp, hipStream_t s) {
-  partials = bna_presum(partials, &count, C, tmp, s);
-  hipLaunchKernelGGL(bna_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, count, C, c_log, M, gamma,
-                     beta, rmean, rvar, st, eps, momentum);
-  return LAUNCH_OK();
+  const BnaFwdFin fin = {C, c_log, M, gamma, beta, rmean, rvar, st, eps, momentum};
+  return spk_reduce::reduce_finalize(partials, count, C, tmp, fin, s);
 }
 
 int spk_launch_bna_bwd_finalize(const float* partials, int count, int C, int c_log, double M, const float* gamma,
                                 const float* invstd, float* dgamma, float* dbeta, float* coef, float* tmp, hipStream_t s) {
-  partials = bna_presum(partials, &count, C, tmp, s);
-  hipLaunchKernelGGL(bna_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, count, C, c_log, M, gamma,
-                     invstd, dgamma, dbeta, coef);
-  return LAUNCH_OK();
+  const BnaBwdFin fin = {C, c_log, M, gamma, invstd, dgamma, dbeta, coef};
+  return spk_reduce::reduce_finalize(partials, count, C, tmp, fin, s);
 }
 
 int spk_launch_pack_padded_multi(const float* pbuf, bf16_t* wpack, float* dwt, const PadPackTable& t, hipStream_t s) {

@@ -10,6 +10,7 @@
 // two-stage and ordered (block partials -> fixed-order finalize), never
 // atomics, so a step is bitwise reproducible.
 #include "spk_common.h"
+#include "ordered_reduce.h"
 
 namespace {
 
@@ -26,70 +27,45 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return v;
 }
 
-// Ordered parallel sum of `count` partial rows for 64 channels at a time:
-// block = 64 channels x 16 row groups; thread (c, r) adds rows r, r+16, ...
-// (coalesced 256-B rows), then the 16 group sums are added in index order.
-// Deterministic for a given `count`.  which: 0 / 1 selects [row][which][C].
-__device__ __forceinline__ double colsum64(const float* __restrict__ partials, int count, int C,
-                                           int which, int c, int r, bool valid, double* sm) {
-  double acc = 0.0;
-  if (valid)
-    for (int t = r; t < count; t += 16) acc += (double)partials[((size_t)t * 2 + which) * C + c];
-  sm[r * 64 + (threadIdx.x & 63)] = acc;
-  __syncthreads();
-  double tot = 0.0;
-  if (r == 0)
-    for (int k = 0; k < 16; ++k) tot += sm[k * 64 + (threadIdx.x & 63)];
-  __syncthreads();
-  return tot;
-}
-
-// Stage 1 of the two-stage ordered reduction: blockIdx.y takes a contiguous
-// slice of the `count` partial rows and writes one row of out[slices][2][C].
-__global__ __launch_bounds__(1024) void partial_rows_kernel(const float* __restrict__ partials,
-                                                            int count, int C, int rows_per_slice,
-                                                            float* __restrict__ out) {
-  __shared__ double sm[16 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const bool valid = c < C;
-  const int t0 = blockIdx.y * rows_per_slice;
-  const int cnt = max(0, min(count - t0, rows_per_slice));
-  const float* base = partials + (size_t)t0 * 2 * C;
-  const double s1 = colsum64(base, cnt, C, 0, c, r, valid, sm);
-  const double s2 = colsum64(base, cnt, C, 1, c, r, valid, sm);
-  if (r == 0 && valid) {
-    out[((size_t)blockIdx.y * 2 + 0) * C + c] = (float)s1;
-    out[((size_t)blockIdx.y * 2 + 1) * C + c] = (float)s2;
-  }
-}
-
-// ---- BatchNorm forward (train) ----
+// ---- BatchNorm forward (train): what the last stage of the reduction does with a channel's two sums ----
 // partials: [m_tiles][2][C] (sum, sum of squares) written by the conv epilogue
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(
-    const float* __restrict__ partials, int m_tiles, int C, double M, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-    float* __restrict__ mean_out, float* __restrict__ invstd_out, float* __restrict__ scale,
-    float* __restrict__ shift, float eps, float momentum) {
-  __shared__ double sm[16 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const bool valid = c < C;
-  const double s1 = colsum64(partials, m_tiles, C, 0, c, r, valid, sm);
-  const double s2 = colsum64(partials, m_tiles, C, 1, c, r, valid, sm);
-  if (r != 0 || !valid) return;
-  const double mean = s1 / M;
-  double var = s2 / M - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  mean_out[c] = (float)mean;
-  invstd_out[c] = invstd;
-  const float sc = gamma[c] * invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - (float)mean * sc;
-  // running stats: unbiased variance, momentum 0.1 (torch BatchNorm2d defaults)
-  const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-  rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-  rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
-}
+struct BnFwdFin {
+  double M;
+  const float *gamma, *beta;
+  float *rmean, *rvar, *mean_out, *invstd_out, *scale, *shift;
+  float eps, momentum;
+  __device__ __forceinline__ void operator()(int c, double s1, double s2) const {
+    const double mean = s1 / M;
+    double var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    // running stats: unbiased variance, momentum 0.1 (torch BatchNorm2d defaults)
+    const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+};
+
+// ---- BatchNorm backward, stage 2: dgamma, dbeta (into the flat grad buffer when wanted) + the three per-channel
+// coefficients of the apply pass ----
+struct BnBwdFin {
+  int C;
+  double M;
+  const float *gamma, *invstd;
+  float *dgamma, *dbeta, *coef;
+  __device__ __forceinline__ void operator()(int c, double s1, double s2) const {
+    if (dbeta) dbeta[c] = (float)s1;
+    if (dgamma) dgamma[c] = (float)s2;
+    coef[c] = (float)(s1 / M);            // mean(dz)
+    coef[C + c] = (float)(s2 / M);        // mean(dz * xhat)
+    coef[2 * C + c] = gamma[c] * invstd[c];
+  }
+};
 
 // a = relu?(y*scale + shift (+ res))
 __global__ void bn_apply_kernel(const bf16_t* __restrict__ y, const float* __restrict__ scale,
@@ -172,25 +148,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int r = 0; r < rif; ++r) t += sm[(r * 2 + which) * TW + col];
     partials[((size_t)blockIdx.x * 2 + which) * C + cb * 8 + col] = t;
   }
-}
-
-// stage 2: dgamma, dbeta (into the flat grad buffer when wanted) + the two
-// per-channel coefficients of the apply pass
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(
-    const float* __restrict__ partials, int nblocks, int C, double M, const float* __restrict__ gamma,
-    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ coef) {
-  __shared__ double sm[16 * 64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), r = threadIdx.x >> 6;
-  const bool valid = c < C;
-  const double s1 = colsum64(partials, nblocks, C, 0, c, r, valid, sm);
-  const double s2 = colsum64(partials, nblocks, C, 1, c, r, valid, sm);
-  if (r != 0 || !valid) return;
-  if (dbeta) dbeta[c] = (float)s1;
-  if (dgamma) dgamma[c] = (float)s2;
-  coef[c] = (float)(s1 / M);            // mean(dz)
-  coef[C + c] = (float)(s2 / M);        // mean(dz * xhat)
-  coef[2 * C + c] = gamma[c] * invstd[c];
 }
 
 // stage 3: dy = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); the
@@ -332,6 +289,53 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ gy, const unsigned
           }
       }
     *(u32x4_t*)(gxr + (size_t)i * 8) = pack8(acc);
+  }
+}
+
+// The 3x3 / stride 2 / pad 1 form (every torchvision ResNet's stem pool), one thread per PAIR of input pixels (2a, 2a + 1)
+// of a row and 8 channels.  The pair sees window columns a (taps 1 and 2) and a + 1 (tap 0) of the one or two window rows
+// that cover input row iy - the same for every lane, so there is no divergence (the per-pixel kernel above runs all three
+// tap columns with half the lanes masked and is VALU-bound at 274 us for ResNet-50's 565 MB at batch 256) and each
+// (arg-max bytes, gradient) pair is loaded once for the two pixels.  Same sums in the same order as the per-pixel kernel.
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_pair_kernel(const bf16_t* __restrict__ gy,
+                                                                  const unsigned char* __restrict__ idx,
+                                                                  bf16_t* __restrict__ gx, int h, int w, int c, int ho, int wo) {
+  const unsigned c8 = (unsigned)c >> 3;
+  const unsigned row_items = (unsigned)(w >> 1) * c8;
+  const int img = blockIdx.x / h, iy = blockIdx.x - img * h;
+  const bf16_t* gyi = gy + (size_t)img * ho * wo * c;
+  const unsigned char* idxi = idx + (size_t)img * ho * wo * c;
+  bf16_t* gxr = gx + ((size_t)img * h + iy) * w * c;
+  // window rows over input row iy: odd iy -> rows (iy + 1) / 2 at tap row 0 and (iy - 1) / 2 at tap row 2; even -> iy / 2 at tap row 1
+  const int odd = iy & 1;
+  const int oyA = odd ? (iy + 1) >> 1 : iy >> 1, trA = odd ? 0 : 1;   // first in the per-pixel kernel's order (tap row ascending)
+  const int oyB = (iy - 1) >> 1;                                      // second (odd rows only), tap row 2
+  for (unsigned i = blockIdx.y * blockDim.x + threadIdx.x; i < row_items; i += gridDim.y * blockDim.x) {
+    const unsigned a = i / c8, cc = i - a * c8;
+    float e[8] = {0, 0, 0, 0, 0, 0, 0, 0}, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // pixels 2a and 2a + 1
+    for (int pass = 0; pass <= odd; ++pass) {
+      const int oy = pass ? oyB : oyA, tr = pass ? 2 : trA;
+      if (oy >= ho) continue;
+      const size_t o0 = (((size_t)oy * wo + a) * c8 + cc) * 8;
+      const bool has1 = (int)a + 1 < wo;
+      const size_t o1 = has1 ? o0 + (size_t)c8 * 8 : o0;
+      const u32x2_t p0 = *(const u32x2_t*)(idxi + o0), p1 = *(const u32x2_t*)(idxi + o1);
+      float g0[8], g1[8];
+      unpack8(*(const u32x4_t*)(gyi + o0), g0);
+      unpack8(*(const u32x4_t*)(gyi + o1), g1);
+      const unsigned t0 = (unsigned)(tr * 3);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned b0 = (p0[j >> 2] >> ((j & 3) * 8)) & 0xffu, b1 = (p1[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+        // per-pixel order: tap column ascending.  Even pixel 2a: window a at tap column 1.  Odd pixel 2a + 1: window a + 1 at
+        // tap column 0, then window a at tap column 2.
+        e[j] += (b0 == t0 + 1) ? g0[j] : 0.f;
+        o[j] += (has1 && b1 == t0) ? g1[j] : 0.f;
+        o[j] += (b0 == t0 + 2) ? g0[j] : 0.f;
+      }
+    }
+    *(u32x4_t*)(gxr + ((size_t)(2 * a) * c8 + cc) * 8) = pack8(e);
+    *(u32x4_t*)(gxr + ((size_t)(2 * a + 1) * c8 + cc) * 8) = pack8(o);
   }
 }
 
@@ -647,25 +651,12 @@ inline int grid_for(size_t total, int block) {
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -1)
 
-// collapses `count` partial rows to <= 64 rows in `tmp` when that pays
-static const float* presum(const float* partials, int* count, int C, float* tmp, hipStream_t s) {
-  if (*count <= 128 || !tmp) return partials;
-  const int slices = 64;
-  const int rps = (*count + slices - 1) / slices;
-  hipLaunchKernelGGL(partial_rows_kernel, dim3((C + 63) / 64, slices), dim3(1024), 0, s, partials, *count, C,
-                     rps, tmp);
-  *count = slices;
-  return tmp;
-}
-
 int spk_launch_bn_finalize(const float* partials, int m_tiles, int C, double M, const float* gamma,
                            const float* beta, float* rmean, float* rvar, float* mean, float* invstd,
                            float* scale, float* shift, float eps, float momentum, float* tmp,
                            hipStream_t s) {
-  partials = presum(partials, &m_tiles, C, tmp, s);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, partials, m_tiles, C, M,
-                     gamma, beta, rmean, rvar, mean, invstd, scale, shift, eps, momentum);
-  return LAUNCH_OK();
+  const BnFwdFin fin = {M, gamma, beta, rmean, rvar, mean, invstd, scale, shift, eps, momentum};
+  return spk_reduce::reduce_finalize(partials, m_tiles, C, tmp, fin, s);
 }
 
 int spk_launch_bn_apply(const bf16_t* y, const float* scale, const float* shift, const bf16_t* res,
@@ -698,9 +689,8 @@ int spk_launch_bn_bwd(const bf16_t* g, const unsigned char* a, const bf16_t* y, 
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb, cts), dim3(256), lds, s, g, a, y, mean, invstd, partials,
                        M, C, relu, rpb);
   }
-  const float* fin = presum(partials, &nb, C, tmp, s);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(1024), 0, s, fin, nb, C,
-                     (double)M, gamma, invstd, dgamma, dbeta, coef);
+  const BnBwdFin fin = {C, (double)M, gamma, invstd, dgamma, dbeta, coef};
+  if (spk_reduce::reduce_finalize(partials, nb, C, tmp, fin, s)) return -1;
   int arpb = 0;
   const int anb = pointwise_rows(M, C, &arpb);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(anb), dim3(256), 0, s, g, a, y, mean, invstd, coef, dy, g_res,
@@ -720,7 +710,12 @@ int spk_launch_maxpool_bwd(const bf16_t* gy, const unsigned char* idx, bf16_t* g
                            int c, int k, int stride, int pad, int ho, int wo, hipStream_t s) {
   const unsigned row_items = (unsigned)w * (c / 8);
   const dim3 grid((unsigned)n * h, std::min(65535u, (row_items + 255) / 256));
-  if (k == 3 && stride == 2 && pad == 1)
+  static const bool pair_on = !getenv("SPK_POOL_PAIR") || atoi(getenv("SPK_POOL_PAIR")) != 0;
+  if (k == 3 && stride == 2 && pad == 1 && pair_on && w % 2 == 0 && wo == w / 2 && ho == (h + 1) / 2) {
+    const unsigned items = (unsigned)(w / 2) * (c / 8);
+    hipLaunchKernelGGL(maxpool3s2_bwd_pair_kernel, dim3((unsigned)n * h, (items + 255) / 256), dim3(256), 0, s, gy, idx, gx,
+                       h, w, c, ho, wo);
+  } else if (k == 3 && stride == 2 && pad == 1)
     hipLaunchKernelGGL((maxpool_bwd_kernel<3, 2, 1>), grid, dim3(256), 0, s, gy, idx, gx, n, h, w, c, k, stride, pad, ho, wo);
   else
     hipLaunchKernelGGL((maxpool_bwd_kernel<0, 0, 0>), grid, dim3(256), 0, s, gy, idx, gx, n, h, w, c, k, stride, pad, ho, wo);

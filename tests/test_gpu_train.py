@@ -480,6 +480,46 @@ def test_training_is_bitwise_reproducible():
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
+def test_launch_forms_of_the_step_give_the_same_weights():
+    """Round 5 changed HOW two things are launched, not what they compute: the stem pool's backward handles pixel pairs, and
+    the step returns before the last weight gradient is done (the optimizer updates that tensor last, behind a join).
+    Five Adam steps of ResNet-50 at 64 x 64, batch 32, each form switched off in turn and everything on one stream: the
+    same weights and running statistics, bit for bit."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, hashlib, numpy as np, torch\n"
+        f"sys.path[:0] = [{str(root)!r}, {str(root / 'syke-pic_amd')!r}]\n"
+        "from sykepic_hip import synth\n"
+        "from sykepic_hip.net import HipNet\n"
+        "from sykepic_hip.optim import HipOptimizer\n"
+        "net = HipNet('resnet50', 10, weights=None, head=(64, 32))\n"
+        "net.reset_parameters(seed=3); net.set_seed(3)\n"
+        "for p in net.parameters(): p.requires_grad = True\n"
+        "opt = HipOptimizer(net, 'Adam', [{'params': list(net.parameters()), 'lr': 1e-3}])\n"
+        "net.train()\n"
+        "for s in range(5):\n"
+        "    x = torch.from_numpy(synth.synth_images(32, 3, 64, 64, seed=100 + s)).cuda()\n"
+        "    y = torch.from_numpy(synth.synth_labels(32, 10, seed=200 + s)).cuda()\n"
+        "    net.forward_backward(x, y); opt.step()\n"
+        "h = hashlib.sha256()\n"
+        "for k, v in sorted(net.state_dict().items()): h.update(v.cpu().numpy().tobytes())\n"
+        "print('SHA', h.hexdigest())\n")
+    seen = {}
+    for env in ({}, {"SPK_POOL_PAIR": "0"}, {"SPK_TAIL_DEFER": "0"}, {"SPK_WGRAD_STREAM": "0"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPK_TUNE_CACHE="off", SPK_AUTOTUNE="0", **env),
+                             capture_output=True, text=True, timeout=900)   # (tile choice pinned: it groups the BatchNorm partial sums)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sha = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("SHA")]
+        assert len(sha) == 1, out.stdout[-500:]
+        seen[str(env)] = sha[0]
+    assert len(set(seen.values())) == 1, seen
+
+
 def test_fresh_network_is_randomly_initialised_and_learns():
     """A HipNet built with weights=None starts from torch/torchvision's initial distributions (the
     reference's TorchVisionNet(weights=None)), reproducibly under torch.manual_seed, and a few Adam steps on one
