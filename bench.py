@@ -11,7 +11,7 @@ runs the same per-GPU batch (inference needs no collective; training
 all-reduces the flat gradient buffer over RCCL).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernels
-(the conv kernels of the forward: conv_bneck / conv_pw / conv_c3 / conv_igemm / conv_stem): algorithmic conv FLOPs / their
+(the conv kernels of the forward: conv_bneck / conv_pw / conv_pwr / conv_c3 / conv_igemm / conv_stem): algorithmic conv FLOPs / their
 HIP-event time.  The
 `cpu_baseline` leg times the oracle (torch fp32 CPU restatement of the
 reference path) on this box's host cores on a bounded sample.
@@ -75,9 +75,9 @@ def parse():
 # the sources the ResNet inference conv kernels (the roofline's dominant kernel) are built from AND the executor that
 # decides which of them run (shortcut fusion, pw / c3 routing, the split rule: all of these change the HBM bytes per
 # launch): the PMC traffic figure is re-taken when any of these changes; tools/pmc_traffic.py carries the same list
-TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_pw.hip", "conv_c3.hip", "conv_bneck.hip", "conv_stem.hip", "spk_common.h", "model.hip",
+TRAFFIC_SOURCES = ("conv_igemm.hip", "conv_pw.hip", "conv_pwr.hip", "conv_c3.hip", "conv_bneck.hip", "conv_stem.hip", "spk_common.h", "model.hip",
                    "model.h")
-CONV_KERNELS = "conv_bneck_kernel + conv_pw_kernel + conv_c3_kernel + conv_igemm_kernel + conv_stem_kernel"
+CONV_KERNELS = "conv_bneck_kernel + conv_pw_kernel + conv_pwr_kernel + conv_c3_kernel + conv_igemm_kernel + conv_stem_kernel"
 
 
 def kernel_source_sha(sources=None):

@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../sykepic_hip/libsykepic_hip.so
-SRCS="model.hip train.hip ops_abi.hip conv_igemm.hip conv_pw.hip conv_c3.hip conv_bneck.hip conv_stem.hip conv_wgrad.hip pointwise.hip effnet.hip pw_fp8.hip dwconv_lds.hip preprocess.hip augment.hip head.hip train_kernels.hip train_effnet.hip zero_sum.hip"
+SRCS="model.hip train.hip ops_abi.hip conv_igemm.hip conv_pw.hip conv_pwr.hip conv_c3.hip conv_bneck.hip conv_stem.hip conv_wgrad.hip pointwise.hip effnet.hip pw_fp8.hip dwconv_lds.hip preprocess.hip augment.hip head.hip train_kernels.hip train_effnet.hip zero_sum.hip"
 mkdir -p build
 pids=()
 for f in $SRCS; do

@@ -995,7 +995,9 @@ int spk_conv_launch(const ConvArgs& a_in, int mode, hipStream_t s, int* m_tiles_
       if (a.Cout % bn) continue;
       if (cfg == 5 && a.splitw) continue;
       if (cfg == 1 && a.Cout != 64) continue;
-      if (bm > 64 && a.M < bm * 64) continue;  // would leave most CUs idle
+      // would leave most CUs idle: fewer than 64 M tiles AND fewer than 128 blocks in all (the 7 x 7 layers of a half
+      // batch - 6272 pixels x 512 / 2048 couts - get their 128-row tiles timed: 196 / 784 blocks)
+      if (bm > 64 && a.M < bm * 64 && (long)((a.M + bm - 1) / bm) * (a.Cout / bn) < 128) continue;
       // 0 register-staged, 1 LDS-DMA, 2 register-staged persistent, 3 LDS-DMA 2-stage, 4 hybrid, 5 LDS-DMA 2-stage BK 32, 6 LDS-DMA 1 stage
       for (int dma = (cfg == 6 ? 3 : 0); dma < 7; ++dma) {
         if (dma == 2) continue;  // 5: LDS-DMA 2-stage, 32-deep K steps; 6: LDS-DMA 1 stage

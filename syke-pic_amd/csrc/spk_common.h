@@ -198,6 +198,9 @@ int spk_launch_pw_dual_prep(const float* w1, const float* w2, const float* s1, c
 // -3: no configuration fits
 int spk_conv1x1_dual_launch(const PwConvArgs& q, hipStream_t s);
 int spk_pw_launch(const PwConvArgs& a, int cfg, hipStream_t s);   // -3: this config does not fit the problem
+// conv_pwr.hip: the 1x1 kernel of the deep layers (configurations 12.. of spk_pw_launch); -3: does not fit the problem
+int spk_pwr_num_configs();
+int spk_pwr_launch(const PwConvArgs& a, int cfg, hipStream_t s);
 int spk_pw_chain_launch(const PwConvArgs& a, hipStream_t s);      // with PwConvArgs::wpz; -3: no chained kernel for this problem
 int spk_launch_pack_pw(const float* w, const float* scale, bf16_t* out, int cout, int cin, int dt, int nb, hipStream_t s);
 // eval path: the faster of the implicit GEMM (a) and conv_pw (q) for this problem, tuned once and cached

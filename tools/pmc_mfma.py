@@ -19,14 +19,14 @@ marks = [i for i in ids if "to_nhwc4" in disp[i]["name"]]
 seg = [i for i in ids if marks[-2] <= i < marks[-1]]
 agg, n = collections.defaultdict(float), 0
 for i in seg:
-    if any(k in disp[i]["name"] for k in ("conv_igemm_kernel", "conv_pw_kernel", "conv_c3_kernel", "conv_stem", "conv_bneck_kernel", "conv_btail_kernel")):
+    if any(k in disp[i]["name"] for k in ("conv_igemm_kernel", "conv_pw_kernel", "conv_pwr_kernel", "conv_c3_kernel", "conv_stem", "conv_bneck_kernel", "conv_btail_kernel")):
         n += 1
         for k, v in disp[i].items():
             if k != "name":
                 agg[k] += v
 gui = agg["GRBM_GUI_ACTIVE"] / 8.0
 out = {
-    "kernels": "conv_bneck_kernel + conv_pw_kernel + conv_c3_kernel + conv_igemm_kernel + conv_stem_kernel, one forward", "launches": n, "counters": dict(agg),
+    "kernels": "conv_bneck_kernel + conv_pw_kernel + conv_pwr_kernel + conv_c3_kernel + conv_igemm_kernel + conv_stem_kernel, one forward", "launches": n, "counters": dict(agg),
     "gpu_active_cycles": gui,
     "mfma_util": agg["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui * 256 * 4),
     "wave_cycles_split": {"wait_any (s_waitcnt / barrier)": agg["SQ_WAIT_ANY"] / agg["SQ_WAVE_CYCLES"],

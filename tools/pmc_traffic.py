@@ -20,7 +20,7 @@ sys.path.insert(0, str(ROOT))
 import bench  # noqa: E402  (TRAFFIC_SOURCES / TRAIN_SOURCES: the figure is quoted only for the sources it was taken on)
 
 SOURCES = {"infer": bench.TRAFFIC_SOURCES, "train": bench.TRAIN_SOURCES}
-KERNELS = {"infer": ("conv_igemm_kernel", "conv_pw_kernel", "conv_c3_kernel", "conv_stem_kernel", "conv_bneck_kernel", "conv_btail_kernel"),
+KERNELS = {"infer": ("conv_igemm_kernel", "conv_pw_kernel", "conv_pwr_kernel", "conv_c3_kernel", "conv_stem_kernel", "conv_bneck_kernel", "conv_btail_kernel"),
            "train": ("conv_igemm_kernel", "conv_wgrad_kernel", "conv_stem_kernel")}
 
 
