@@ -348,6 +348,16 @@ int spk_op_bottleneck(const void* x_dev, const float* w1_dev, const float* w2_de
 int spk_op_conv1x1_chain(const void* x, const float* w, const float* bn_scale, const float* bn_bias, const void* res,
                          void* y, const float* wz, const float* bnz_scale, const float* bnz_bias, void* z, int n, int h,
                          int wd, int cin, int cout, int coutz, int relu, int reluz, void* stream);
+/* A block-closing 1x1 conv and the block's 1x1 shortcut (downsample) conv as ONE K-concatenated GEMM (round 3,
+ * csrc/conv_pw.hip / conv_pwr.hip, PwConvArgs::x2): y = act(BN1(W1 . x) + BN2(W2 . x2[stride2])) - what the eval path
+ * runs in the first block of every ResNet stage (torchvision Bottleneck.forward with `downsample`, reached through
+ * `net(x)`: sykepic/compute/probability.py:189).  x [n,ho,wo,cin], x2 [n,h2,w2,cin2], y [n,ho,wo,cout] NHWC fp16 on the
+ * device; weights fp32 [cout][cin] / [cout][cin2]; s / b: the folded eval-BatchNorm scale and shift of each conv.
+ * cfg: a configuration of the 1x1 kernels, 0 .. spk_op_conv1x1_num_configs() - 1 (SPK_ERR_UNSUPPORTED when it does not
+ * fit the problem); every configuration gives the same bits. */
+int spk_op_conv1x1_dual(const void* x, const float* w1, const float* s1, const float* b1, const void* x2, const float* w2,
+                        const float* s2, const float* b2, void* y, int n, int ho, int wo, int cin, int h2, int w2d, int cin2,
+                        int cout, int stride2, int relu, int split, int cfg, void* stream);
 /* Zero-sum rounding (csrc/zero_sum.hip) of fp32 weight rows on caller-provided DEVICE buffers: w, out [rows][row_len],
  * mu [mu_period] (element k weighted with mu[k % mu_period]) or NULL (all ones).  out[i] is fp16(w[i]) or the fp16
  * neighbour on the other side of w[i]; per row sum_k mu_k (out_k - w_k) is driven to ~0.  Synchronises the stream. */

@@ -575,7 +575,7 @@ int launch_res(const PwConvArgs& a, hipStream_t s) {
 }
 
 // candidate table (index = cfg id).  BN = 32*NPAIR couts, BM = WAVES*MT*16 pixels.
-constexpr int kNumCfgs = 16;   // 12-15: the LDS-ring kernel of the deep layers (conv_pwr.hip)
+constexpr int kNumCfgs = 18;   // 12-17: the LDS-ring kernel of the deep layers (conv_pwr.hip)
 template <int DT, int NB>
 int launch_cfg(const PwConvArgs& a, int cfg, hipStream_t s) {
   switch (cfg) {
@@ -591,7 +591,7 @@ int launch_cfg(const PwConvArgs& a, int cfg, hipStream_t s) {
     case 9: return launch_res<DT, NB, 2, 2, 8, 16>(a, s);    // resident 256 x 64 (K <= 512)
     case 10: return launch_res<DT, NB, 4, 2, 8, 4>(a, s);    // resident 512 x 64 (K <= 128)
     case 11: return launch_res<DT, NB, 2, 4, 4, 8>(a, s);    // resident 128 x 128, 4 waves (two blocks per CU)
-    case 12: case 13: case 14: case 15:                      // activations through an LDS ring, weights straight from L2
+    case 12: case 13: case 14: case 15: case 16: case 17:    // activations through an LDS ring, weights straight from L2
       return (DT == DT_F16 && NB == 1) ? spk_pwr_launch(a, cfg - 12, s) : -3;
     default: return -3;
   }

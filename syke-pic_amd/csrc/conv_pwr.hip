@@ -10,10 +10,12 @@
 // rate: tools/micro/mfma_shape.hip).  This kernel is phase 1 of conv_bneck.hip on its own:
 //   * 8 waves, two per SIMD; a wave owns 64 couts (two 32-cout pairs) x MT pixel tiles, the block BN = 64 WN couts x
 //     BM = 16 MT (8 / WN) pixels;
-//   * the ACTIVATIONS stream through a three-stage LDS ring in 64-channel chunks by LDS-DMA (128-byte rows, 16-byte
-//     chunks XOR-swizzled at the source), one barrier per chunk, each fragment read feeds four MFMAs;
+//   * the ACTIVATIONS stream through an LDS ring in 64-channel chunks by LDS-DMA (128-byte rows, 16-byte chunks
+//     XOR-swizzled at the source), one barrier per chunk, each fragment read feeds four MFMAs;
 //   * the WEIGHTS come straight from L2 into MFMA operand registers in fragment order (pack_pw_kernel's image): no LDS
 //     traffic and no barrier for them, each byte is loaded once per wave that owns its couts;
+//   * both run D = 2-3 chunks AHEAD of the MFMAs (phase 1 of conv_bneck.hip fetches a chunk's weights one chunk ahead:
+//     0.4-0.75 us of MFMAs against an L2 round trip of ~1 us under load - it waits at the top of every chunk);
 //   * swapped operand roles and the permuted couts of conv_pw.hip: the epilogue runs from registers.
 // K order (32-deep steps ascending) and the fp32 epilogue are those of conv_pw.hip / conv_igemm.hip: bit-identical
 // results (tests/test_gpu_pw.py runs every configuration against the others), so the tuner's choice never shows.
@@ -47,23 +49,26 @@ __device__ __forceinline__ u32x4_t buffer_load_b128_untracked(u32x4_t rsrc, unsi
   return d;
 }
 
-template <int MT_, int WN_>
+template <int MT_, int WN_, int D_>
 struct PwrCfg {
-  static constexpr int MT = MT_, WN = WN_, NW = 8, WM = NW / WN;
+  static constexpr int MT = MT_, WN = WN_, D = D_, NW = 8, WM = NW / WN;   // D: chunks the memory system runs ahead of the MFMAs
   static constexpr int BM = 16 * MT * WM, BN = 64 * WN;
   static constexpr int DI = (BM / 8 + NW - 1) / NW;       // LDS-DMA instructions (8 rows x 128 B) per wave and chunk
   static constexpr int XSTAGE = DI * NW * 1024;
-  static constexpr int NXS = 3;                            // ring stages
+  static constexpr int NXS = D + 1;                        // ring stages
   static constexpr int LDS = NXS * XSTAGE + 2 * BN * 4;    // + [BN] scale, [BN] shift
   static constexpr int DEPTH = 4;                          // activation fragments in flight (ring of registers)
   static_assert(NW % WN == 0, "waves");
-  static_assert(2 * MT >= 2 + DI, "a chunk has fewer MFMA groups than memory instructions to place between them");
+  static_assert(2 * MT >= DI, "a chunk has fewer MFMA groups than LDS-DMA instructions to place between them");
+  static_assert((D - 1) * (DI + 8) <= 63 && D >= 1 && D <= 3, "vmcnt is a 6-bit counter");
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-template <int MT, int WN, bool HAS_RES>
+// DUAL: K-concatenated second activation source (PwConvArgs::x2: a block-closing conv and the block's 1x1 shortcut conv as
+// one GEMM, conv_pw.hip): chunks from Cin / 64 on stream from x2 at the output pixel's position under stride2.
+template <int MT, int WN, int D, bool HAS_RES, bool DUAL>
 __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_tiles, int n_tiles) {
-  using K = PwrCfg<MT, WN>;
+  using K = PwrCfg<MT, WN, D>;
   constexpr int NW = K::NW, BM = K::BM, BN = K::BN, DI = K::DI, XSTAGE = K::XSTAGE, NXS = K::NXS, DEPTH = K::DEPTH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -79,9 +84,11 @@ __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_ti
   const int nt = swz % n_tiles, mt = swz / n_tiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int Cin = a.Cin, Cout = a.Cout;
-  const int NCH = Cin >> 6;                                // 64-channel chunks (even: the host checks Cin % 128)
+  const int nch1 = Cin >> 6;                               // 64-channel chunks of the first source
+  const int NCH = DUAL ? (Cin + a.Cin2) >> 6 : nch1;       // ... in all (even: the host checks)
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? a.x2 : a.x), 0, DUAL ? a.x2_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, a.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_RES ? a.res : a.y), 0, HAS_RES ? a.y_bytes : 0, 0x00020000);
 
@@ -94,22 +101,29 @@ __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_ti
 
   // LDS-DMA of one 64-channel chunk: instruction ii = wave + NW i covers tile rows 8 ii .. 8 ii + 7; lane l lands in row
   // l / 8, slot l % 8 and therefore fetches the chunk whose swizzled slot that is
-  unsigned voff[DI];
+  unsigned voff[DI], voff2[DUAL ? DI : 1];
 #pragma unroll
   for (int i = 0; i < DI; ++i) {
     const int row = 8 * (wave + NW * i) + (lane >> 3);
     const int gm = m0 + row;
-    voff[i] = (row < BM && gm < a.M) ? (unsigned)gm * (unsigned)(Cin * 2) + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4) : 0x80000000u;
+    const bool ok = row < BM && gm < a.M;
+    const unsigned slot = (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    voff[i] = ok ? (unsigned)gm * (unsigned)(Cin * 2) + slot : 0x80000000u;
+    if (DUAL) {
+      const int hw = a.Ho * a.Wo, img = gm / hw, rem = gm - img * hw, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+      const int px2 = (img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2;
+      voff2[i] = ok ? (unsigned)px2 * (unsigned)(a.Cin2 * 2) + slot : 0x80000000u;
+    }
   }
+  // (the casts of the vector offsets: hipcc 7.2's host pass drops the kernel when an lvalue array element is passed there)
+  auto dma_piece = [&](int c, int stage, int i) {
+    lds_ptr_t dst = (lds_ptr_t)(ring + stage * XSTAGE + (wave + NW * i) * 1024);
+    if (DUAL && c >= nch1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx2, dst, 16, (unsigned)voff2[DUAL ? i : 0], (c - nch1) * 128, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, dst, 16, (unsigned)voff[i], c * 128, 0, 0);
+  };
   auto dma = [&](int c, int stage) {
 #pragma unroll
-    for (int i = 0; i < DI; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(ring + stage * XSTAGE + (wave + NW * i) * 1024), 16, (unsigned)voff[i],   // (the cast: hipcc 7.2's host pass drops the kernel when an lvalue array element is passed here)
-                                               c * 128, 0, 0);
-  };
-  auto dma_piece = [&](int c, int stage, int i) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(ring + stage * XSTAGE + (wave + NW * i) * 1024), 16, (unsigned)voff[i],
-                                             c * 128, 0, 0);
+    for (int i = 0; i < DI; ++i) dma_piece(c, stage, i);
   };
   // activation fragment of pixel tile j, K step ks of a chunk: row 16 (wm MT + j) + p, chunk 4 ks + g, swizzled
   // ((row >> 1) & 7 == (p >> 1) & 7: tiles start on multiples of 16; K step 1 = the byte offset xor 64)
@@ -118,8 +132,13 @@ __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_ti
   const unsigned w_lane = (unsigned)(n0 / 32 + 2 * wn) * 2048 + lane * 16;
   const unsigned kstep_bytes = (unsigned)Cout * 64;        // one 32-deep K step of the whole image
   const unsigned long long wpp = (unsigned long long)a.wp;
-  const u32x4_t rws = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)Cin * (unsigned)Cout * 2u, 0x00020000u};
-  u32x4_t wa[2][2][4];   // [chunk parity][ks][tile of the wave's 64 couts]
+  const u32x4_t rws = {(unsigned)wpp, (unsigned)(wpp >> 32) & 0xffffu, (unsigned)NCH * 64u * (unsigned)Cout * 2u, 0x00020000u};
+  // Weight fragments of chunk k live in set k % D: [ks][tile of the wave's 64 couts].  The memory system runs D chunks ahead
+  // of the MFMAs: while chunk k is multiplied, the LDS-DMA pieces of chunk k + D are issued between its first MFMA groups
+  // and the weight fragments of chunk k + D are loaded INTO chunk k's own registers, each half right behind its last use
+  // (K step 0 after MFMA group MT - 1, K step 1 after the last group) - D sets, not D + 1.  With D = 1 a wave waits for
+  // its weights at the top of every chunk: a chunk is 0.4-0.75 us of MFMAs, an L2 round trip under load about 1 us.
+  u32x4_t wa[D][2][4];
   auto load_w_ks = [&](u32x4_t (&d)[2][4], int c, int ks) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) d[ks][t] = buffer_load_b128_untracked(rws, w_lane, (unsigned)(2 * c + ks) * kstep_bytes, t * 1024);
@@ -130,20 +149,26 @@ __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_ti
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  load_w_ks(wa[0], 0, 0);
-  load_w_ks(wa[0], 0, 1);
-  dma(0, 0);
-  dma(1, 1);   // NCH >= 2
-  int st_cur = 0, st_fill = 2;   // ring stage of chunk c / of chunk c + 2
-  auto chunk = [&](int c, const u32x4_t (&w)[2][4], u32x4_t (&wnext)[2][4]) {
-    // this wave's pieces of chunk c have landed once at most the next chunk's DMAs are outstanding; the barrier publishes
-    // everyone's pieces and proves everyone is done with chunk c - 1, whose stage is refilled at once.  The chunk's weight
-    // fragments - requested one chunk ago, BEFORE the DMAs that may still be in flight - are complete here too.
-    if (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI) : "memory");
+  // prologue: chunks 0 .. D - 1 in flight, each as [LDS-DMA pieces, weight fragments] - the order of every later chunk
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+    if (k < NCH) {
+      dma(k, k);
+      load_w_ks(wa[k], k, 0);
+      load_w_ks(wa[k], k, 1);
+    }
+  int st_cur = 0, st_fill = D;   // ring stage of chunk c / of chunk c + D
+  auto chunk = [&](int c, u32x4_t (&w)[2][4]) {
+    // Chunk c's pieces and fragments have landed once only what was issued after them is outstanding: vmcnt retires in
+    // issue order and every later chunk j in (c, c + D) put DI + 8 operations behind them - as many as exist.  The barrier
+    // publishes everyone's pieces and proves everyone is done with chunk c - 1, whose stage is refilled at once.
+    const int newer = NCH - 1 - c;
+    if (D >= 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DI + 8)) : "memory");
+    else if (D >= 2 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI + 8) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const bool more_w = c + 1 < NCH, more_x = c + 2 < NCH;
+    const bool more = c + D < NCH;
     lds_u8_t xb0 = (lds_u8_t)ring + st_cur * XSTAGE + xlane;
     lds_u8_t xb1 = (lds_u8_t)ring + st_cur * XSTAGE + (xlane ^ 64u);
     asm volatile("" : "+v"(xb0), "+v"(xb1));
@@ -162,21 +187,20 @@ __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_ti
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(w[ks][t], fr[u % DEPTH], acc[j][t]);
       __builtin_amdgcn_sched_barrier(0);
-      // the next chunk's weight fragments, then the DMA pieces of chunk c + 2, between the MFMA groups (order: weights
-      // first - it is what the s_waitcnt at the top counts on)
-      if (u < 2) {
-        if (more_w) load_w_ks(wnext, c + 1, u);
-      } else if (u < 2 + DI) {
-        if (more_x) dma_piece(c + 2, st_fill, u - 2);
+      if (more) {
+        if (u < DI) dma_piece(c + D, st_fill, u);
+        if (u == MT - 1) load_w_ks(w, c + D, 0);
+        if (u == UNITS - 1) load_w_ks(w, c + D, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     st_cur = st_cur == NXS - 1 ? 0 : st_cur + 1;
     st_fill = st_fill == NXS - 1 ? 0 : st_fill + 1;
   };
-  for (int c = 0; c < NCH; c += 2) {
-    chunk(c, wa[0], wa[1]);
-    chunk(c + 1, wa[1], wa[0]);
+  for (int c = 0; c < NCH; c += D) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      if (c + i < NCH) chunk(c + i, wa[i]);
   }
   // every untracked load has been waited for by the last chunk's s_waitcnt vmcnt(0) (no dead load past the last chunk:
   // the compiler re-uses those registers from here on)
@@ -233,38 +257,44 @@ __global__ __launch_bounds__(512, 2) void conv_pwr_kernel(PwConvArgs a, int m_ti
   }
 }
 
-template <int MT, int WN>
+template <int MT, int WN, int D, bool HAS_RES, bool DUAL>
+int launch_k(const PwConvArgs& a, hipStream_t s, int m_tiles, int n_tiles) {
+  using K = PwrCfg<MT, WN, D>;
+  auto k = conv_pwr_kernel<MT, WN, D, HAS_RES, DUAL>;
+  static std::atomic<unsigned long long> attr;
+  (void)spk_lds_limit_once(attr, (const void*)k, K::LDS);
+  hipLaunchKernelGGL(k, dim3(m_tiles * n_tiles), dim3(512), K::LDS, s, a, m_tiles, n_tiles);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+template <int MT, int WN, int D>
 int launch(const PwConvArgs& a, hipStream_t s) {
-  using K = PwrCfg<MT, WN>;
+  using K = PwrCfg<MT, WN, D>;
   if (a.Cout % K::BN) return -3;
   const int m_tiles = (a.M + K::BM - 1) / K::BM, n_tiles = a.Cout / K::BN;
-  static std::atomic<unsigned long long> attr_r, attr_n;
-  if (a.res) {
-    auto k = conv_pwr_kernel<MT, WN, true>;
-    (void)spk_lds_limit_once(attr_r, (const void*)k, K::LDS);
-    hipLaunchKernelGGL(k, dim3(m_tiles * n_tiles), dim3(512), K::LDS, s, a, m_tiles, n_tiles);
-  } else {
-    auto k = conv_pwr_kernel<MT, WN, false>;
-    (void)spk_lds_limit_once(attr_n, (const void*)k, K::LDS);
-    hipLaunchKernelGGL(k, dim3(m_tiles * n_tiles), dim3(512), K::LDS, s, a, m_tiles, n_tiles);
-  }
-  return hipGetLastError() == hipSuccess ? 0 : -1;
+  if (a.x2) return a.res ? -3 : launch_k<MT, WN, D, false, true>(a, s, m_tiles, n_tiles);   // (the fused shortcut conv IS the shortcut)
+  return a.res ? launch_k<MT, WN, D, true, false>(a, s, m_tiles, n_tiles) : launch_k<MT, WN, D, false, false>(a, s, m_tiles, n_tiles);
 }
 
 }  // namespace
 
-int spk_pwr_num_configs() { return 4; }
+int spk_pwr_num_configs() { return 6; }
 
 // 0 ok, -1 HIP error, -3 this configuration does not fit the problem.  Plain fp16 1x1 convs of stride 1 with one weight
-// image and one activation source; K a multiple of 128.
+// image; an optional second activation source (any stride); K a multiple of 128 in all.
 int spk_pwr_launch(const PwConvArgs& a, int cfg, hipStream_t s) {
-  if (a.dt != DT_F16 || a.nb != 1 || a.x2 || a.wpz || a.stride != 1 || a.Cin % 128 || a.Cin < 256 || a.Cout % 256 || a.M <= 0) return -3;
+  if (a.dt != DT_F16 || a.nb != 1 || a.wpz || a.stride != 1 || a.Cin % 64 || a.Cout % 256 || a.M <= 0) return -3;
+  const int K = a.Cin + (a.x2 ? a.Cin2 : 0);
+  if (K % 128 || K < 256) return -3;
+  if (a.x2 && (a.Cin2 % 64 || (size_t)a.x2_bytes >= 0x80000000ull)) return -3;
   if ((size_t)a.y_bytes >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull) return -3;
   switch (cfg) {
-    case 0: return launch<7, 8>(a, s);    // 112 pixels x 512 couts
-    case 1: return launch<4, 8>(a, s);    //  64 x 512
-    case 2: return launch<6, 4>(a, s);    // 192 x 256 (7 tiles per wave: 256 VGPRs and spills - the untracked loads forbid that)
-    case 3: return launch<4, 4>(a, s);    // 128 x 256
+    case 0: return launch<7, 8, 2>(a, s);    // 112 pixels x 512 couts
+    case 1: return launch<4, 8, 3>(a, s);    //  64 x 512, three chunks ahead (short chunks)
+    case 2: return launch<6, 4, 2>(a, s);    // 192 x 256 (7 tiles per wave: 256 VGPRs and spills - the untracked loads forbid that)
+    case 3: return launch<4, 4, 3>(a, s);    // 128 x 256
+    case 4: return launch<7, 8, 3>(a, s);    // 112 x 512, three chunks ahead
+    case 5: return launch<5, 8, 3>(a, s);    //  80 x 512
     default: return -3;
   }
 }

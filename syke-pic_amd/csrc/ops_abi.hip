@@ -283,6 +283,45 @@ extern "C" int spk_op_conv1x1(const void* x, const float* w, const float* bn_sca
 }
 extern "C" int spk_op_conv1x1_num_configs(void) { return spk_pw_num_configs(); }
 
+// A block-closing 1x1 conv and the block's 1x1 shortcut (downsample) conv as ONE K-concatenated GEMM (PwConvArgs::x2):
+// y = act(BN1(W1 . x) + BN2(W2 . x2[stride2])), what the eval path runs in the first block of a ResNet stage.  The two
+// eval-BatchNorm scales are folded into the concatenated fp16 weight rows (spk_launch_pw_dual_prep).  cfg: a configuration
+// of spk_pw_launch (SPK_ERR_UNSUPPORTED when it does not fit the problem).
+extern "C" int spk_op_conv1x1_dual(const void* x, const float* w1, const float* s1, const float* b1, const void* x2,
+                                   const float* w2, const float* s2, const float* b2, void* y, int n, int ho, int wo, int cin,
+                                   int h2, int w2d, int cin2, int cout, int stride2, int relu, int split, int cfg,
+                                   void* stream) {
+  if (!x || !w1 || !s1 || !b1 || !x2 || !w2 || !s2 || !b2 || !y || n < 1 || ho < 1 || wo < 1 || stride2 < 1)
+    return ofail(SPK_ERR_ARG, "op_conv1x1_dual: bad arguments");
+  if (cin % 64 || cin2 % 64 || cout % 64) return ofail(SPK_ERR_UNSUPPORTED, "channels must be multiples of 64");
+  if ((ho - 1) * stride2 >= h2 || (wo - 1) * stride2 >= w2d) return ofail(SPK_ERR_ARG, "op_conv1x1_dual: second source too small");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = n * ho * wo, K = cin + cin2;
+  if ((size_t)M * cin * 2 >= 0x80000000ull || (size_t)n * h2 * w2d * cin2 * 2 >= 0x80000000ull || (size_t)M * cout * 2 >= 0x80000000ull)
+    return ofail(SPK_ERR_UNSUPPORTED, "op_conv1x1_dual: an operand of 2 GiB or more");
+  Scratch sc;
+  float* wcat = sc.get<float>((size_t)cout * K);
+  float* sb = sc.get<float>((size_t)2 * cout);
+  bf16_t* wp = sc.get<bf16_t>((size_t)2 * cout * K);
+  if (!wcat || !sb || !wp) return ofail(SPK_ERR_HIP, "hipMalloc failed");
+  O_TRY(spk_launch_pw_dual_prep(w1, w2, s1, s2, b1, b2, wcat, sb, sb + cout, cout, cin, cin2, s), "pw_dual_prep");
+  O_TRY(spk_launch_pack_pw(wcat, nullptr, wp, cout, K, DT_F16, split ? 2 : 1, s), "pack_pw");
+  PwConvArgs q;
+  memset(&q, 0, sizeof q);
+  q.x = (const bf16_t*)x; q.wp = wp; q.y = (bf16_t*)y; q.scale = sb; q.shift = sb + cout;
+  q.N = n; q.H = ho; q.W = wo; q.Ho = ho; q.Wo = wo; q.stride = 1; q.Cin = cin; q.Cout = cout; q.M = M;
+  q.relu = relu; q.dt = DT_F16; q.nb = split ? 2 : 1;
+  q.x_bytes = (unsigned)((size_t)M * cin * 2);
+  q.y_bytes = (unsigned)((size_t)M * cout * 2);
+  q.x2 = (const bf16_t*)x2; q.Cin2 = cin2; q.H2 = h2; q.W2 = w2d; q.stride2 = stride2;
+  q.x2_bytes = (unsigned)((size_t)n * h2 * w2d * cin2 * 2);
+  const int r = spk_pw_launch(q, cfg, s);
+  if (r == -3) return ofail(SPK_ERR_UNSUPPORTED, "this configuration does not fit the problem");
+  if (r) return ofail(SPK_ERR_HIP, "dual conv1x1 launch failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return ofail(SPK_ERR_HIP, "dual conv1x1 kernel failed");
+  return SPK_OK;
+}
+
 // Two chained 1x1 convs in one launch (conv_pw.hip, PwConvArgs::wpz): y = act(BN(W . x) + res) with 256 couts, then
 // z = actz(BNz(Wz . y)) from the output tile in registers; single fp16 weight images.  What the eval path runs for a
 // bottleneck's block-closing conv and the next block's first conv.  SPK_ERR_UNSUPPORTED: no chained kernel for the shape.

@@ -77,6 +77,7 @@ SYMBOLS = {
     "spk_model_set_zero_sum": (C.c_int, [_P, C.c_int]),
     "spk_op_conv_dgrad_bn_backward": (C.c_int, [_P, _P, _P, C.c_int] + [_P] * 8 + [C.c_int] * 8 + [_P, _P, _P]),
     "spk_op_conv1x1_chain": (C.c_int, [_P] * 10 + [C.c_int] * 8 + [_P]),
+    "spk_op_conv1x1_dual": (C.c_int, [_P] * 9 + [C.c_int] * 12 + [_P]),
     "spk_op_zero_sum_round": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "spk_model_set_fp8": (C.c_int, [_P, C.c_int]),
     "spk_model_calibrate_fp8": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

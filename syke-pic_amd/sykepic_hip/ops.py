@@ -232,6 +232,28 @@ def conv1x1_chain(x, weight, bn_scale, bn_bias, res, weight_z, bnz_scale, bnz_bi
     return y.permute(0, 3, 1, 2), z.permute(0, 3, 1, 2)
 
 
+def conv1x1_dual(x, w1, bn1_scale, bn1_bias, x2, w2, bn2_scale, bn2_bias, stride2=2, relu=True, split=False, cfg=0):
+    """A block-closing 1x1 conv and the block's 1x1 shortcut conv as one K-concatenated GEMM (spk_op_conv1x1_dual):
+    act(BN1(W1 . x) + BN2(W2 . x2[::stride2, ::stride2])).  x [N,Cin,Ho,Wo], x2 [N,Cin2,H2,W2] float16; returns
+    [N,Cout,Ho,Wo] float16.  Raises RuntimeError "does not fit" when `cfg` cannot run the problem."""
+    so = lib.load()
+    dev = x.device
+    n, cin, ho, wo = x.shape
+    _, cin2, h2, w2d = x2.shape
+    cout = w1.shape[0]
+    xh = x.half().permute(0, 2, 3, 1).contiguous()
+    x2h = x2.half().permute(0, 2, 3, 1).contiguous()
+    y = torch.full((n, ho, wo, cout), float("nan"), dtype=torch.float16, device=dev)
+    f = lambda t: t.float().contiguous()   # noqa: E731
+    w1k, w2k = f(w1.reshape(cout, cin)), f(w2.reshape(cout, cin2))
+    s1, b1, s2, b2 = f(bn1_scale), f(bn1_bias), f(bn2_scale), f(bn2_bias)
+    with torch.cuda.device(dev):
+        lib.check(so.spk_op_conv1x1_dual(_p(xh), _p(w1k), _p(s1), _p(b1), _p(x2h), _p(w2k), _p(s2), _p(b2), _p(y), n, ho, wo,
+                                         cin, h2, w2d, cin2, cout, int(stride2), int(bool(relu)), int(bool(split)), int(cfg),
+                                         _stream(dev)))
+    return y.permute(0, 3, 1, 2)
+
+
 def conv3x3_num_configs():
     return int(lib.load().spk_op_conv3x3_num_configs())
 

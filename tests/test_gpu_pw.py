@@ -115,3 +115,52 @@ def test_chained_pair_equals_two_launches(shape):
     assert torch.equal(z, z1)
     err = (y.float().cpu() - ref).abs()
     assert (err <= 8e-3 + 6e-3 * ref.abs()).all()
+
+
+DUAL_SHAPES = [
+    # n, ho, wo, cin (block-closing conv), cin2 (shortcut conv), cout, stride2     (ResNet-50's four stage openers, scaled down)
+    (2, 56, 56, 64, 64, 256, 1),
+    (3, 28, 28, 128, 256, 512, 2),
+    (5, 14, 14, 256, 512, 1024, 2),
+    (7, 7, 7, 512, 1024, 2048, 2),
+    (2, 13, 9, 256, 256, 512, 2),           # ragged pixel count, odd second source (25 x 17)
+]
+
+
+@pytest.mark.parametrize("shape", DUAL_SHAPES, ids=lambda s: "n%d_%dx%d_c%d+%d-%d_s%d" % s)
+def test_every_configuration_of_the_fused_shortcut_conv_agrees(shape):
+    """The block-closing conv + shortcut conv as one K-concatenated GEMM (PwConvArgs::x2) on every configuration that fits
+    - conv_pw.hip's and, for the deep stages, conv_pwr.hip's: within fp16 output rounding of the fp32 chain, and the same
+    bits from all of them (the tuner's choice must not show)."""
+    from sykepic_hip import ops
+    n, ho, wo, cin, cin2, cout, s2 = shape
+    g = torch.Generator().manual_seed(cin * 3 + cin2)
+    h2, w2 = (ho - 1) * s2 + 1 + (s2 - 1), (wo - 1) * s2 + 1          # (rows: one spare line under stride 2)
+    x = torch.relu(torch.randn(n, cin, ho, wo, generator=g)).half()
+    x2 = torch.relu(torch.randn(n, cin2, h2, w2, generator=g)).half()
+    w1 = (torch.rand(cout, cin, generator=g) * 2 - 1) * (6.0 / cin) ** 0.5
+    w2_ = (torch.rand(cout, cin2, generator=g) * 2 - 1) * (6.0 / cin2) ** 0.5
+    sc1, sc2 = 0.5 + torch.rand(cout, generator=g), 0.5 + torch.rand(cout, generator=g)
+    b1, b2 = torch.rand(cout, generator=g) - 0.5, torch.rand(cout, generator=g) - 0.5
+    F = torch.nn.functional
+    ref = F.conv2d(x.float(), w1[:, :, None, None]) * sc1[None, :, None, None] + b1[None, :, None, None]
+    ref = ref + F.conv2d(x2.float(), w2_[:, :, None, None], stride=s2)[:, :, :ho, :wo] * sc2[None, :, None, None] + b2[None, :, None, None]
+    ref = torch.relu(ref)
+    dev = "cuda:0"
+    outs = []
+    for cfg in range(ops.conv1x1_num_configs()):
+        try:
+            y = ops.conv1x1_dual(x.to(dev), w1.to(dev), sc1.to(dev), b1.to(dev), x2.to(dev), w2_.to(dev), sc2.to(dev), b2.to(dev),
+                                 stride2=s2, relu=True, split=False, cfg=cfg)
+        except RuntimeError as e:
+            assert "does not fit" in str(e), str(e)
+            continue
+        y = y.float().cpu()
+        assert torch.isfinite(y).all(), f"cfg {cfg}: an output element was never written"
+        err = (y - ref).abs()
+        bound = 8e-3 + 6e-3 * ref.abs()      # plain fp16 weights with the BatchNorm scales folded in (as the `plain` rows above)
+        assert (err <= bound).all(), (cfg, float(err.max()), int((err > bound).sum()))
+        outs.append((cfg, y))
+    assert len(outs) >= 2, [c for c, _ in outs]
+    for cfg, y in outs[1:]:
+        assert torch.equal(y, outs[0][1]), f"cfg {cfg} differs from cfg {outs[0][0]}"
