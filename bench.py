@@ -101,7 +101,7 @@ def train_traffic(args):
 
 
 TRAIN_SOURCES = ("conv_igemm.hip", "conv_wgrad.hip", "conv_stem.hip", "spk_common.h", "train.hip", "train_kernels.hip",
-                 "model.h")
+                 "ordered_reduce.h", "model.h")
 
 
 def cpu_model():

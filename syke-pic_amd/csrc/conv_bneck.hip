@@ -218,24 +218,33 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[j][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    load_w(wa[0], 0);
-    dma(0, 0);
-    if (NXS == 3) dma(1, 1);
-    auto chunk = [&](int c, const u32x4_t (&w)[2][4], u32x4_t (&wnext)[2][4]) {
-      // this wave's pieces of chunk c have landed once at most the next chunk's DMAs are outstanding; the barrier
-      // publishes everyone's pieces and proves everyone is done with chunk c - 1, whose stage is refilled at once
-      if (NXS == 3 && c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI) : "memory");
+    // Three ring stages (the 8-wave form): the memory system runs TWO chunks ahead of the MFMAs for both operands.  The weight
+    // fragments of chunk c + 2 are loaded into chunk c's own registers, each half right behind its last use (K step 0 after
+    // MFMA group MT1 - 1, K step 1 after the last group): two sets, as before, but a full chunk more of lead - with one chunk
+    // (0.4-0.75 us of MFMAs against an L2 round trip of ~1 us under load) every wave waited for its weights at the top of
+    // every chunk (conv_pwr.hip, where this was measured: 47.9 -> 43.6 us on the 14 x 14 stage opener).  Two stages (the
+    // 4-wave form): plain loads one chunk ahead, every wait is vmcnt(0).
+    if (NXS == 3) {
+      dma(0, 0);
+      load_w(wa[0], 0);
+      dma(1, 1);
+      load_w(wa[1], 1);
+    } else {
+      load_w(wa[0], 0);
+      dma(0, 0);
+    }
+    auto chunk = [&](int c, u32x4_t (&w)[2][4], u32x4_t (&wnext)[2][4]) {
+      // Chunk c's pieces and fragments have landed once only what was issued after them is outstanding (vmcnt retires in
+      // issue order): with three stages that is chunk c + 1's DI pieces and 8 fragment loads - if there is a chunk c + 1.
+      // The barrier publishes everyone's pieces and proves everyone is done with chunk c - 1, whose stage is refilled at once.
+      if (NXS == 3 && c + 1 < NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DI + 8) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // (the chunk's weight fragments - requested one chunk ago, BEFORE the DMAs that may still be in flight - are complete
-      // here too: buffer_load_b128_untracked)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      // The next chunk's weight fragments and the DMA pieces of chunk c + NXS - 1 are issued BETWEEN the MFMA groups below, a
-      // few per group (an MFMA holds the issue port for half of its 16 cycles): issued here in one go they cost every wave
-      // ~0.5 k cycles per chunk in front of its first MFMA, in step on all waves of the CU.  Order as before - weights, then
-      // DMA pieces - which is what the s_waitcnt at the top counts on.  (No dead load past the last chunk: nothing would
-      // ever wait for it - see below the loop.)
-      const bool more_w = c + 1 < NCH, more_x = c + NXS - 1 < NCH;
+      // Memory instructions are issued BETWEEN the MFMA groups below, a few per group (an MFMA holds the issue port for half of
+      // its 16 cycles): issued in one go they cost every wave ~0.5 k cycles per chunk in front of its first MFMA, in step on
+      // all waves of the CU.  (No dead load past the last chunk: nothing would ever wait for it - see below the loop.)
+      const bool more_w = c + (NXS == 3 ? 2 : 1) < NCH, more_x = c + NXS - 1 < NCH;
       lds_u8_t xb0 = (lds_u8_t)win + (c % NXS) * XSTAGE + xlane;
       lds_u8_t xb1 = (lds_u8_t)win + (c % NXS) * XSTAGE + (xlane ^ 64u);
       asm volatile("" : "+v"(xb0), "+v"(xb1));
@@ -254,7 +263,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_bneck_kernel(BneckArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[j][t] = mfma16<DT_F16>(w[ks][t], fr[u % DEPTH], acc[j][t]);
         __builtin_amdgcn_sched_barrier(0);
-        if (u < 2) {
+        if (NXS == 3) {
+          if (more_x && u < DI) dma_piece(c + 2, (c + 2) % NXS, u);
+          if (more_w && u == MT1 - 1) load_w_ks(w, c + 2, 0);
+          if (more_w && u == UNITS - 1) load_w_ks(w, c + 2, 1);
+        } else if (u < 2) {
           if (more_w) load_w_ks(wnext, c + 1, u);
         } else if (u < 2 + DI) {
           if (more_x) dma_piece(c + NXS - 1, (c + NXS - 1) % NXS, u - 2);
