@@ -12,6 +12,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 export SPK_TUNE_CACHE=$PWD/gpurun_out/tune_${TAG}.txt
 rm -f $SPK_TUNE_CACHE
+# start from the shipped tuner seed - what a fresh box (the driver's) starts from - and tune whatever it does not list
+grep -v "^#" syke-pic_amd/sykepic_hip/tune_seed_gfx950.txt > $SPK_TUNE_CACHE
 python3 bench.py --mode both --no-cpu-baseline --steps 3 --warmup 2 > gpurun_out/${TAG}_warm.json 2> gpurun_out/${TAG}_warm.err
 cp $SPK_TUNE_CACHE gpurun_out/${TAG}_tune_cache.txt
 python3 bench.py --layers-out gpurun_out/${TAG}_infer_calibrated_layers.json > gpurun_out/${TAG}_bench_line.json 2> gpurun_out/${TAG}_bench_line.err
@@ -53,3 +55,8 @@ S=$(find gpurun_out/pmc_${TAG}_sq -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_mfma.py "$S" gpurun_out/${TAG}_pmc_mfma_util_infer_calibrated.json > gpurun_out/${TAG}_pmc_mfma.log
 rm -rf gpurun_out/pmc_${TAG}_sq
 tail -n 4 gpurun_out/${TAG}_pmc_traffic_infer.log; tail -n 4 gpurun_out/${TAG}_pmc_mfma.log
+# per-kernel SQ counters (three --pmc passes, one stream): wave-cycle split, issue mix, LDS bank conflicts
+unset SPK_EVAL_STREAMS SPK_WGRAD_STREAM
+SPK_EVAL_STREAMS=1 bash tools/pmc_sq.sh ${TAG}_infer --mode infer > gpurun_out/${TAG}_sq.log 2>&1
+python3 tools/pmc_sq_table.py ${TAG}_infer > gpurun_out/${TAG}_sq_counters_infer_calibrated.txt 2>> gpurun_out/${TAG}_sq.log || echo "sq table failed"
+python3 tools/layer_roofs.py gpurun_out/${TAG}_infer_calibrated_layers.json > gpurun_out/${TAG}_infer_layer_roofs.txt

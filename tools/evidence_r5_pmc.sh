@@ -7,6 +7,8 @@ export TMPDIR=/tmp
 mkdir -p gpurun_out
 export SPK_TUNE_CACHE=$PWD/gpurun_out/tune_${TAG}.txt
 rm -f $SPK_TUNE_CACHE
+# start from the shipped tuner seed - what a fresh box (the driver's) starts from - and tune whatever it does not list
+grep -v "^#" syke-pic_amd/sykepic_hip/tune_seed_gfx950.txt > $SPK_TUNE_CACHE
 python3 bench.py --mode both --no-cpu-baseline --steps 3 --warmup 2 > gpurun_out/${TAG}_warm.json 2> gpurun_out/${TAG}_warm.err
 export SPK_EVAL_STREAMS=1
 export SPK_WGRAD_STREAM=0
