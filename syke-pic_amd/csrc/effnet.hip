@@ -330,12 +330,23 @@ __global__ __launch_bounds__(256) void se_fc1_kernel(const float* __restrict__ p
         av[im] = im < nim ? a : 0.f;
       }
     } else {
+      // run-time count (a half batch of 64 images on the 112^2 / 56^2 stages: 5 ... 16 rows): four rows x IPB images in
+      // flight per step, added in row order as before.  One row at a time this path was a chain of `chunks` L2 round trips:
+      // 55-67 us per launch, six launches per EfficientNet-B4 half batch (0.37 of its 4.5 ms).
 #pragma unroll
-      for (int im = 0; im < SE_IPB; ++im) {
-        float a = 0.f;
-        if (im < nim)
-          for (int k = 0; k < chunks; ++k) a += partial[((size_t)(img0 + im) * chunks + k) * c_p + i];
-        av[im] = a;
+      for (int im = 0; im < SE_IPB; ++im) av[im] = 0.f;
+      for (int k0 = 0; k0 < chunks; k0 += 4) {
+        float pv[SE_IPB][4];
+#pragma unroll
+        for (int im = 0; im < SE_IPB; ++im)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)   // indices clamped: every load is issued, the surplus is dropped below
+            pv[im][u] = partial[((size_t)(img0 + min(im, nim - 1)) * chunks + min(k0 + u, chunks - 1)) * c_p + i];
+#pragma unroll
+        for (int im = 0; im < SE_IPB; ++im)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (k0 + u < chunks && im < nim) av[im] += pv[im][u];
       }
     }
 #pragma unroll
