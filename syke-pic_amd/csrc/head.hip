@@ -6,6 +6,7 @@
 // stays in exact fp32 (LDS-tiled FMA GEMM) — this keeps the logits' error
 // budget for the bf16 backbone.
 #include "spk_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -61,6 +62,51 @@ __global__ __launch_bounds__(256) void sgemm_strided_kernel(
       float* c = C + gi * sci + gj * scj;
       *c = accumulate ? *c + r : r;
     }
+  }
+}
+
+// The same product on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32: an fmaf chain per output, k ascending) for ANY strides:
+// a wave owns a 16 x 16 output tile, a block 2 x 2 of them; per 4-deep K step a lane supplies ONE element of each operand
+// (row lane & 15, k = k0 + (lane >> 4)) - with a unit stride along the rows (the weight-gradient form: A = dY^T, B = X^T,
+// K = the batch) the 16 lanes of a k read 64 contiguous bytes.  Eight K steps of loads in flight.  The head's backward
+// GEMMs (2048 x 256 x 256 and smaller) took 37 us each on the LDS-tiled FMA kernel above, 0.22 ms of a ResNet-50 step.
+__global__ __launch_bounds__(256) void sgemm_mfma_strided_kernel(
+    const float* __restrict__ A, long sai, long sak, const float* __restrict__ B, long sbj, long sbk,
+    const float* __restrict__ bias, float* __restrict__ C, long sci, long scj, int M, int N, int K,
+    float alpha, int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int i0 = blockIdx.y * 32 + (wave >> 1) * 16, j0 = blockIdx.x * 32 + (wave & 1) * 16;
+  if (i0 >= M || j0 >= N) return;
+  const float* pa = A + (long)min(i0 + r, M - 1) * sai;   // (rows past the edge: clamped, their outputs are not stored)
+  const float* pb = B + (long)min(j0 + r, N - 1) * sbj;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;
+  for (int k0 = 0; k0 < K; k0 += 4 * U) {
+    float va[U], vb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + 4 * u + g;
+      const bool ok = k < K;
+      const int kc = ok ? k : K - 1;
+      va[u] = pa[(long)kc * sak];
+      vb[u] = pb[(long)kc * sbk];
+      if (!ok) va[u] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(va[u], vb[u], acc, 0, 0, 0);
+  }
+  // C layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+  const int gj = j0 + r;
+  if (gj >= N) return;
+  const float bj = bias ? bias[gj] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int gi = i0 + g * 4 + e;
+    if (gi >= M) continue;
+    float* c = C + gi * sci + gj * scj;
+    const float v = acc[e] * alpha + bj;
+    *c = accumulate ? *c + v : v;
   }
 }
 
@@ -235,6 +281,12 @@ int spk_launch_predict(const float* p, int n, int c, const float* thr, float sca
 int spk_launch_sgemm(const float* A, long sai, long sak, const float* B, long sbj, long sbk,
                      const float* bias, float* C, long sci, long scj, int M, int N, int K,
                      float alpha, int accumulate, hipStream_t s) {
+  static const bool fma = getenv("SPK_SGEMM_FMA") && atoi(getenv("SPK_SGEMM_FMA")) != 0;   // the LDS-tiled FMA kernel (A/B runs)
+  if (!fma) {
+    hipLaunchKernelGGL(sgemm_mfma_strided_kernel, dim3((N + 31) / 32, (M + 31) / 32), dim3(256), 0, s, A, sai, sak, B, sbj, sbk,
+                       bias, C, sci, scj, M, N, K, alpha, accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+  }
   dim3 grid((N + 63) / 64, (M + 63) / 64);
   hipLaunchKernelGGL(sgemm_strided_kernel, grid, dim3(256), 0, s, A, sai, sak, B, sbj, sbk, bias, C,
                      sci, scj, M, N, K, alpha, accumulate);
