@@ -128,8 +128,12 @@ def test_trained_efficientnet_b0_fp16_calibrated_and_fp8():
     """The fp16 EfficientNet path sits at p90 1.4e-3 / max 4.6e-3 on random-weight nets (tests/test_gpu_effnet.py).  On a net
     whose BatchNorm statistics describe its data - and with the input stored as exact pixel values - it holds the
     reference's tolerance with a wide margin: measured max 2.0e-4, p90 5.8e-5, median 1.5e-5 over 256 fresh images, top-1
-    identical on all of them (before the exact input: 1.3e-3 / 3.7e-4 / 8e-5).  Asserted: max <= 5e-4.  fp8 (e4m3 inside
-    the MBConv blocks) is judged on top-1 of decided images: a throughput mode, not a drop-in one."""
+    identical on all of them (before the exact input: 1.3e-3 / 3.7e-4 / 8e-5).  The worst image of the 256 depends on the
+    training trajectory: the net is trained HERE, by the HIP path, and the kernel tuner's tile choices - made per box - group
+    the BatchNorm partial sums differently, so every box trains another, equally valid net.  Seen over the runs of rounds
+    4-5: fp16 2.0e-4 ... 3.5e-4, calibrated 2.0e-4 ... 6.6e-4, p90 6e-5 ... 9e-5, median 1.5e-5 ... 2.7e-5.  Asserted: max <= 8e-4
+    (the reference's tolerance is 1e-3), p90 <= 2e-4, median <= 5e-5.  fp8 (e4m3 inside the MBConv blocks) is judged on
+    top-1 of decided images: a throughput mode, not a drop-in one."""
     from oracle import refnet
     net, acc = train_hip("efficientnet_b0", 400, 2e-3, seed=12)
     ref = refnet.RefNet("efficientnet_b0", CLASSES, head=(64, 32))
@@ -154,7 +158,7 @@ def test_trained_efficientnet_b0_fp16_calibrated_and_fp8():
     res["fp8"] = compare(net, ref, x, "fp8 (e4m3 MBConv interior)")
     net.set_fp8(False)
     for mode in ("fp16", "precise", "calibrated"):
-        assert res[mode]["max"] <= 5e-4 and res[mode]["p90"] <= 2e-4 and res[mode]["median"] <= 5e-5, (mode, res[mode])
+        assert res[mode]["max"] <= 8e-4 and res[mode]["p90"] <= 2e-4 and res[mode]["median"] <= 5e-5, (mode, res[mode])
         assert res[mode]["top1_decided"] == 1.0, (mode, res[mode])
     assert res["fp8"]["top1_decided"] >= 0.99 and res["fp8"]["p90"] <= 1.5e-2, res["fp8"]
 
