@@ -272,7 +272,7 @@ int launch_c3(const C3Args& a, hipStream_t s) {
 }  // namespace
 
 // cfg: pixel tiles per wave x waves per pair
-int spk_c3_num_configs() { return 11; }
+int spk_c3_num_configs() { return 14; }
 int spk_c3_launch(const C3Args& a, int cfg, hipStream_t s) {
   if (a.Cin % 64 || a.Cout % 64 || a.M <= 0 || a.dt != DT_F16) return -2;
   if ((size_t)a.M * a.Cout * 2 >= 0x80000000ull || (size_t)a.x_bytes >= 0x80000000ull) return -2;
@@ -290,6 +290,10 @@ int spk_c3_launch(const C3Args& a, int cfg, hipStream_t s) {
     case 8: return a.Cout >= 256 ? -3 : C3_GO(4, 4);    // 256 px x 64 couts
     case 9: return a.Cout >= 256 ? -3 : C3_GO(6, 4);    // 384 px x 64 couts
     case 10: return a.Cout >= 256 ? -3 : C3_GO(7, 2);   // 224 px x 128 couts
+    // small pixel tiles for the 7 x 7 maps of a half batch (6272 pixels: 56 tiles of 112 fill a fifth of the chip's waves)
+    case 11: return a.Cout < 256 ? -3 : C3_GO(4, 1);    // 64 px x 256 couts
+    case 12: return a.Cout < 256 ? -3 : C3_GO(3, 1);    // 48 px x 256 couts
+    case 13: return a.Cout < 256 ? -3 : C3_GO(5, 1);    // 80 px x 256 couts
     default: return -3;
   }
 #undef C3_GO
